@@ -1,0 +1,236 @@
+"""ctypes binding of libdyd_gfx950.so (C ABI: include/dyd.h).
+
+This is the thin layer between the Python host code and the HIP kernels.  It has NO CPU
+fallback: a missing library or a missing gfx950 device raises ``NativeUnavailable`` the
+first time a device stage is requested.
+
+Numpy-facing helpers (``bbox_minmax`` ...) use the host-pointer entry points (the library
+stages H2D/D2H); ``lib()`` exposes the raw ``_dev`` entry points for callers that keep data
+resident in HBM (bench.py, the distributed path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libdyd_gfx950.so")
+
+KEEP_FIRST, KEEP_LAST, KEEP_NONE = 0, 1, 2
+_KEEP = {"first": KEEP_FIRST, "last": KEEP_LAST, False: KEEP_NONE}
+
+_lock = threading.Lock()
+_lib = None
+_ready = False
+
+
+class NativeUnavailable(RuntimeError):
+    """libdyd_gfx950.so could not be loaded or no gfx950 device is usable."""
+
+
+class NativeError(RuntimeError):
+    """An entry point of libdyd_gfx950.so returned an error code."""
+
+
+_c = C
+_dp, _i32p, _i64p, _u8p, _u64p = (C.POINTER(t) for t in (C.c_double, C.c_int32, C.c_int64, C.c_uint8, C.c_uint64))
+
+# name -> (restype, argtypes); mirrors include/dyd.h line by line
+SIGNATURES = {
+    "dyd_init": (C.c_int, [C.c_int]),
+    "dyd_shutdown": (None, []),
+    "dyd_last_error": (C.c_char_p, []),
+    "dyd_device_count": (C.c_int, []),
+    "dyd_version": (C.c_char_p, []),
+    "dyd_device_name": (C.c_char_p, []),
+    "dyd_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "dyd_free": (C.c_int, [C.c_void_p]),
+    "dyd_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dyd_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dyd_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    "dyd_sync": (C.c_int, [C.c_void_p]),
+    "dyd_last_kernel_ms": (C.c_double, []),
+    "dyd_bbox_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dyd_bbox_minmax_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_iou_any_ge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
+    "dyd_iou_any_ge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "dyd_bbox_iou_fused_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                         C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_hash128": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dyd_hash128_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dyd_dedup": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dyd_dedup_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "dyd_isin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dyd_isin_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dyd_dedup_global_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "dyd_mt19937_permutation": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p]),
+    "dyd_split_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                C.c_void_p, C.c_void_p]),
+    "dyd_split_ids_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libdyd_gfx950.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j8"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("building libdyd_gfx950.so failed:\n" + out.stdout)
+    if verbose:
+        print(out.stdout)
+    return LIB_PATH
+
+
+def load_library():
+    """dlopen the library and declare every prototype.  Does not touch the GPU."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeUnavailable(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C deal-yolo-daya_amd/csrc`).  There is no CPU fallback.")
+            try:
+                lib_ = C.CDLL(LIB_PATH)
+            except OSError as e:
+                raise NativeUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib_, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib_
+    return _lib
+
+
+def lib():
+    """The loaded library with an initialised device context (raises if there is no gfx950)."""
+    global _ready
+    l = load_library()
+    if not _ready:
+        with _lock:
+            if not _ready:
+                dev = int(os.environ.get("DYD_DEVICE", "-1"))
+                rc = l.dyd_init(dev)
+                if rc != 0:
+                    raise NativeUnavailable(
+                        "dyd_init failed: " + l.dyd_last_error().decode("utf-8", "replace")
+                        + " — the HIP device stage is required; there is no CPU fallback.")
+                _ready = True
+    return l
+
+
+def available() -> bool:
+    try:
+        lib()
+        return True
+    except NativeUnavailable:
+        return False
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what} failed ({rc}): " + load_library().dyd_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_name() -> str:
+    return lib().dyd_device_name().decode()
+
+
+def last_kernel_ms() -> float:
+    return float(load_library().dyd_last_kernel_ms())
+
+
+# ------------------------------------------------------------------ numpy-facing helpers
+def bbox_minmax(xy: np.ndarray, pt_off: np.ndarray):
+    """K1 over host arrays: returns (box4 [B,4] f64, arg4 [B,4] i32)."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    pt_off = np.ascontiguousarray(pt_off, dtype=np.int32)
+    nb = len(pt_off) - 1
+    if nb < 0 or (nb >= 0 and (pt_off[0] != 0 or 2 * int(pt_off[-1]) != xy.size)):
+        raise ValueError("pt_off must start at 0 and end at the number of points")
+    box = np.empty((nb, 4), np.float64)
+    arg = np.empty((nb, 4), np.int32)
+    check(lib().dyd_bbox_minmax(_ptr(xy), _ptr(pt_off), nb, _ptr(box), _ptr(arg)), "dyd_bbox_minmax")
+    return box, arg
+
+
+def iou_any_ge(box4: np.ndarray, row_off: np.ndarray, min_boxes: int, thr: float, want_max: bool = False):
+    """K2 over host arrays: HIGH flag per row (and the max pair IoU when ``want_max``)."""
+    box4 = np.ascontiguousarray(box4, dtype=np.float64).reshape(-1)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int32)
+    n = len(row_off) - 1
+    if n < 0 or row_off[0] != 0 or 4 * int(row_off[-1]) != box4.size:
+        raise ValueError("row_off must start at 0 and end at the number of boxes")
+    high = np.empty(n, np.uint8)
+    mx = np.empty(n, np.float64) if want_max else None
+    check(lib().dyd_iou_any_ge(_ptr(box4), _ptr(row_off), n, int(min_boxes), float(thr), _ptr(high),
+                               _ptr(mx) if want_max else None), "dyd_iou_any_ge")
+    return (high, mx) if want_max else high
+
+
+def hash128(data: np.ndarray, off: np.ndarray) -> np.ndarray:
+    """K3 over host arrays: [n,2] u64."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    n = len(off) - 1
+    if n < 0 or off[0] != 0 or int(off[-1]) != data.size:
+        raise ValueError("off must start at 0 and end at len(bytes)")
+    out = np.empty((n, 2), np.uint64)
+    check(lib().dyd_hash128(_ptr(data) if data.size else None, _ptr(off), n, _ptr(out)), "dyd_hash128")
+    return out
+
+
+def dedup(h: np.ndarray, keep) -> np.ndarray:
+    """K4 over host arrays: keep-mask (uint8) for keep in {"first", "last", False}."""
+    if keep not in _KEEP:
+        raise ValueError('keep must be either "first", "last" or False')
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty(len(h), np.uint8)
+    check(lib().dyd_dedup(_ptr(h), len(h), _KEEP[keep], _ptr(out)), "dyd_dedup")
+    return out
+
+
+def isin(h: np.ndarray, ref_h: np.ndarray) -> np.ndarray:
+    """K5 over host arrays."""
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+    ref_h = np.ascontiguousarray(ref_h, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty(len(h), np.uint8)
+    check(lib().dyd_isin(_ptr(h), len(h), _ptr(ref_h) if len(ref_h) else None, len(ref_h), _ptr(out)), "dyd_isin")
+    return out
+
+
+def mt19937_permutation(seed: int, n: int) -> np.ndarray:
+    """Host code inside the library: numpy legacy RandomState(seed).permutation(n)."""
+    if not (0 <= int(seed) <= 2 ** 32 - 1):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")   # numpy's message (mtrand legacy seeding)
+    out = np.empty(int(n), np.int64)
+    check(load_library().dyd_mt19937_permutation(int(seed), int(n), _ptr(out)), "dyd_mt19937_permutation")
+    return out
+
+
+def split_ids(cat, perm_concat, cat_off, n_train, n_val):
+    """K6 over host arrays: (split u8, pos i64)."""
+    cat = np.ascontiguousarray(cat, dtype=np.int32)
+    perm_concat = np.ascontiguousarray(perm_concat, dtype=np.int64)
+    cat_off = np.ascontiguousarray(cat_off, dtype=np.int64)
+    n_train = np.ascontiguousarray(n_train, dtype=np.int64)
+    n_val = np.ascontiguousarray(n_val, dtype=np.int64)
+    n_cat = len(n_train)
+    if len(cat_off) != n_cat + 1 or len(n_val) != n_cat or int(cat_off[-1]) != len(perm_concat):
+        raise ValueError("cat_off / n_train / n_val / perm sizes disagree")
+    split = np.empty(len(cat), np.uint8)
+    pos = np.empty(len(cat), np.int64)
+    check(lib().dyd_split_ids(_ptr(cat), len(cat), _ptr(perm_concat), _ptr(cat_off), _ptr(n_train), _ptr(n_val),
+                              n_cat, _ptr(split), _ptr(pos)), "dyd_split_ids")
+    return split, pos

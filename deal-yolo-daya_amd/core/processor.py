@@ -1,0 +1,490 @@
+"""Drop-in step functions of the annotation hot path, MI355X-native.
+
+Same names, positional signatures, return values, printed log lines and error behaviour as
+the five hot-path functions of the reference's ``src/deal_yolo_data/core/processor.py`` — the
+Streamlit page imports them by name (reference ui/pages/processing.py:25-38) and calls them
+positionally through ``run_step`` (:548, :566, :584, :598, :630):
+
+    deduplicate_csv_by_source        reference processor.py:111-164   -> K3 + K4
+    remove_duplicates_between_csv    reference processor.py:166-219   -> K3 + K5
+    process_csv_replace_ptlist       reference processor.py:229-319   -> K1
+    filter_by_box_count_and_iou      reference processor.py:321-407   -> K2
+    split_dataset_by_rules           reference processor.py:654-831   -> K6 (+ host MT19937)
+
+Each step is  flatten (cells -> SoA numpy buffers)  ->  device stage (HIP kernels behind
+include/dyd.h)  ->  emit (masks / indices back into pandas).  Every step also has a
+DataFrame-level twin (``*_frame``) that skips the CSV hand-off.  The device stage is
+mandatory: without libdyd_gfx950.so and a gfx950 GPU the steps raise (``_native``).
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import pandas as pd
+
+from .. import flatten as _fl
+from ..backend import resolve as _backend
+from .utils import _parse_data_objects, _split_label_cell, _split_object_labels, safe_filename
+
+ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference processor.py:244
+BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
+_CHUNK_CELLS = 1 << 18                               # cells flattened per device batch
+
+
+# =============================================================================== a1  dedup
+def dedup_keep_mask(col: pd.Series, keep="first", backend=None) -> np.ndarray:
+    """Boolean keep-mask of ``drop_duplicates(keep=keep)`` on one key column: K3 hash, K4 mask."""
+    if keep not in ("first", "last", False):
+        raise ValueError('keep must be either "first", "last" or False')       # pandas' own message
+    be = _backend(backend)
+    if len(col) == 0:
+        return np.zeros(0, bool)
+    data, off, na = _fl.column_key_bytes(col)
+    h = be.hash128(data, off)
+    if na.any():
+        h[na] = _fl.NA_KEY                              # all missing cells are one key (NaN == NaN)
+    return be.dedup(h, keep).astype(bool)
+
+
+def dedup_frame(df: pd.DataFrame, keep="first", backend=None) -> pd.DataFrame:
+    """In-memory twin of the dedup step: rows in original order, index reset (:140-144)."""
+    mask = dedup_keep_mask(df["source"], keep, backend)
+    return df[mask].reset_index(drop=True)
+
+
+def deduplicate_csv_by_source(
+        csv_path: str,
+        output_file: Optional[str] = "deduplicate_result.csv",
+        encoding: str = "utf-8-sig",
+        keep: str = "first",
+        verbose: bool = True,
+        backend=None,
+) -> pd.DataFrame:
+    if not os.path.exists(csv_path):
+        raise FileNotFoundError(f"CSV文件不存在：{csv_path}")
+    if not csv_path.endswith(".csv"):
+        raise ValueError(f"文件不是CSV格式：{csv_path}（请传入.csv后缀的文件）")
+    try:
+        df = pd.read_csv(csv_path, encoding=encoding, parse_dates=False)
+    except Exception as e:
+        raise Exception(f"读取CSV文件失败：{str(e)}") from e
+    if verbose:
+        print(f"成功读取CSV文件：{os.path.basename(csv_path)}")
+        print(f"读取后原始数据行数：{len(df)}")
+    if "source" not in df.columns:
+        raise KeyError(f"CSV文件中未找到'source'列，请检查列名是否正确（当前列名：{list(df.columns)}）")
+
+    result = dedup_frame(df, keep, backend)
+    if verbose:
+        print(f"去重策略：按'source'列保留{keep}条数据")
+        print(f"去除重复数据行数：{len(df) - len(result)}")
+        print(f"去重后剩余数据行数：{len(result)}")
+
+    if output_file is not None:
+        try:
+            parent = os.path.dirname(output_file)
+            if parent:
+                os.makedirs(parent, exist_ok=True)
+            result.to_csv(output_file, index=False, encoding=encoding)
+        except Exception as e:
+            raise Exception(f"保存去重文件失败：{str(e)}") from e
+        if verbose:
+            print(f"去重后的文件已保存至：{os.path.abspath(output_file)}")
+    return result
+
+
+# =============================================================================== a2  reference filter
+def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None) -> np.ndarray:
+    """``main.astype(str).isin(set(ref.dropna().astype(str)))`` (:194-198): K3 on both, K5."""
+    be = _backend(backend)
+    if len(main_col) == 0:
+        return np.zeros(0, bool)
+    md, mo = _fl.column_str_bytes(main_col)
+    rd, ro = _fl.column_str_bytes(ref_col, drop_na=True)
+    hm = be.hash128(md, mo)
+    hr = be.hash128(rd, ro) if len(ro) > 1 else np.zeros((0, 2), np.uint64)
+    return be.isin(hm, hr).astype(bool)
+
+
+def ref_filter_frame(df_main: pd.DataFrame, df_ref: pd.DataFrame, compare_col: str = "source",
+                     backend=None) -> pd.DataFrame:
+    hit = ref_hit_mask(df_main[compare_col], df_ref[compare_col], backend)
+    return df_main[~hit].copy()
+
+
+def remove_duplicates_between_csv(
+        main_csv: str,
+        ref_csv: str,
+        output_csv: str = "filtered_main.csv",
+        compare_col: str = "source",
+        encoding: str = "utf-8-sig",
+        verbose: bool = True,
+        backend=None,
+) -> pd.DataFrame:
+    for path in (main_csv, ref_csv):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"文件不存在：{path}")
+        if not path.endswith(".csv"):
+            raise ValueError(f"文件不是CSV格式：{path}（请传入.csv后缀文件）")
+    try:
+        df_main = pd.read_csv(main_csv, encoding=encoding, parse_dates=False)
+        df_ref = pd.read_csv(ref_csv, encoding=encoding, parse_dates=False)
+    except Exception as e:
+        raise Exception(f"读取CSV失败：{str(e)}") from e
+    if verbose:
+        print(f"读取主文件：{len(df_main)}行")
+        print(f"读取参考文件：{len(df_ref)}行")
+    if compare_col not in df_main.columns:
+        raise KeyError(f"主文件中未找到列 '{compare_col}'")
+    if compare_col not in df_ref.columns:
+        raise KeyError(f"参考文件中未找到列 '{compare_col}'")
+
+    kept = ref_filter_frame(df_main, df_ref, compare_col, backend)
+    if verbose:
+        print(f"去重依据列：{compare_col}")
+        print(f"参考文件中唯一值数量：{df_ref[compare_col].dropna().astype(str).nunique()}")
+        print(f"剔除重复行数：{len(df_main) - len(kept)}")
+        print(f"保留行数：{len(kept)}")
+    try:
+        parent = os.path.dirname(output_csv)
+        if parent:
+            os.makedirs(parent, exist_ok=True)
+        kept.to_csv(output_csv, index=False, encoding=encoding)
+    except Exception as e:
+        raise Exception(f"保存结果失败：{str(e)}") from e
+    if verbose:
+        print(f"结果已保存至：{os.path.abspath(output_csv)}")
+    return kept
+
+
+# =============================================================================== a3  polygon -> bbox
+def replace_ptlist_cells(cells, backend=None, stats: Optional[dict] = None) -> tuple:
+    """(new JSON text or None, width, height) per annotation cell: flatten -> K1 -> emit."""
+    be = _backend(backend)
+    cells = list(cells)
+    texts, widths, heights = [], [], []
+    totals = {"cells": 0, "boxes": 0, "points": 0, "host_boxes": 0}
+    for start in range(0, len(cells), _CHUNK_CELLS):
+        batch = _fl.flatten_polygons(cells[start:start + _CHUNK_CELLS])
+        if len(batch.pt_off) > 1:
+            _, arg4 = be.bbox_minmax(batch.xy, batch.pt_off)
+        else:
+            arg4 = np.zeros((0, 4), np.int32)
+        texts.extend(_fl.emit_polygons(batch, arg4))
+        for doc in batch.docs:                         # :285-292 (doc is a dict here, or the step raised)
+            widths.append(doc.get("width") if doc is not None else None)
+            heights.append(doc.get("height") if doc is not None else None)
+        for k in totals:
+            totals[k] += batch.stats[k]
+    if stats is not None:
+        stats.update(totals)
+    return texts, widths, heights
+
+
+def replace_ptlist_frame(df: pd.DataFrame, backend=None, stats: Optional[dict] = None):
+    """In-memory twin of the replace step -> (kept frame with the three new columns, excluded rows)."""
+    kept = df.dropna(subset=[ANNOTATION_COL]).copy()               # :249
+    excluded = df[df[ANNOTATION_COL].isna()].copy()                # :250
+    texts, widths, heights = replace_ptlist_cells(kept[ANNOTATION_COL].tolist(), backend, stats)
+    kept[BBOX_COL] = pd.Series(texts, index=kept.index, dtype=object)
+    kept["width"] = widths
+    kept["height"] = heights
+    return kept, excluded
+
+
+def process_csv_replace_ptlist(
+        input_csv_path: str,
+        output_csv_path: str = "processed_replaced_ptlist.csv",
+        excluded_output_file: Optional[str] = "processed_excluded.csv",
+        backend=None,
+):
+    try:
+        df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+        print(f"成功读取CSV，共 {len(df)} 行数据")
+    except FileNotFoundError:
+        print(f"错误：未找到文件 {input_csv_path}")
+        return None
+    except Exception as e:
+        print(f"读取失败：{e}")
+        return None
+    if ANNOTATION_COL not in df.columns:
+        print(f"错误：CSV缺少列 '{ANNOTATION_COL}'")
+        return None
+
+    kept, excluded = replace_ptlist_frame(df, backend)
+    wanted = ["source", ANNOTATION_COL, BBOX_COL, "width", "height"]       # :298-306
+    Path(output_csv_path).parent.mkdir(parents=True, exist_ok=True)
+    kept[[c for c in wanted if c in kept.columns]].to_csv(output_csv_path, index=False, encoding="utf-8-sig")
+    if excluded_output_file is not None:
+        Path(excluded_output_file).parent.mkdir(parents=True, exist_ok=True)
+        excluded.to_csv(excluded_output_file, index=False, encoding="utf-8-sig")
+    return {
+        "filtered_rows": len(kept),
+        "excluded_rows": len(excluded),
+        "excluded_output": excluded_output_file,
+    }
+
+
+# =============================================================================== a4  IoU filter
+def iou_high_mask(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
+                  stats: Optional[dict] = None) -> np.ndarray:
+    """HIGH flag per bbox-JSON cell (:392-398): flatten -> K2."""
+    be = _backend(backend)
+    cells = list(cells)
+    out = np.zeros(len(cells), bool)
+    totals = {"rows": 0, "boxes": 0, "host_rows": 0}
+    for start in range(0, len(cells), _CHUNK_CELLS):
+        batch = _fl.flatten_boxes(cells[start:start + _CHUNK_CELLS])
+        n = len(batch.row_off) - 1
+        if n:
+            out[start:start + n] = be.iou_any_ge(batch.box4, batch.row_off, min_boxes, iou_threshold).astype(bool)
+        for ri, boxes in batch.host_rows.items():
+            out[start + ri] = _fl.host_row_is_high(boxes, min_boxes, iou_threshold)
+        for k in totals:
+            totals[k] += batch.stats[k]
+    if stats is not None:
+        stats.update(totals)
+    return out
+
+
+def iou_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
+                     stats: Optional[dict] = None):
+    """In-memory twin of the IoU step -> (high frame, other frame), rows in original order."""
+    mask = iou_high_mask(df[BBOX_COL].tolist(), min_boxes, iou_threshold, backend, stats)
+    return df[mask], df[~mask]
+
+
+def filter_by_box_count_and_iou(
+        input_csv_path,
+        high_iou_csv="high_iou_0.98.csv",
+        other_csv="other_data.csv",
+        min_boxes: int = 2,
+        iou_threshold: float = 0.98,
+        backend=None,
+):
+    try:
+        df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    except Exception as e:
+        print(f"读取失败：{e}")
+        return
+    if BBOX_COL not in df.columns:
+        print(f"错误：缺少必要列 {BBOX_COL}")
+        return
+    high, other = iou_filter_frame(df, min_boxes, iou_threshold, backend)
+    Path(high_iou_csv).parent.mkdir(parents=True, exist_ok=True)
+    Path(other_csv).parent.mkdir(parents=True, exist_ok=True)
+    high.to_csv(high_iou_csv, index=False, encoding="utf-8-sig")
+    other.to_csv(other_csv, index=False, encoding="utf-8-sig")
+
+
+# =============================================================================== a5  split
+def rules_to_label_map(rules_df: pd.DataFrame, rule_mode: str = "wide", label_col=None, category_col=None) -> dict:
+    """label -> category from the rules sheet (:688-703); later entries overwrite earlier ones."""
+    mapping = {}
+    if rule_mode == "wide":
+        for column in rules_df.columns:
+            category = str(column).strip()
+            if not category:
+                continue
+            for cell in rules_df[column].dropna():
+                for label in _split_label_cell(cell):
+                    mapping[label] = category
+    elif rule_mode == "two_column":
+        for _, rule in rules_df.iterrows():
+            label = str(rule.get(label_col, "")).strip()
+            category = str(rule.get(category_col, "")).strip()
+            if label and category and label.lower() != "nan" and category.lower() != "nan":
+                mapping[label] = category
+    return mapping
+
+
+def split_cut_sizes(n: int, train_ratio: float, val_ratio: float, test_ratio: float) -> tuple:
+    """(n_train, n_val) = (int(n*tr), int(n*va)) after normalising the ratios by their sum (:673-676, :802-803)."""
+    total = train_ratio + val_ratio + test_ratio
+    train_ratio /= total
+    val_ratio /= total
+    return int(n * train_ratio), int(n * val_ratio)
+
+
+def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Optional[list] = None,
+                 train_ratio: float = 0.8, val_ratio: float = 0.1, test_ratio: float = 0.1,
+                 random_seed: int = 42, backend=None) -> dict:
+    """In-memory twin of the split step (no Excel I/O).
+
+    Host: expand every row into one record per (object, label in the rules), in object-then-label
+    order (:741-775).  Device: K6 ranks each record inside its category, applies the MT19937
+    permutation of ``sample(frac=1, random_state=seed)`` and assigns train/val/test (:800-806).
+
+    -> {"categories": {cat: (train, val, test)}, "unclassified": frame, "split_counts": frame,
+        "category_counts": {cat: n}, "expanded": {src_row, category_id, position, split}}"""
+    be = _backend(backend)
+    if json_columns is None:                                        # :680-685
+        json_columns = [c for c in (BBOX_COL, ANNOTATION_COL) if c in df.columns]
+    present_json = [c for c in json_columns if c in df.columns]
+
+    categories: dict = {}                 # category -> id, in first-appearance order (:773 dict order)
+    src_row, cat_id, new_json, new_label, new_combo = [], [], [], [], []
+    unclassified, counts = [], []         # (row position, reason, label-or-None) ; split_counts records
+    cols = list(df.columns)
+    col_pos = {c: i for i, c in enumerate(cols)}
+    values = df.to_numpy(dtype=object) if len(df) else np.empty((0, len(cols)), object)
+    source_pos = col_pos.get("source")
+
+    for ri in range(len(df)):
+        cell = None
+        for c in json_columns:
+            if c in col_pos:
+                v = values[ri, col_pos[c]]
+                if isinstance(v, str) and v:
+                    cell = v
+                    break
+        doc, objs, err = _parse_data_objects(cell)
+        src = values[ri, source_pos] if source_pos is not None else None
+        if err or not objs:
+            reason = err or "标注字段objects为空"
+            unclassified.append((ri, reason, None))
+            counts.append({"source": src, "原始标签组合": "", "拆分条数": 0, "是否可分类": "否", "无法分类原因": reason})
+            continue
+        seen = set()
+        for o in objs:
+            if isinstance(o, dict) and o.get("name"):
+                seen.update(_split_object_labels(o.get("name")))
+        combo = "，".join(sorted(seen)) if seen else ""
+        n_out, reasons = 0, set()
+        for o in objs:
+            if not isinstance(o, dict):
+                continue
+            labels = _split_object_labels(o.get("name"))
+            if not labels:
+                unclassified.append((ri, "标注框缺少name字段", None))
+                continue
+            for label in labels:
+                if label not in label_to_category:
+                    why = f"标签{label}未在规则中定义"
+                    unclassified.append((ri, why, label))
+                    reasons.add(why)
+                    continue
+                category = label_to_category[label]
+                single = copy.deepcopy(o)
+                single["name"] = label
+                slim = {k: v for k, v in doc.items() if k != "objects"}
+                slim["objects"] = [single]
+                src_row.append(ri)
+                cat_id.append(categories.setdefault(category, len(categories)))
+                new_json.append(json.dumps(slim, ensure_ascii=False))
+                new_label.append(label)
+                new_combo.append(combo)
+                n_out += 1
+        if n_out == 0:
+            unclassified.append((ri, "；".join(sorted(reasons)) if reasons else "标签无法匹配规则", None))
+        status = "否" if n_out == 0 else ("部分可分类" if reasons else "是")
+        counts.append({"source": src, "原始标签组合": combo, "拆分条数": n_out, "是否可分类": status,
+                       "无法分类原因": "；".join(sorted(reasons))})
+
+    # ---- device stage: rank in category -> shuffled position -> split id --------------------
+    cat_arr = np.asarray(cat_id, np.int32)
+    n_cat = len(categories)
+    sizes = np.bincount(cat_arr, minlength=n_cat).astype(np.int64) if n_cat else np.zeros(0, np.int64)
+    cat_off = np.zeros(n_cat + 1, np.int64)
+    np.cumsum(sizes, out=cat_off[1:])
+    perms = [be.mt19937_permutation(random_seed, int(s)) for s in sizes]      # same seed per category (:800)
+    cuts = [split_cut_sizes(int(s), train_ratio, val_ratio, test_ratio) for s in sizes]
+    n_train = np.asarray([c[0] for c in cuts], np.int64)
+    n_val = np.asarray([c[1] for c in cuts], np.int64)
+    if len(cat_arr):
+        split, pos = be.split_ids(cat_arr, np.concatenate(perms) if perms else np.zeros(0, np.int64), cat_off,
+                                  n_train, n_val)
+    else:
+        split, pos = np.zeros(0, np.uint8), np.zeros(0, np.int64)
+
+    # ---- emit: per-category frames in shuffled order, cut by split id ------------------------
+    src_arr = np.asarray(src_row, np.int64)
+    out_cats, cat_counts = {}, {}
+    for category, cid in categories.items():
+        members = np.flatnonzero(cat_arr == cid)
+        order = np.empty(len(members), np.int64)
+        order[pos[members]] = members                        # shuffled position -> expanded record
+        frame = df.iloc[src_arr[order]].copy()
+        text = pd.Series([new_json[i] for i in order], index=frame.index, dtype=object)
+        for c in present_json:
+            frame[c] = text
+        frame["分类标签"] = [new_label[i] for i in order]
+        frame["分类类别"] = category
+        frame["原始标签组合"] = [new_combo[i] for i in order]
+        frame = frame.reset_index(drop=True)
+        sp = split[order]
+        out_cats[category] = (frame[sp == 0], frame[sp == 1], frame[sp == 2])
+        cat_counts[category] = int(len(members))
+
+    if unclassified:
+        rows = np.asarray([u[0] for u in unclassified], np.int64)
+        unc = df.iloc[rows].copy()
+        unc["无法分类原因"] = [u[1] for u in unclassified]
+        if any(u[2] is not None for u in unclassified):
+            unc["无法分类标签"] = [u[2] if u[2] is not None else np.nan for u in unclassified]
+    else:
+        unc = pd.DataFrame()
+    return {"categories": out_cats, "unclassified": unc, "split_counts": pd.DataFrame(counts),
+            "category_counts": cat_counts,
+            "expanded": {"src_row": src_arr, "category_id": cat_arr, "position": pos, "split": split,
+                         "category_names": list(categories)}}
+
+
+def split_dataset_by_rules(
+        input_csv_path: str,
+        rules_excel_path: str,
+        output_dir: str,
+        rule_mode: str = "wide",
+        sheet_name: Optional[str] = None,
+        label_col: Optional[str] = None,
+        category_col: Optional[str] = None,
+        json_columns: Optional[list] = None,
+        train_ratio: float = 0.8,
+        val_ratio: float = 0.1,
+        test_ratio: float = 0.1,
+        random_seed: int = 42,
+        backend=None,
+):
+    if not os.path.exists(input_csv_path):
+        raise FileNotFoundError(f"输入CSV不存在：{input_csv_path}")
+    if not os.path.exists(rules_excel_path):
+        raise FileNotFoundError(f"规则Excel不存在：{rules_excel_path}")
+
+    df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    rules_df = pd.read_excel(rules_excel_path, sheet_name=sheet_name) if sheet_name else pd.read_excel(rules_excel_path)
+    label_to_category = rules_to_label_map(rules_df, rule_mode, label_col, category_col)
+
+    output_dir = Path(output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    res = split_frames(df, label_to_category, json_columns, train_ratio, val_ratio, test_ratio, random_seed, backend)
+
+    category_files = []
+    for category, (train_df, val_df, test_df) in res["categories"].items():
+        out_path = output_dir / f"{safe_filename(category)}.xlsx"
+        with pd.ExcelWriter(out_path) as writer:
+            train_df.to_excel(writer, sheet_name="train", index=False)
+            val_df.to_excel(writer, sheet_name="val", index=False)
+            test_df.to_excel(writer, sheet_name="test", index=False)
+        category_files.append(out_path)
+    unclassified_path = output_dir / "unclassified.xlsx"
+    res["unclassified"].to_excel(unclassified_path, index=False)
+    split_counts_path = output_dir / "split_counts.xlsx"
+    res["split_counts"].to_excel(split_counts_path, index=False)
+
+    return {
+        "output_dir": output_dir,
+        "category_files": category_files,
+        "unclassified": unclassified_path,
+        "split_counts": split_counts_path,
+        "summary": {
+            "categories": len(res["categories"]),
+            "classified": sum(res["category_counts"].values()),
+            "unclassified": len(res["unclassified"]),
+            "category_counts": res["category_counts"],
+        },
+    }

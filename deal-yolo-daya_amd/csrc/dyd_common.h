@@ -1,0 +1,105 @@
+// dyd_common.h — internal helpers shared by the translation units of libdyd_gfx950.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+
+#include "../../include/dyd.h"
+
+namespace dyd {
+
+constexpr int kWave = 64;
+
+// Process-wide context, created lazily by dyd_init (reference processor.py has no
+// equivalent: it never leaves CPython).
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;  // the library's own stream (used when the caller passes NULL)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 0;
+    char name[256] = {0};
+    // reusable device scratch (hash tables, staging), grown on demand
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    hipEvent_t scratch_ev = nullptr;  // recorded after the last kernel that used the scratch
+    bool scratch_used = false;
+};
+
+Context &ctx();
+std::recursive_mutex &api_mutex();
+void set_error(const char *fmt, ...);
+void set_last_kernel_ms(double ms);
+int ensure_init();
+// returns a device buffer of at least `bytes` owned by the context.  `st` is made to wait for the
+// previous user of the scratch; call release_scratch(st) after the last launch that touches it.
+int get_scratch(size_t bytes, void **out, hipStream_t st);
+void release_scratch(hipStream_t st);
+inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+
+#define DYD_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            ::dyd::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                             __LINE__);                                                    \
+            return e__ == hipErrorOutOfMemory ? DYD_ERR_OOM : DYD_ERR_HIP;                 \
+        }                                                                                  \
+    } while (0)
+
+#define DYD_REQUIRE(cond, msg)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::dyd::set_error("invalid argument: %s", msg); \
+            return DYD_ERR_INVALID;                 \
+        }                                           \
+    } while (0)
+
+#define DYD_API_ENTER()                                              \
+    std::lock_guard<std::recursive_mutex> lock__(::dyd::api_mutex()); \
+    do {                                                             \
+        int rc__ = ::dyd::ensure_init();                             \
+        if (rc__ != DYD_OK) return rc__;                             \
+    } while (0)
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return DYD_ERR_OOM;
+        }
+        return DYD_OK;
+    }
+    template <class T>
+    T *as() { return static_cast<T *>(p); }
+};
+
+// times the kernels launched between begin() and end() on one stream
+struct KernelTimer {
+    hipStream_t s;
+    explicit KernelTimer(hipStream_t st) : s(st) { (void)hipEventRecord(ctx().ev0, s); }
+    void finish() {
+        (void)hipEventRecord(ctx().ev1, s);
+        (void)hipEventSynchronize(ctx().ev1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx().ev0, ctx().ev1);
+        set_last_kernel_ms(ms);
+    }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace dyd

@@ -1,0 +1,263 @@
+// k6_split.hip — K6: train/val/test split ids per category.
+//
+// Replaces, per category, DataFrame.sample(frac=1, random_state=seed).reset_index(drop=True)
+// followed by the iloc cuts at int(n*train_ratio) and int(n*val_ratio)
+// (reference core/processor.py:796-806).  The permutation itself is numpy's legacy MT19937
+// stream and is produced on the host (dyd_mt19937_permutation); the device (1) ranks every
+// expanded row inside its category in row order — a stable multi-way prefix count, which is
+// the order category_rows[category] is appended in at :773 — (2) inverts the permutation and
+// (3) turns rank -> shuffled position -> split id.
+//
+// Layout in HBM: cat = E int32 (-1 = unclassified), perm = sum n_c int64, outputs split E u8 and
+// pos E int64.  Algorithmic bytes per launch: 4*E + 8*E + 9*E = 21*E.  Bound: HBM.
+//
+// Mapping: a wave owns a tile of K6_TILE consecutive rows and keeps one running counter per
+// category in LDS.  Pass A counts the tile per category; pass B is an exclusive scan over tiles
+// per category (one workgroup per category); pass C replays the tile 64 rows at a time: lanes
+// holding the same category are found with ballots, a lane's rank is counter + popcount of the
+// lower lanes of its ballot.  Categories are processed in windows of K6_CATS so any n_cat fits.
+#include "dyd_common.h"
+
+namespace dyd {
+
+constexpr int K6_BLOCK = 256;                // 4 waves
+constexpr int K6_TILE = 2048;                // rows per wave tile
+constexpr int K6_CATS = 1024;                // categories per window (4 KiB of LDS counters per wave)
+constexpr int K6_WAVES = K6_BLOCK / kWave;
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    const unsigned lane = threadIdx.x & 63;
+    return lane ? (~0ull >> (64 - lane)) : 0ull;
+}
+
+// pass A: hist[(c - c0) * n_tiles + tile] = number of rows of category c in the tile
+__global__ __launch_bounds__(K6_BLOCK) void k6_count(const int32_t *__restrict__ cat, int64_t n, int32_t c0,
+                                                     int32_t c1, int64_t n_tiles, unsigned int *__restrict__ hist) {
+    __shared__ unsigned int s_cnt[K6_WAVES][K6_CATS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * K6_WAVES + wave;
+    const int32_t nc = c1 - c0;
+    for (int c = lane; c < nc; c += kWave) s_cnt[wave][c] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (tile < n_tiles) {
+        const int64_t r0 = tile * K6_TILE;
+        const int64_t r1 = (r0 + K6_TILE < n) ? r0 + K6_TILE : n;
+        for (int64_t r = r0 + lane; r < r1; r += kWave) {
+            const int32_t c = cat[r];
+            if (c >= c0 && c < c1) atomicAdd(&s_cnt[wave][c - c0], 1u);
+        }
+    }
+    __syncthreads();
+    if (tile < n_tiles)
+        for (int c = lane; c < nc; c += kWave) hist[(int64_t)c * n_tiles + tile] = s_cnt[wave][c];
+}
+
+// pass B: in-place exclusive scan of hist[c][0..n_tiles) for every category of the window
+__global__ __launch_bounds__(K6_BLOCK) void k6_scan(unsigned int *hist, int64_t n_tiles) {
+    __shared__ unsigned long long s_part[K6_BLOCK];
+    unsigned int *row = hist + (int64_t)blockIdx.x * n_tiles;
+    unsigned long long carry = 0;
+    for (int64_t base = 0; base < n_tiles; base += K6_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const unsigned int v = (i < n_tiles) ? row[i] : 0u;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < K6_BLOCK; off <<= 1) {  // Hillis-Steele inclusive scan
+            unsigned long long add = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s_part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const unsigned long long incl = s_part[threadIdx.x];
+        const unsigned long long total = s_part[K6_BLOCK - 1];
+        if (i < n_tiles) row[i] = (unsigned int)(carry + incl - v);
+        carry += total;
+        __syncthreads();
+    }
+}
+
+// inverse permutation: inv[cat_off[c] + perm[k]] = k - cat_off[c] for k in category c's range
+__global__ __launch_bounds__(K6_BLOCK) void k6_invert(const int64_t *__restrict__ perm,
+                                                      const int64_t *__restrict__ cat_off, int32_t n_cat,
+                                                      int64_t total, int64_t *__restrict__ inv) {
+    const int64_t k = (int64_t)blockIdx.x * K6_BLOCK + threadIdx.x;
+    if (k >= total) return;
+    int lo = 0, hi = n_cat;  // largest c with cat_off[c] <= k
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cat_off[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int64_t base = cat_off[lo];
+    const int64_t size = cat_off[lo + 1] - base;
+    const int64_t p = perm[k];
+    if (p >= 0 && p < size) inv[base + p] = k - base;  // guarded: a malformed perm cannot write out of range
+}
+
+// pass C: ranks -> positions -> split ids for the categories of the window
+__global__ __launch_bounds__(K6_BLOCK) void k6_assign(const int32_t *__restrict__ cat, int64_t n, int32_t c0,
+                                                      int32_t c1, int64_t n_tiles,
+                                                      const unsigned int *__restrict__ hist,
+                                                      const int64_t *__restrict__ inv,
+                                                      const int64_t *__restrict__ cat_off,
+                                                      const int64_t *__restrict__ n_train,
+                                                      const int64_t *__restrict__ n_val,
+                                                      uint8_t *__restrict__ out_split, int64_t *__restrict__ out_pos) {
+    __shared__ unsigned int s_cnt[K6_WAVES][K6_CATS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * K6_WAVES + wave;
+    if (tile >= n_tiles) return;  // no workgroup barrier below: waves are independent
+    const int32_t nc = c1 - c0;
+    for (int c = lane; c < nc; c += kWave) s_cnt[wave][c] = hist[(int64_t)c * n_tiles + tile];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t r0 = tile * K6_TILE;
+    const int64_t r1 = (r0 + K6_TILE < n) ? r0 + K6_TILE : n;
+    const unsigned long long lt = lanemask_lt();
+    for (int64_t rb = r0; rb < r1; rb += kWave) {
+        const int64_t r = rb + lane;
+        const int32_t c = (r < r1) ? cat[r] : -1;
+        const bool mine = (c >= c0 && c < c1);
+        unsigned long long todo = __ballot(mine);
+        int64_t rank = -1;
+        while (todo) {  // one round per distinct category among the 64 rows
+            const int leader = __ffsll((long long)todo) - 1;
+            const int32_t cl = __shfl(c, leader);
+            const unsigned long long same = __ballot(mine && c == cl);
+            const unsigned int before = s_cnt[wave][cl - c0];
+            if (mine && c == cl) rank = (int64_t)before + __popcll(same & lt);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) s_cnt[wave][cl - c0] = before + (unsigned int)__popcll(same);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~same;
+        }
+        if (mine) {
+            const int64_t base = cat_off[c];
+            const int64_t size = cat_off[c + 1] - base;
+            int64_t pos = -1;
+            uint8_t sp = 255;
+            if (rank < size) {  // guarded: cat_off must cover the category's rows
+                pos = inv[base + rank];
+                const int64_t a = n_train[c], b = n_val[c];
+                sp = pos < a ? 0 : (pos < a + b ? 1 : 2);
+            }
+            out_pos[r] = pos;
+            out_split[r] = sp;
+        }
+    }
+}
+
+// rows whose category is outside [0, n_cat): unclassified
+__global__ __launch_bounds__(K6_BLOCK) void k6_unclassified(const int32_t *__restrict__ cat, int64_t n,
+                                                            int32_t n_cat, uint8_t *__restrict__ out_split,
+                                                            int64_t *__restrict__ out_pos) {
+    const int64_t r = (int64_t)blockIdx.x * K6_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int32_t c = cat[r];
+    if (c < 0 || c >= n_cat) {
+        out_split[r] = 255;
+        out_pos[r] = -1;
+    }
+}
+
+static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, const int64_t *cat_off,
+                        const int64_t *n_train, const int64_t *n_val, int32_t n_cat, int64_t total,
+                        uint8_t *out_split, int64_t *out_pos, hipStream_t st) {
+    const int64_t n_tiles = ceil_div(n, K6_TILE);
+    const int64_t blocks = ceil_div(n_tiles, K6_WAVES);
+    const int32_t win = n_cat < K6_CATS ? n_cat : K6_CATS;
+    const size_t inv_bytes = (size_t)(total > 0 ? total : 1) * 8;
+    const size_t hist_bytes = (size_t)(win > 0 ? win : 1) * (size_t)n_tiles * 4;
+    void *scr = nullptr;
+    int rc = get_scratch(inv_bytes + hist_bytes, &scr, st);
+    if (rc) return rc;
+    int64_t *inv = static_cast<int64_t *>(scr);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(static_cast<char *>(scr) + inv_bytes);
+    hipLaunchKernelGGL(k6_unclassified, dim3((unsigned)ceil_div(n, K6_BLOCK)), dim3(K6_BLOCK), 0, st, cat, n, n_cat,
+                       out_split, out_pos);
+    DYD_HIP(hipGetLastError());
+    if (total > 0) {
+        DYD_HIP(hipMemsetAsync(inv, 0, inv_bytes, st));
+        hipLaunchKernelGGL(k6_invert, dim3((unsigned)ceil_div(total, K6_BLOCK)), dim3(K6_BLOCK), 0, st, perm, cat_off,
+                           n_cat, total, inv);
+        DYD_HIP(hipGetLastError());
+    }
+    for (int32_t c0 = 0; c0 < n_cat; c0 += K6_CATS) {
+        const int32_t c1 = (n_cat - c0 < K6_CATS) ? n_cat : c0 + K6_CATS;
+        hipLaunchKernelGGL(k6_count, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist);
+        DYD_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k6_scan, dim3((unsigned)(c1 - c0)), dim3(K6_BLOCK), 0, st, hist, n_tiles);
+        DYD_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k6_assign, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist, inv,
+                           cat_off, n_train, n_val, out_split, out_pos);
+        DYD_HIP(hipGetLastError());
+    }
+    release_scratch(st);
+    return DYD_OK;
+}
+
+}  // namespace dyd
+
+using namespace dyd;
+
+extern "C" {
+
+int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat, const int64_t *cat_off,
+                      const int64_t *n_train, const int64_t *n_val, int32_t n_cat, uint8_t *out_split,
+                      int64_t *out_pos, void *stream) {
+    // cat_off lives on the device here; its last entry (the permutation length) is needed on the
+    // host to size the scratch, so this twin reads it back once (8 bytes).
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0 && n_cat >= 0, "negative size");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(cat && out_split && out_pos, "null pointer");
+    DYD_REQUIRE(n_cat == 0 || (cat_perm_concat && cat_off && n_train && n_val), "null pointer");
+    DYD_REQUIRE(n < (1LL << 40), "n too large");
+    hipStream_t st = pick_stream(stream);
+    int64_t total = 0;
+    if (n_cat > 0) {
+        DYD_HIP(hipMemcpyAsync(&total, cat_off + n_cat, 8, hipMemcpyDeviceToHost, st));
+        DYD_HIP(hipStreamSynchronize(st));
+        DYD_REQUIRE(total >= 0, "cat_off[n_cat] < 0");
+    }
+    return split_launch(cat, n, cat_perm_concat, cat_off, n_train, n_val, n_cat, total, out_split, out_pos, st);
+}
+
+int dyd_split_ids(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat, const int64_t *cat_off,
+                  const int64_t *n_train, const int64_t *n_val, int32_t n_cat, uint8_t *out_split, int64_t *out_pos) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0 && n_cat >= 0, "negative size");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(cat && out_split && out_pos, "null pointer");
+    DYD_REQUIRE(n_cat == 0 || (cat_off && n_train && n_val), "null pointer");
+    int64_t total = 0;
+    if (n_cat > 0) {
+        DYD_REQUIRE(cat_off[0] == 0, "cat_off[0] != 0");
+        for (int32_t c = 0; c < n_cat; ++c) DYD_REQUIRE(cat_off[c + 1] >= cat_off[c], "cat_off not monotone");
+        total = cat_off[n_cat];
+        DYD_REQUIRE(total == 0 || cat_perm_concat, "cat_perm_concat is null");
+    }
+    DevBuf d_cat, d_perm, d_off, d_tr, d_va, d_split, d_pos;
+    int rc;
+    if ((rc = d_cat.alloc(4 * (size_t)n)) || (rc = d_perm.alloc(8 * (size_t)total)) ||
+        (rc = d_off.alloc(8 * (size_t)(n_cat + 1))) || (rc = d_tr.alloc(8 * (size_t)n_cat)) ||
+        (rc = d_va.alloc(8 * (size_t)n_cat)) || (rc = d_split.alloc((size_t)n)) || (rc = d_pos.alloc(8 * (size_t)n)))
+        return rc;
+    hipStream_t st = ctx().stream;
+    DYD_HIP(hipMemcpyAsync(d_cat.p, cat, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (total) DYD_HIP(hipMemcpyAsync(d_perm.p, cat_perm_concat, 8 * (size_t)total, hipMemcpyHostToDevice, st));
+    if (n_cat) {
+        DYD_HIP(hipMemcpyAsync(d_off.p, cat_off, 8 * (size_t)(n_cat + 1), hipMemcpyHostToDevice, st));
+        DYD_HIP(hipMemcpyAsync(d_tr.p, n_train, 8 * (size_t)n_cat, hipMemcpyHostToDevice, st));
+        DYD_HIP(hipMemcpyAsync(d_va.p, n_val, 8 * (size_t)n_cat, hipMemcpyHostToDevice, st));
+    }
+    KernelTimer t(st);
+    rc = split_launch(d_cat.as<int32_t>(), n, d_perm.as<int64_t>(), d_off.as<int64_t>(), d_tr.as<int64_t>(),
+                      d_va.as<int64_t>(), n_cat, total, d_split.as<uint8_t>(), d_pos.as<int64_t>(), st);
+    if (rc) return rc;
+    t.finish();
+    DYD_HIP(hipMemcpyAsync(out_split, d_split.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(out_pos, d_pos.p, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    return DYD_OK;
+}
+
+}  // extern "C"

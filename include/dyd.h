@@ -1,0 +1,166 @@
+/*
+ * dyd.h — C ABI of libdyd_gfx950.so, the MI355X (gfx950) device stage of the
+ * annotation hot path of Cyclones-Y/Deal-Yolo-Daya.
+ *
+ * The reference (`src/deal_yolo_data/core/processor.py`) is pure Python and has no
+ * FFI of its own; every entry point below replaces a Python loop or a pandas call of
+ * that file and is what a ctypes binding added to the reference would bind
+ * (INTEGRATION.md shows that binding).  Each declaration cites the reference lines
+ * it replaces.
+ *
+ * Conventions
+ *   - every function returns DYD_OK (0) or a negative DYD_ERR_* code; the message
+ *     for the calling thread's last failure is dyd_last_error().  No C++ exception
+ *     crosses this boundary.
+ *   - all buffers are caller-owned and contiguous.  Functions without a suffix take
+ *     HOST pointers and stage H2D / D2H themselves; `_dev` twins take DEVICE
+ *     pointers (from dyd_malloc, or any hipMalloc'ed memory of the same device, e.g.
+ *     a torch tensor's data_ptr) plus the hipStream_t to launch on (NULL = the
+ *     library's own stream).  `_dev` calls are asynchronous on that stream.
+ *   - offsets arrays have n+1 entries, start at 0 and are non-decreasing.
+ *   - the library keeps one lazily created context per process (device, stream,
+ *     scratch); entry points are serialised by a process-wide mutex, so they may be
+ *     called from any thread (Streamlit runs each session's script on its own
+ *     thread: reference ui/pages/processing.py:200-213).
+ */
+#ifndef DYD_H
+#define DYD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYD_OK 0
+#define DYD_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, bad offsets) */
+#define DYD_ERR_NO_DEVICE (-2) /* no gfx950 device visible / dyd_init failed */
+#define DYD_ERR_HIP (-3)       /* a HIP runtime call or kernel launch failed */
+#define DYD_ERR_OOM (-4)       /* device allocation failed */
+#define DYD_ERR_RANGE (-5)     /* size exceeds what an int32 offset array can address */
+
+/* keep modes of dyd_dedup == pandas drop_duplicates(keep=...) (processor.py:140-144) */
+#define DYD_KEEP_FIRST 0
+#define DYD_KEEP_LAST 1
+#define DYD_KEEP_NONE 2
+
+/* ---- context -------------------------------------------------------------------- */
+int dyd_init(int device_or_minus1);
+void dyd_shutdown(void);
+const char *dyd_last_error(void);
+int dyd_device_count(void);
+const char *dyd_version(void);
+/* name of the device the context is bound to ("" before dyd_init) */
+const char *dyd_device_name(void);
+
+/* ---- device memory + timing (for callers that keep data resident in HBM) -------- */
+int dyd_malloc(void **dptr, size_t bytes);
+int dyd_free(void *dptr);
+int dyd_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int dyd_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int dyd_memset(void *dst_dev, int byte, size_t bytes);
+int dyd_sync(void *stream);
+/* elapsed ms of the kernels launched by the calling thread's most recent non-_dev
+ * entry point (hipEvent pair around the kernel launches only, staging excluded) */
+double dyd_last_kernel_ms(void);
+
+/* ---- K1: polygon ptList -> bbox -------------------------------------------------
+ * Replaces get_bbox_points (processor.py:252-260), called per object at :273.
+ * xy      : P points, interleaved (x,y) f64                       [2*P]
+ * pt_off  : point offsets per box                                 [n_boxes+1]
+ * out_box4: (min_x, min_y, max_x, max_y) per box                  [4*n_boxes]
+ * out_arg4: index INSIDE the box of the point that supplies each of the four values,
+ *           in the same order                                     [4*n_boxes]
+ * Semantics are CPython's builtin min/max over the box's points in order: the FIRST
+ * extremal element wins (strict < / > replaces the running best), so -0.0 vs 0.0 and
+ * int-vs-float ties resolve to the lower index, and a NaN wins only from position 0.
+ * A box with no points yields four NaNs and four -1 (the host emits JSON null,
+ * processor.py:254-255). */
+int dyd_bbox_minmax(const double *xy, const int32_t *pt_off, int64_t n_boxes,
+                    double *out_box4, int32_t *out_arg4);
+int dyd_bbox_minmax_dev(const double *xy, const int32_t *pt_off, int64_t n_boxes,
+                        double *out_box4, int32_t *out_arg4, void *stream);
+
+/* ---- K2: per-image box-count + all-pairs IoU filter ------------------------------
+ * Replaces meet_conditions (processor.py:368-376) + calculate_iou (:328-339) and the
+ * corner normalisation of extract_boxes (:359-362).
+ * box4    : per box the two ptList points as stored (p1x, p1y, p2x, p2y); corners are
+ *           re-normalised in the kernel with first-wins min/max       [4*B]
+ * row_off : box offsets per image row                                  [n_rows+1]
+ * out_high: 1 iff n_i >= min_boxes and some pair i<j has IoU >= thr    [n_rows]
+ * out_max_iou_or_null: optional diagnostic, max pair IoU of the row (0.0 when the row
+ *           has fewer than two boxes); not a reference output          [n_rows]
+ * f64 arithmetic in the reference's operation order, no contraction, IEEE division. */
+int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows,
+                   int32_t min_boxes, double thr, uint8_t *out_high,
+                   double *out_max_iou_or_null);
+int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_rows,
+                       int32_t min_boxes, double thr, uint8_t *out_high,
+                       double *out_max_iou_or_null, void *stream);
+
+/* ---- K1+K2 fused: poly -> bbox -> IoU flag in one pass ---------------------------
+ * One launch that produces K1's outputs and K2's flag for rows whose boxes all come
+ * from K1 (processing.py:580-598 runs the two steps back to back on the same rows).
+ * box_off : box offsets per image row [n_rows+1], n_boxes = box_off[n_rows]; other
+ *           arguments as K1 / K2. */
+int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_t *box_off,
+                           int64_t n_rows, int64_t n_boxes, int32_t min_boxes, double thr,
+                           double *out_box4, int32_t *out_arg4, uint8_t *out_high, void *stream);
+
+/* ---- K3: 128-bit hash of a string column -----------------------------------------
+ * The equality test inside DataFrame.drop_duplicates (processor.py:140) and
+ * Series.isin (:198) is replaced by equality of 128-bit hashes of the host's
+ * canonical byte form of each cell (MurmurHash3 x64_128, seed 0).
+ * bytes: concatenated cells; off: byte offsets [n+1]; out_hi_lo: (h1, h2) per row [2*n] */
+int dyd_hash128(const uint8_t *bytes, const int64_t *off, int64_t n, uint64_t *out_hi_lo);
+int dyd_hash128_dev(const uint8_t *bytes, const int64_t *off, int64_t n, uint64_t *out_hi_lo,
+                    void *stream);
+
+/* ---- K4: first / last / none-occurrence mask over hash keys ----------------------
+ * Replaces drop_duplicates(subset=["source"], keep=keep) (processor.py:140-144).
+ * h: (h1,h2) per row [2*n]; out_keep[i] = 1 iff row i survives. */
+int dyd_dedup(const uint64_t *h, int64_t n, int keep_mode, uint8_t *out_keep);
+int dyd_dedup_dev(const uint64_t *h, int64_t n, int keep_mode, uint8_t *out_keep, void *stream);
+
+/* ---- K5: membership of main keys in a reference key set --------------------------
+ * Replaces Series.isin(ref_values) (processor.py:194-199). out_mask[i] = 1 iff h[i] is
+ * one of the r reference keys. */
+int dyd_isin(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, uint8_t *out_mask);
+int dyd_isin_dev(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r,
+                 uint8_t *out_mask, void *stream);
+
+/* ---- multi-GPU dedup: keys of ALL ranks after the allgather ----------------------
+ * all_h : gathered keys of every rank in global row order          [2*n_all]
+ * first_global / n_local: this rank owns global rows [first_global, first_global+n_local)
+ * out_keep: mask for the rank's own rows                             [n_local] */
+int dyd_dedup_global_dev(const uint64_t *all_h, int64_t n_all, int64_t first_global,
+                         int64_t n_local, int keep_mode, uint8_t *out_keep, void *stream);
+
+/* ---- K6: train/val/test split ids -------------------------------------------------
+ * Replaces DataFrame.sample(frac=1, random_state=seed) + the int(n*ratio) cuts per
+ * category (processor.py:796-806).
+ * dyd_mt19937_permutation is host code: numpy's legacy RandomState(seed).permutation(n)
+ * (init_genrand + reversed Fisher-Yates with masked-rejection 32-bit draws).
+ * cat            : category id per expanded row, -1 = unclassified     [n]
+ * cat_perm_concat: per category its permutation, concatenated           [sum n_c]
+ * cat_off        : start of each category inside cat_perm_concat        [n_cat+1]
+ * n_train/n_val  : cut sizes per category                               [n_cat]
+ * out_split      : 0 train / 1 val / 2 test / 255 unclassified          [n]
+ * out_pos        : position of the row inside its shuffled category     [n] (-1 unclassified) */
+int dyd_mt19937_permutation(uint32_t seed, int64_t n, int64_t *out);
+int dyd_split_ids(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat,
+                  const int64_t *cat_off, const int64_t *n_train, const int64_t *n_val,
+                  int32_t n_cat, uint8_t *out_split, int64_t *out_pos);
+int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat,
+                      const int64_t *cat_off, const int64_t *n_train, const int64_t *n_val,
+                      int32_t n_cat, uint8_t *out_split, int64_t *out_pos, void *stream);
+
+/* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
+ * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging. */
+int dyd_set_option(const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYD_H */

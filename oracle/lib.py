@@ -1,0 +1,103 @@
+"""ctypes wrappers over liboracle.so (oracle/dyd_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc, see oracle/Makefile)."""
+    src = os.path.join(_HERE, "dyd_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def bbox_minmax(xy: np.ndarray, pt_off: np.ndarray):
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    pt_off = np.ascontiguousarray(pt_off, dtype=np.int32)
+    nb = len(pt_off) - 1
+    box = np.empty((nb, 4), np.float64)
+    arg = np.empty((nb, 4), np.int32)
+    _load().orc_bbox_minmax(_p(xy, C.c_double), _p(pt_off, C.c_int32), C.c_int64(nb),
+                            _p(box, C.c_double), _p(arg, C.c_int32))
+    return box, arg
+
+
+def iou_any_ge(box4: np.ndarray, row_off: np.ndarray, min_boxes: int, thr: float, want_max=False):
+    box4 = np.ascontiguousarray(box4, dtype=np.float64).reshape(-1)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int32)
+    n = len(row_off) - 1
+    high = np.empty(n, np.uint8)
+    mx = np.empty(n, np.float64) if want_max else None
+    _load().orc_iou_any_ge(_p(box4, C.c_double), _p(row_off, C.c_int32), C.c_int64(n),
+                           C.c_int32(min_boxes), C.c_double(thr), _p(high, C.c_uint8),
+                           _p(mx, C.c_double) if want_max else None)
+    return (high, mx) if want_max else high
+
+
+def hash128(data: np.ndarray, off: np.ndarray):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    if data.size == 0:
+        data = np.zeros(1, np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    n = len(off) - 1
+    out = np.empty((n, 2), np.uint64)
+    _load().orc_hash128(_p(data, C.c_uint8), _p(off, C.c_int64), C.c_int64(n), _p(out, C.c_uint64))
+    return out
+
+
+def dedup(h: np.ndarray, keep_mode: int):
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty(len(h), np.uint8)
+    _load().orc_dedup(_p(h, C.c_uint64), C.c_int64(len(h)), C.c_int(keep_mode), _p(out, C.c_uint8))
+    return out
+
+
+def isin(h: np.ndarray, ref_h: np.ndarray):
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+    ref_h = np.ascontiguousarray(ref_h, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty(len(h), np.uint8)
+    _load().orc_isin(_p(h, C.c_uint64), C.c_int64(len(h)), _p(ref_h, C.c_uint64),
+                     C.c_int64(len(ref_h)), _p(out, C.c_uint8))
+    return out
+
+
+def mt19937_permutation(seed: int, n: int):
+    out = np.empty(n, np.int64)
+    _load().orc_mt19937_permutation(C.c_uint32(seed), C.c_int64(n), _p(out, C.c_int64))
+    return out
+
+
+def split_ids(cat, perm_concat, cat_off, n_train, n_val):
+    cat = np.ascontiguousarray(cat, dtype=np.int32)
+    perm_concat = np.ascontiguousarray(perm_concat, dtype=np.int64)
+    cat_off = np.ascontiguousarray(cat_off, dtype=np.int64)
+    n_train = np.ascontiguousarray(n_train, dtype=np.int64)
+    n_val = np.ascontiguousarray(n_val, dtype=np.int64)
+    n = len(cat)
+    split = np.empty(n, np.uint8)
+    pos = np.empty(n, np.int64)
+    _load().orc_split_ids(_p(cat, C.c_int32), C.c_int64(n), _p(perm_concat, C.c_int64),
+                          _p(cat_off, C.c_int64), _p(n_train, C.c_int64), _p(n_val, C.c_int64),
+                          C.c_int32(len(n_train)), _p(split, C.c_uint8), _p(pos, C.c_int64))
+    return split, pos

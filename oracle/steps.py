@@ -1,0 +1,363 @@
+"""CPU restatement of the reference's five hot-path steps.  TEST INFRASTRUCTURE ONLY.
+
+Single-threaded CPython + pandas, deliberately keeping the reference's cost structure
+(``read_csv`` -> ``json.loads`` -> builtin ``min``/``max`` -> ``iterrows`` double loop ->
+``to_csv``) so that timing it on the GPU box's host stands in for the reference
+(bench.py ``cpu_baseline.kind == "port"``).  Each function names the reference lines it
+restates (src/deal_yolo_data/core/processor.py unless noted).  Pinned by tests/golden/.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+import re
+from pathlib import Path
+
+import pandas as pd
+
+ANN_COL = "结果字段-目标检测标签配置"           # processor.py:244
+NEW_COL = "新_" + ANN_COL                      # processor.py:283, 384
+_LABEL_SEP = re.compile(r"[,，;；|]")          # utils.py:642, 662
+
+
+# --------------------------------------------------------------------------- a1 :111-164
+def dedup_frame(df: pd.DataFrame, keep="first") -> pd.DataFrame:
+    return df.drop_duplicates(subset=["source"], keep=keep, ignore_index=True)
+
+
+def dedup_csv(csv_path, output_file="deduplicate_result.csv", encoding="utf-8-sig", keep="first"):
+    if not os.path.exists(csv_path):
+        raise FileNotFoundError(csv_path)
+    if not csv_path.endswith(".csv"):
+        raise ValueError(csv_path)
+    try:
+        df = pd.read_csv(csv_path, encoding=encoding, parse_dates=False)
+    except Exception as e:  # :133-134
+        raise Exception(str(e)) from e
+    if "source" not in df.columns:
+        raise KeyError("source")
+    out = dedup_frame(df, keep)
+    if output_file is not None:
+        d = os.path.dirname(output_file)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        out.to_csv(output_file, index=False, encoding=encoding)
+    return out
+
+
+# --------------------------------------------------------------------------- a2 :166-219
+def ref_filter_frame(df_main: pd.DataFrame, df_ref: pd.DataFrame, col="source") -> pd.DataFrame:
+    wanted = set(df_ref[col].dropna().astype(str))          # :194
+    hit = df_main[col].astype(str).isin(wanted)              # :198
+    return df_main[~hit].copy()                              # :199
+
+
+def ref_filter_csv(main_csv, ref_csv, output_csv="filtered_main.csv", compare_col="source",
+                   encoding="utf-8-sig"):
+    for p in (main_csv, ref_csv):
+        if not os.path.exists(p):
+            raise FileNotFoundError(p)
+        if not p.endswith(".csv"):
+            raise ValueError(p)
+    df_main = pd.read_csv(main_csv, encoding=encoding, parse_dates=False)
+    df_ref = pd.read_csv(ref_csv, encoding=encoding, parse_dates=False)
+    for d in (df_main, df_ref):
+        if compare_col not in d.columns:
+            raise KeyError(compare_col)
+    out = ref_filter_frame(df_main, df_ref, compare_col)
+    d = os.path.dirname(output_csv)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    out.to_csv(output_csv, index=False, encoding=encoding)
+    return out
+
+
+# --------------------------------------------------------------------------- a3 :229-319
+def bbox_of_ptlist(ptlist):
+    """:252-260 — builtin min/max keep the FIRST extremal element and its Python type."""
+    pts = [p for p in ptlist if isinstance(p, dict) and "x" in p and "y" in p]
+    if not pts:
+        return [{"x": None, "y": None}, {"x": None, "y": None}]
+    lo_x = min(p["x"] for p in pts)
+    hi_x = max(p["x"] for p in pts)
+    lo_y = min(p["y"] for p in pts)
+    hi_y = max(p["y"] for p in pts)
+    return [{"x": lo_x, "y": lo_y}, {"x": hi_x, "y": hi_y}]
+
+
+def replace_cell(cell):
+    """:262-281 — only JSONDecodeError is swallowed; structural surprises raise."""
+    try:
+        if pd.isna(cell) or not isinstance(cell, str):
+            return None
+        doc = json.loads(cell)
+        rewritten = []
+        for obj in doc.get("objects", []):
+            if not isinstance(obj, dict):
+                continue
+            new_obj = obj.copy()
+            new_pts = bbox_of_ptlist(obj.get("polygon", {}).get("ptList", []))
+            if "polygon" not in new_obj:
+                new_obj["polygon"] = {}
+            new_obj["polygon"]["ptList"] = new_pts
+            rewritten.append(new_obj)
+        doc["objects"] = rewritten
+        return json.dumps(doc, ensure_ascii=False)
+    except json.JSONDecodeError:
+        return None
+
+
+def width_height_of_cell(cell):
+    """:285-292 — second parse of the same cell, bare except."""
+    try:
+        if pd.isna(cell) or not isinstance(cell, str):
+            return None, None
+        doc = json.loads(cell)
+        return doc.get("width"), doc.get("height")
+    except:  # noqa: E722  (the reference's bare except)
+        return None, None
+
+
+def replace_frame(df: pd.DataFrame):
+    """:249-309 -> (projected frame with NEW_COL/width/height, excluded rows)."""
+    kept = df.dropna(subset=[ANN_COL]).copy()
+    excluded = df[df[ANN_COL].isna()].copy()
+    kept[NEW_COL] = kept[ANN_COL].apply(replace_cell)
+    wh = kept[ANN_COL].apply(lambda c: dict(zip(("width", "height"), width_height_of_cell(c))))
+    kept["width"] = [d["width"] for d in wh]
+    kept["height"] = [d["height"] for d in wh]
+    cols = [c for c in ("source", ANN_COL, NEW_COL, "width", "height") if c in kept.columns]
+    return kept, kept[cols], excluded
+
+
+def replace_csv(input_csv_path, output_csv_path="processed_replaced_ptlist.csv",
+                excluded_output_file="processed_excluded.csv"):
+    try:
+        df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    except Exception:
+        return None
+    if ANN_COL not in df.columns:
+        return None
+    kept, projected, excluded = replace_frame(df)
+    Path(output_csv_path).parent.mkdir(parents=True, exist_ok=True)
+    projected.to_csv(output_csv_path, index=False, encoding="utf-8-sig")
+    if excluded_output_file is not None:
+        Path(excluded_output_file).parent.mkdir(parents=True, exist_ok=True)
+        excluded.to_csv(excluded_output_file, index=False, encoding="utf-8-sig")
+    return {"filtered_rows": len(kept), "excluded_rows": len(excluded),
+            "excluded_output": excluded_output_file}
+
+
+# --------------------------------------------------------------------------- a4 :321-407
+def pair_iou(p, q):
+    """:328-339 — CPython numerics: exact ints, IEEE doubles, true division."""
+    ix1 = max(p[0], q[0])
+    iy1 = max(p[1], q[1])
+    ix2 = min(p[2], q[2])
+    iy2 = min(p[3], q[3])
+    inter = max(0, ix2 - ix1) * max(0, iy2 - iy1)
+    if inter == 0:
+        return 0.0
+    a1 = (p[2] - p[0]) * (p[3] - p[1])
+    a2 = (q[2] - q[0]) * (q[3] - q[1])
+    uni = a1 + a2 - inter
+    return inter / uni if uni != 0 else 0.0
+
+
+def boxes_of_cell(cell):
+    """:341-366 — any exception truncates the row's box list to the prefix collected."""
+    found = []
+    try:
+        if pd.isna(cell) or not isinstance(cell, str):
+            return found
+        doc = json.loads(cell)
+        for obj in doc.get("objects", []):
+            if not isinstance(obj, dict):
+                continue
+            pts = obj.get("polygon", {}).get("ptList", [])
+            if len(pts) != 2:
+                continue
+            a, b = pts
+            if not (isinstance(a, dict) and isinstance(b, dict) and "x" in a and "y" in a
+                    and "x" in b and "y" in b):
+                continue
+            found.append((min(a["x"], b["x"]), min(a["y"], b["y"]),
+                          max(a["x"], b["x"]), max(a["y"], b["y"])))
+    except Exception:
+        pass
+    return found
+
+
+def row_is_high(boxes, min_boxes, thr):
+    """:368-376"""
+    if len(boxes) < min_boxes:
+        return False
+    for i in range(len(boxes)):
+        for j in range(i + 1, len(boxes)):
+            if pair_iou(boxes[i], boxes[j]) >= thr:
+                return True
+    return False
+
+
+def iou_filter_frame(df: pd.DataFrame, min_boxes=2, thr=0.98):
+    """:389-406 -> (high frame, other frame); iterrows + list-of-Series like the reference."""
+    hi, lo = [], []
+    for _, row in df.iterrows():
+        (hi if row_is_high(boxes_of_cell(row[NEW_COL]), min_boxes, thr) else lo).append(row)
+    return pd.DataFrame(hi, columns=df.columns), pd.DataFrame(lo, columns=df.columns)
+
+
+def iou_filter_csv(input_csv_path, high_iou_csv="high_iou_0.98.csv", other_csv="other_data.csv",
+                   min_boxes=2, iou_threshold=0.98):
+    try:
+        df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    except Exception:
+        return
+    if NEW_COL not in df.columns:
+        return
+    hi, lo = iou_filter_frame(df, min_boxes, iou_threshold)
+    Path(high_iou_csv).parent.mkdir(parents=True, exist_ok=True)
+    Path(other_csv).parent.mkdir(parents=True, exist_ok=True)
+    hi.to_csv(high_iou_csv, index=False, encoding="utf-8-sig")
+    lo.to_csv(other_csv, index=False, encoding="utf-8-sig")
+
+
+# --------------------------------------------------------------------------- a5 :654-831
+def split_label_cell(cell):
+    """utils.py:635-643"""
+    if pd.isna(cell):
+        return []
+    text = str(cell).strip()
+    if not text:
+        return []
+    return [t.strip() for t in _LABEL_SEP.split(text) if t.strip()]
+
+
+def split_object_labels(name):
+    """utils.py:659-662"""
+    if not name:
+        return []
+    return [t.strip() for t in _LABEL_SEP.split(str(name)) if t.strip()]
+
+
+def parse_objects(cell):
+    """utils.py:645-657"""
+    if pd.isna(cell) or not isinstance(cell, str) or not cell:
+        return None, [], "空数据"
+    try:
+        doc = json.loads(cell)
+        objs = doc.get("objects", [])
+        if not isinstance(objs, list):
+            return doc, [], "objects不是列表"
+        return doc, objs, None
+    except json.JSONDecodeError:
+        return None, [], "JSON解析失败"
+    except Exception as e:
+        return None, [], str(e)
+
+
+def rules_to_map(rules_df: pd.DataFrame, rule_mode="wide", label_col=None, category_col=None):
+    """:688-703"""
+    mapping = {}
+    if rule_mode == "wide":
+        for col in rules_df.columns:
+            cat = str(col).strip()
+            if not cat:
+                continue
+            for cell in rules_df[col].dropna():
+                for lab in split_label_cell(cell):
+                    mapping[lab] = cat
+    elif rule_mode == "two_column":
+        for _, r in rules_df.iterrows():
+            lab = str(r.get(label_col, "")).strip()
+            cat = str(r.get(category_col, "")).strip()
+            if lab and cat and lab.lower() != "nan" and cat.lower() != "nan":
+                mapping[lab] = cat
+    return mapping
+
+
+def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns=None, train_ratio=0.8,
+                 val_ratio=0.1, test_ratio=0.1, random_seed=42):
+    """:673-676, :680-685, :705-818 without the Excel I/O.
+
+    Returns {"categories": {cat: (train, val, test)}, "unclassified": frame,
+             "split_counts": frame, "category_counts": {cat: n}}."""
+    s = train_ratio + val_ratio + test_ratio
+    train_ratio, val_ratio, test_ratio = train_ratio / s, val_ratio / s, test_ratio / s
+    if json_columns is None:
+        json_columns = [c for c in (NEW_COL, ANN_COL) if c in df.columns]
+    per_cat, unclassified, counts = {}, [], []
+    for _, row in df.iterrows():
+        cell = None
+        for c in json_columns:
+            if c in row and isinstance(row[c], str) and row[c]:
+                cell = row[c]
+                break
+        doc, objs, err = parse_objects(cell)
+        if err or not objs:
+            why = err or "标注字段objects为空"
+            r = row.copy()
+            r["无法分类原因"] = why
+            unclassified.append(r)
+            counts.append({"source": row.get("source"), "原始标签组合": "", "拆分条数": 0,
+                           "是否可分类": "否", "无法分类原因": why})
+            continue
+        seen = set()
+        for o in objs:
+            if isinstance(o, dict) and o.get("name"):
+                seen.update(split_object_labels(o.get("name")))
+        combo = "，".join(sorted(seen)) if seen else ""
+        n_out, reasons, hit = 0, set(), False
+        for o in objs:
+            if not isinstance(o, dict):
+                continue
+            labs = split_object_labels(o.get("name"))
+            if not labs:
+                r = row.copy()
+                r["无法分类原因"] = "标注框缺少name字段"
+                unclassified.append(r)
+                continue
+            for lab in labs:
+                if lab not in label_to_category:
+                    r = row.copy()
+                    r["无法分类原因"] = f"标签{lab}未在规则中定义"
+                    r["无法分类标签"] = lab
+                    unclassified.append(r)
+                    reasons.add(f"标签{lab}未在规则中定义")
+                    continue
+                cat = label_to_category[lab]
+                r = row.copy()
+                one = copy.deepcopy(o)
+                one["name"] = lab
+                slim = {k: v for k, v in doc.items() if k != "objects"}
+                slim["objects"] = [one]
+                text = json.dumps(slim, ensure_ascii=False)
+                for c in json_columns:
+                    if c in df.columns:
+                        r[c] = text
+                r["分类标签"] = lab
+                r["分类类别"] = cat
+                r["原始标签组合"] = combo
+                per_cat.setdefault(cat, []).append(r)
+                hit = True
+                n_out += 1
+        if not hit:
+            r = row.copy()
+            r["无法分类原因"] = "；".join(sorted(reasons)) if reasons else "标签无法匹配规则"
+            unclassified.append(r)
+        status = "否" if not hit else ("部分可分类" if reasons else "是")
+        counts.append({"source": row.get("source"), "原始标签组合": combo, "拆分条数": n_out,
+                       "是否可分类": status, "无法分类原因": "；".join(sorted(reasons))})
+    out, cat_counts = {}, {}
+    for cat, rows in per_cat.items():
+        if not rows:
+            continue
+        cat_counts[cat] = len(rows)
+        f = pd.DataFrame(rows).sample(frac=1, random_state=random_seed).reset_index(drop=True)
+        n = len(f)
+        a = int(n * train_ratio)
+        b = int(n * val_ratio)
+        out[cat] = (f.iloc[:a], f.iloc[a:a + b], f.iloc[a + b:])
+    return {"categories": out, "unclassified": pd.DataFrame(unclassified),
+            "split_counts": pd.DataFrame(counts), "category_counts": cat_counts}

@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference (it never travels to the GPU box; the fixtures do).  The reference ships no
+tests or vectors of its own, so these outputs are what pins oracle/ and the HIP path:
+
+    replace_cases.json   a3 process_csv_replace_ptlist  edge-case matrix (value cases + raising cases)
+    iou_cases.json       a4 filter_by_box_count_and_iou edge-case matrix
+    dedup_cases.json     a1 deduplicate_csv_by_source   keep = first / last / False, NaN sources
+    ref_filter_cases.json a2 remove_duplicates_between_csv NaN / "nan" / numeric columns
+    perm_cases.json      a5 DataFrame.sample(frac=1, random_state=seed) orders + int(n*ratio) cuts
+    split_case.json      a5 split_dataset_by_rules with Excel I/O captured in memory
+    e2e_*.csv.gz         one seeded table through all five steps (inputs and every output)
+
+Usage:  python tests/golden/make_golden.py
+"""
+import gzip
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import src.deal_yolo_data.core.processor as ref  # noqa: E402  (the reference itself)
+from deal_yolo_daya_amd import synth  # noqa: E402
+
+ANN = "结果字段-目标检测标签配置"
+NEW = "新_" + ANN
+
+
+def _dump(name, obj):
+    with open(os.path.join(HERE, name), "w", encoding="utf-8") as f:
+        json.dump(obj, f, ensure_ascii=False, indent=1)
+    print("wrote", name)
+
+
+def _read_text(p):
+    with open(p, "rb") as f:
+        return f.read().decode("utf-8-sig")
+
+
+# ------------------------------------------------------------------------------- a3
+REPLACE_VALUE_CASES = {
+    "int_polygon": '{"width": 640, "height": 480, "objects": [{"name": "a", "polygon": {"ptList": [{"x": 5, "y": 9}, {"x": 1, "y": 12}, {"x": 7, "y": 3}]}}]}',
+    "float_polygon": '{"objects": [{"polygon": {"ptList": [{"x": 5.5, "y": 9.25}, {"x": 1.0, "y": 12.0}, {"x": 7.75, "y": 3.5}]}}]}',
+    "int_float_tie_first_wins": '{"objects": [{"polygon": {"ptList": [{"x": 1, "y": 2.0}, {"x": 1.0, "y": 2}, {"x": 1, "y": 2}]}}, {"polygon": {"ptList": [{"x": 1.0, "y": 2}, {"x": 1, "y": 2.0}]}}]}',
+    "neg_zero_tie": '{"objects": [{"polygon": {"ptList": [{"x": 0, "y": -0.0}, {"x": -0.0, "y": 0}, {"x": 0.0, "y": 0.0}]}}, {"polygon": {"ptList": [{"x": -0.0, "y": 0.0}, {"x": 0, "y": -0.0}]}}]}',
+    "nan_first_poisons": '{"objects": [{"polygon": {"ptList": [{"x": NaN, "y": 1}, {"x": 2, "y": NaN}, {"x": 3, "y": 0}]}}]}',
+    "nan_later_ignored": '{"objects": [{"polygon": {"ptList": [{"x": 2, "y": 5}, {"x": NaN, "y": NaN}, {"x": 3, "y": 4}]}}]}',
+    "infinities": '{"objects": [{"polygon": {"ptList": [{"x": Infinity, "y": -Infinity}, {"x": 1e308, "y": -1e308}, {"x": -Infinity, "y": Infinity}]}}]}',
+    "empty_ptlist_gives_null": '{"objects": [{"name": "a", "polygon": {"ptList": []}}]}',
+    "missing_polygon_added": '{"objects": [{"name": "a"}, {"name": "b", "polygon": {}}]}',
+    "points_missing_keys_skipped": '{"objects": [{"polygon": {"ptList": [{"x": 1}, {"y": 2}, 5, "s", null, [1, 2], {"x": 9, "y": 8, "z": 7}]}}]}',
+    "non_dict_objects_dropped": '{"objects": [1, "s", null, [1], {"polygon": {"ptList": [{"x": 1, "y": 2}, {"x": 3, "y": 4}]}}]}',
+    "key_order_and_extras_kept": '{"b": [1, {"k": "v"}], "objects": [{"z": 1, "polygon": {"q": true, "ptList": [{"x": 1, "y": 2}], "r": null}, "a": "中文 \\" \\\\ \\u00e9 \\n"}], "a": 1.50}',
+    "no_objects_key": '{"width": 10}',
+    "objects_empty": '{"objects": [], "height": 5}',
+    "single_point": '{"objects": [{"polygon": {"ptList": [{"x": 3, "y": 4}]}}]}',
+    "big_ints_exact": '{"objects": [{"polygon": {"ptList": [{"x": 9007199254740993, "y": 1}, {"x": 9007199254740992, "y": 2}, {"x": 9007199254740994, "y": 0}]}}]}',
+    "bool_coords": '{"objects": [{"polygon": {"ptList": [{"x": true, "y": 0}, {"x": 0, "y": false}, {"x": 1, "y": 1}]}}]}',
+    "string_coords_compare": '{"objects": [{"polygon": {"ptList": [{"x": "b", "y": "10"}, {"x": "a", "y": "9"}]}}]}',
+    "ptlist_is_dict": '{"objects": [{"polygon": {"ptList": {"x": 1, "y": 2}}}]}',
+    "ptlist_is_string": '{"objects": [{"polygon": {"ptList": "abc"}}]}',
+    "number_formats": '{"objects": [{"polygon": {"ptList": [{"x": 1E2, "y": 1.0e-5}, {"x": 100.0, "y": 0.00001}, {"x": 12345678901234567890, "y": 1e22}, {"x": 1.5e300, "y": 123456789.123456789}]}}], "width": 1e16, "height": -0}',
+    "undecodable_json": '{"objects": [',
+    "not_json_at_all": 'hello',
+    "empty_string_cell": ' ',
+    "dup_keys_last_wins": '{"objects": [{"polygon": {"ptList": [{"x": 1, "y": 2, "x": 5}]}, "polygon2": 1}], "width": 1, "width": 2}',
+    "unicode_escapes": '{"objects": [{"name": "\\u4e2d\\u6587\\ud83d\\ude00/\\/", "polygon": {"ptList": [{"x": 1, "y": 1}]}}]}',
+    "width_height_types": '{"width": "1920", "height": null, "objects": []}',
+}
+REPLACE_RAISING_CASES = {
+    "coord_null": '{"objects": [{"polygon": {"ptList": [{"x": null, "y": 1}, {"x": 2, "y": 3}]}}]}',
+    "polygon_null": '{"objects": [{"polygon": null}]}',
+    "top_level_list": '[1, 2]',
+    "objects_null": '{"objects": null}',
+    "ptlist_null": '{"objects": [{"polygon": {"ptList": null}}]}',
+    "ptlist_number": '{"objects": [{"polygon": {"ptList": 5}}]}',
+    "mixed_str_int": '{"objects": [{"polygon": {"ptList": [{"x": "a", "y": 1}, {"x": 2, "y": 3}]}}]}',
+    "polygon_is_list": '{"objects": [{"polygon": [1, 2]}]}',
+    "top_level_number": '5',
+    "coord_list_vs_int": '{"objects": [{"polygon": {"ptList": [{"x": [1], "y": 1}, {"x": 2, "y": 3}]}}]}',
+}
+
+
+def _run_replace(cells, sources=None):
+    with tempfile.TemporaryDirectory() as d:
+        df = pd.DataFrame({"source": sources or [f"u{i}" for i in range(len(cells))], ANN: cells,
+                           "extra": list(range(len(cells)))})
+        inp, out, exc = (os.path.join(d, n) for n in ("in.csv", "out.csv", "exc.csv"))
+        df.to_csv(inp, index=False, encoding="utf-8-sig")
+        res = ref.process_csv_replace_ptlist(inp, out, exc)
+        return res, _read_text(inp), _read_text(out), _read_text(exc)
+
+
+def make_replace():
+    names = list(REPLACE_VALUE_CASES)
+    cells = [REPLACE_VALUE_CASES[n] for n in names] + [None]     # a NaN annotation -> excluded
+    res, inp, out, exc = _run_replace(cells, names + ["nan_annotation_row"])
+    odf = pd.read_csv(io.StringIO(out))
+    per = {}
+    for i, n in enumerate(names):
+        row = odf[odf["source"] == n].iloc[0]
+        per[n] = {"in": REPLACE_VALUE_CASES[n],
+                  "out": None if pd.isna(row[NEW]) else row[NEW],
+                  "width": None if pd.isna(row["width"]) else row["width"],
+                  "height": None if pd.isna(row["height"]) else row["height"]}
+    raising = {}
+    for n, cell in REPLACE_RAISING_CASES.items():
+        try:
+            _run_replace([REPLACE_VALUE_CASES["int_polygon"], cell])
+            raising[n] = {"in": cell, "raises": None}
+        except Exception as e:  # noqa: BLE001
+            raising[n] = {"in": cell, "raises": type(e).__name__}
+    _dump("replace_cases.json", {"result": {"filtered_rows": res["filtered_rows"], "excluded_rows": res["excluded_rows"]},
+                                 "input_csv": inp, "output_csv": out, "excluded_csv": exc,
+                                 "value_cases": per, "raising_cases": raising})
+
+
+# ------------------------------------------------------------------------------- a4
+def _bx(*boxes):
+    return json.dumps({"objects": [{"polygon": {"ptList": [{"x": b[0], "y": b[1]}, {"x": b[2], "y": b[3]}]}} for b in boxes]})
+
+
+IOU_CASES = {
+    "identical_boxes": _bx((0, 0, 10, 10), (0, 0, 10, 10)),
+    "exact_tie_098_int": _bx((0, 0, 100, 100), (0, 0, 100, 98)),
+    "exact_tie_098_float": _bx((0.0, 0.0, 100.0, 100.0), (0.0, 0.0, 100.0, 98.0)),
+    "just_below": _bx((0, 0, 100, 100), (0, 0, 100, 97)),
+    "just_below_float": _bx((0, 0, 100, 100), (0, 0, 100, 97.99999999)),
+    "disjoint": _bx((0, 0, 10, 10), (20, 20, 30, 30)),
+    "touching_edges": _bx((0, 0, 10, 10), (10, 0, 20, 10)),
+    "one_box_only": _bx((0, 0, 10, 10)),
+    "no_boxes": '{"objects": []}',
+    "third_pair_hits": _bx((0, 0, 10, 10), (50, 50, 60, 60), (50, 50, 60, 60.1)),
+    "unnormalised_corners": _bx((10, 10, 0, 0), (0, 10, 10, 0)),
+    "zero_area_identical": _bx((5, 5, 5, 5), (5, 5, 5, 5)),
+    "zero_area_line": _bx((0, 0, 10, 0), (0, 0, 10, 0)),
+    "null_box_middle_truncates": '{"objects": [' + ",".join([
+        '{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}',
+        '{"polygon": {"ptList": [{"x": null, "y": null}, {"x": null, "y": null}]}}',
+        '{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}']) + ']}',
+    "null_box_last": '{"objects": [' + ",".join([
+        '{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}',
+        '{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}',
+        '{"polygon": {"ptList": [{"x": null, "y": null}, {"x": null, "y": null}]}}']) + ']}',
+    "three_point_ptlist_skipped": '{"objects": [{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}, {"x": 1, "y": 1}]}}, {"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}, {"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}]}',
+    "guard_fail_skipped_not_truncated": '{"objects": [{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}, 7, {"polygon": {"ptList": [{"x": 0}, {"x": 10, "y": 10}]}}, {"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}]}',
+    "ptlist_null_truncates": '{"objects": [{"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}, {"polygon": {"ptList": null}}, {"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}]}',
+    "nan_coords": '{"objects": [{"polygon": {"ptList": [{"x": NaN, "y": 0}, {"x": 10, "y": 10}]}}, {"polygon": {"ptList": [{"x": 0, "y": 0}, {"x": 10, "y": 10}]}}]}',
+    "inf_coords": '{"objects": [{"polygon": {"ptList": [{"x": -Infinity, "y": 0}, {"x": Infinity, "y": 10}]}}, {"polygon": {"ptList": [{"x": -Infinity, "y": 0}, {"x": Infinity, "y": 10}]}}]}',
+    "mixed_int_float": _bx((0, 0, 100, 100), (0.0, 0.5, 100.0, 99.5)),
+    "float_rounding": _bx((0.1, 0.2, 100.3, 100.7), (0.1, 0.2, 100.3, 98.69)),
+    "undecodable": '{"objects": [',
+    "top_level_list": '[1]',
+    "bool_coords": _bx((False, False, True, True), (0, 0, 1, 1)),
+    "big_ints": _bx((0, 0, 3037000500, 3037000500), (0, 0, 3037000500, 3037000499)),
+    "negative_coords": _bx((-100, -100, -1, -1), (-100, -100, -1, -2)),
+}
+IOU_RAISING = {
+    "string_coords": _bx(("a", "b", "c", "d"), ("a", "b", "c", "d")),
+}
+IOU_PARAMS = [(2, 0.98), (3, 0.98), (2, 0.0), (2, -1.0), (1, 0.5), (2, 1.0), (0, 0.98), (2, 0.9800000000000001)]
+
+
+def _run_iou(cells, min_boxes, thr):
+    with tempfile.TemporaryDirectory() as d:
+        df = pd.DataFrame({"source": [f"u{i}" for i in range(len(cells))], NEW: cells})
+        inp, hi, lo = (os.path.join(d, n) for n in ("in.csv", "hi.csv", "lo.csv"))
+        df.to_csv(inp, index=False, encoding="utf-8-sig")
+        ref.filter_by_box_count_and_iou(inp, hi, lo, min_boxes, thr)
+        hs = set(pd.read_csv(hi)["source"]) if os.path.getsize(hi) > 4 else set()
+        return [1 if f"u{i}" in hs else 0 for i in range(len(cells))], _read_text(inp), _read_text(hi), _read_text(lo)
+
+
+def make_iou():
+    names = list(IOU_CASES)
+    cells = [IOU_CASES[n] for n in names] + [None]
+    out = {"names": names + ["nan_cell"], "cells": cells, "runs": []}
+    for mb, thr in IOU_PARAMS:
+        mask, inp, hi, lo = _run_iou(cells, mb, thr)
+        run = {"min_boxes": mb, "thr": thr, "high": mask}
+        if (mb, thr) == (2, 0.98):
+            run.update({"input_csv": inp, "high_csv": hi, "other_csv": lo})
+        out["runs"].append(run)
+    out["raising"] = {}
+    for n, cell in IOU_RAISING.items():
+        try:
+            _run_iou([cell], 2, 0.98)
+            out["raising"][n] = {"in": cell, "raises": None}
+        except Exception as e:  # noqa: BLE001
+            out["raising"][n] = {"in": cell, "raises": type(e).__name__}
+    _dump("iou_cases.json", out)
+
+
+# ------------------------------------------------------------------------------- a1 / a2
+def make_dedup():
+    cases = {
+        "strings_with_nan": "source,v\nu1,1\nu2,2\nu1,3\n,4\nu3,5\n,6\nu2,7\nU1,8\n u1,9\n",
+        "all_unique": "source,v\na,1\nb,2\nc,3\n",
+        "all_same": "source,v\na,1\na,2\na,3\n",
+        "numeric_sources": "source,v\n1,1\n2,2\n1,3\n3,4\n",
+        "float_sources_nan": "source,v\n1.5,1\n,2\n1.5,3\n,4\n0.0,5\n-0.0,6\n",
+        "unicode": "source,v\n中文,1\n中文,2\nüber,3\nuber,4\n",
+        "header_only": "source,v\n",
+    }
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, text in cases.items():
+            inp = os.path.join(d, name + ".csv")
+            with open(inp, "w", encoding="utf-8-sig") as f:
+                f.write(text)
+            out[name] = {"input_csv": text, "keep": {}}
+            for keep in ("first", "last", False):
+                o = os.path.join(d, "o.csv")
+                res = ref.deduplicate_csv_by_source(inp, o, keep=keep, verbose=False)
+                out[name]["keep"][str(keep)] = {"output_csv": _read_text(o), "rows": len(res)}
+    _dump("dedup_cases.json", out)
+
+
+def make_ref_filter():
+    cases = {
+        "strings": ("source,v\nu1,1\nu2,2\nu3,3\nu4,4\n", "source\nu2\nu4\nu9\n"),
+        "main_nan_vs_ref_nan_dropped": ("source,v\nu1,1\n,2\nu3,3\n", "source\n\nu3\n"),
+        "main_nan_vs_ref_literal_nan": ("source,v\nu1,1\n,2\nnan,3\n", "source,k\nnan,1\nx,2\n"),
+        "int_vs_int": ("source,v\n1,1\n2,2\n3,3\n", "source\n2\n5\n"),
+        "int_vs_float": ("source,v\n1,1\n2,2\n3,3\n", "source\n2.0\n\n"),
+        "float_vs_float": ("source,v\n1.0,1\n2.5,2\n,3\n", "source\n2.5\n1\n"),
+        "other_column": ("id,source\na,1\nb,2\nc,3\n", "id,z\nb,0\nq,0\n"),
+        "empty_ref": ("source,v\nu1,1\n", "source\n"),
+    }
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, (m, r) in cases.items():
+            mp, rp, op = (os.path.join(d, n) for n in ("m.csv", "r.csv", "o.csv"))
+            for p, t in ((mp, m), (rp, r)):
+                with open(p, "w", encoding="utf-8-sig") as f:
+                    f.write(t)
+            col = "id" if name == "other_column" else "source"
+            res = ref.remove_duplicates_between_csv(mp, rp, op, compare_col=col, verbose=False)
+            out[name] = {"main_csv": m, "ref_csv": r, "compare_col": col, "output_csv": _read_text(op), "rows": len(res)}
+    _dump("ref_filter_cases.json", out)
+
+
+# ------------------------------------------------------------------------------- a5
+def make_perm():
+    out = {"perms": [], "cuts": []}
+    for seed in (0, 42, 9999, 4294967295):
+        for n in (1, 2, 7, 100, 5000):
+            order = pd.DataFrame({"i": np.arange(n)}).sample(frac=1, random_state=seed)["i"].tolist()
+            out["perms"].append({"seed": seed, "n": n, "order": order})
+    for ratios in ((0.8, 0.1, 0.1), (8, 1, 1), (0.7, 0.2, 0.1), (1, 1, 1), (0.5, 0.3, 0.3)):
+        s = ratios[0] + ratios[1] + ratios[2]
+        tr, va = ratios[0] / s, ratios[1] / s
+        for n in (0, 1, 2, 3, 7, 9, 10, 11, 99, 100, 101, 1000, 8918, 12345, 10 ** 7 + 3):
+            out["cuts"].append({"ratios": list(ratios), "n": n, "n_train": int(n * tr), "n_val": int(n * va)})
+    _dump("perm_cases.json", out)
+
+
+class _Capture:
+    """Stand-in for the Excel layer (openpyxl is not installed): captures frames in memory."""
+
+    def __init__(self):
+        self.sheets = {}
+        self.current = None
+
+    def writer(self, path, *a, **k):
+        cap = self
+
+        class W:
+            def __enter__(self_w):
+                cap.current = str(os.path.basename(path))
+                return self_w
+
+            def __exit__(self_w, *e):
+                cap.current = None
+                return False
+        return W()
+
+
+def _frame_records(f):
+    return json.loads(f.to_json(orient="split", force_ascii=False))
+
+
+def run_reference_split(df, rules_df, seed=42, ratios=(0.8, 0.1, 0.1), rule_mode="wide", label_col=None, category_col=None):
+    cap = _Capture()
+    orig = (ref.pd.read_excel, ref.pd.ExcelWriter, pd.DataFrame.to_excel)
+
+    def to_excel(self, target, sheet_name="Sheet1", index=True, **k):
+        key = cap.current if cap.current else str(os.path.basename(str(target)))
+        cap.sheets.setdefault(key, {})[sheet_name] = self.copy()
+
+    ref.pd.read_excel = lambda *a, **k: rules_df
+    ref.pd.ExcelWriter = cap.writer
+    pd.DataFrame.to_excel = to_excel
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            inp = os.path.join(d, "in.csv")
+            rules = os.path.join(d, "rules.xlsx")
+            open(rules, "wb").close()
+            df.to_csv(inp, index=False, encoding="utf-8-sig")
+            res = ref.split_dataset_by_rules(inp, rules, os.path.join(d, "out"), rule_mode, None, label_col, category_col, None,
+                                             ratios[0], ratios[1], ratios[2], seed)
+            summary = res["summary"]
+            files = [os.path.basename(str(p)) for p in res["category_files"]]
+    finally:
+        ref.pd.read_excel, ref.pd.ExcelWriter, pd.DataFrame.to_excel = orig
+    return cap.sheets, summary, files
+
+
+def make_split():
+    t = synth.generate(60, seed=7, max_boxes=6)
+    df = synth.to_frame(t)
+    # a few hand-made rows: multi-label names, undefined labels, missing names, broken cells
+    extra = pd.DataFrame({"source": ["m1", "m2", "m3", "m4", "m5", "m6"], ANN: [
+        '{"objects": [{"name": "c1,c12；c19", "polygon": {"ptList": [{"x": 1, "y": 2}, {"x": 3, "y": 4}]}}]}',
+        '{"objects": [{"name": "", "polygon": {}}, {"polygon": {}}, {"name": "c18"}]}',
+        '{"objects": []}',
+        '{"objects": [',
+        '{"objects": {"a": 1}}',
+        '{"width": 5, "objects": [7, {"name": " c3 | c3 "}]}',
+    ]})
+    df = pd.concat([df, extra], ignore_index=True)
+    df.loc[len(df)] = ["m7", np.nan]
+    rules_df = pd.DataFrame({"catA": [",".join(f"c{i}" for i in range(5)), "c5;c6", "c7|c8，c9"],
+                             "catB": ["c10,c11,c12,c13", "c14；c15", "c16,c17"]})
+    sheets, summary, files = run_reference_split(df, rules_df)
+    out = {"input": _frame_records(df), "rules": _frame_records(rules_df), "seed": 42, "ratios": [0.8, 0.1, 0.1],
+           "summary": summary, "category_files": files,
+           "sheets": {k: {s: _frame_records(f) for s, f in v.items()} for k, v in sheets.items()}}
+    _dump("split_case.json", out)
+
+
+# ------------------------------------------------------------------------------- e2e
+def make_e2e(n_rows=240):
+    t = synth.generate(n_rows, seed=synth.SEED, max_boxes=12, dup_prob=0.15, tie_prob=0.03)
+    df = synth.to_frame(t)
+    df.loc[5, ANN] = np.nan                      # excluded by the replace step
+    df.loc[9, ANN] = '{"objects": ['             # undecodable -> new column empty, row kept
+    ref_df = pd.DataFrame({"source": synth.reference_urls(n_rows)})
+    with tempfile.TemporaryDirectory() as d:
+        P = lambda n: os.path.join(d, n)  # noqa: E731
+        df.to_csv(P("merged.csv"), index=False, encoding="utf-8-sig")
+        ref_df.to_csv(P("ref.csv"), index=False, encoding="utf-8-sig")
+        ref.deduplicate_csv_by_source(P("merged.csv"), P("dedup.csv"), verbose=False)
+        ref.remove_duplicates_between_csv(P("dedup.csv"), P("ref.csv"), P("filtered.csv"), verbose=False)
+        ref.process_csv_replace_ptlist(P("filtered.csv"), P("processed.csv"), P("excluded.csv"))
+        ref.filter_by_box_count_and_iou(P("processed.csv"), P("high.csv"), P("other.csv"), 2, 0.98)
+        for n in ("merged", "ref", "dedup", "filtered", "processed", "excluded", "high", "other"):
+            with open(P(n + ".csv"), "rb") as f, gzip.GzipFile(os.path.join(HERE, f"e2e_{n}.csv.gz"), "wb", mtime=0) as g:
+                g.write(f.read())
+        other = pd.read_csv(P("other.csv"), encoding="utf-8-sig")
+    rules_df = pd.DataFrame({"catA": [f"c{i}" for i in range(10)], "catB": [f"c{i}" for i in range(10, 18)] + [None, None]})
+    sheets, summary, files = run_reference_split(other, rules_df)
+    slim = {}
+    for k, v in sheets.items():
+        slim[k] = {}
+        for s, f in v.items():
+            keep = [c for c in ("source", "分类标签", "分类类别", "原始标签组合", "无法分类原因", "无法分类标签", "拆分条数", "是否可分类", NEW) if c in f.columns]
+            slim[k][s] = _frame_records(f[keep])
+    _dump("e2e_split.json", {"summary": summary, "category_files": files, "rules": _frame_records(rules_df), "sheets": slim})
+    print("wrote e2e_*.csv.gz")
+
+
+if __name__ == "__main__":
+    make_replace()
+    make_iou()
+    make_dedup()
+    make_ref_filter()
+    make_perm()
+    make_split()
+    make_e2e()

@@ -1,0 +1,212 @@
+"""Host logic of the drop-in step functions (flatten / emit / CSV contract / error behaviour),
+driven on CPU with the oracle standing in for the device stage, against the golden outputs of
+the reference.  The same golden checks run against the real HIP kernels in test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import golden_csv_text, load_golden
+from helpers import read_text, write_csv_text
+from deal_yolo_daya_amd import flatten
+from deal_yolo_daya_amd.core import processor as P
+
+EXC = {"TypeError": TypeError, "AttributeError": AttributeError}
+
+
+def run_replace_golden(backend, tmp_path):
+    g = load_golden("replace_cases.json")
+    inp, out, exc = (str(tmp_path / n) for n in ("in.csv", "out.csv", "exc.csv"))
+    write_csv_text(inp, g["input_csv"])
+    res = P.process_csv_replace_ptlist(inp, out, exc, backend=backend)
+    assert res == {"filtered_rows": g["result"]["filtered_rows"], "excluded_rows": g["result"]["excluded_rows"],
+                   "excluded_output": exc}
+    assert read_text(out) == g["output_csv"]
+    assert read_text(exc) == g["excluded_csv"]
+    for name, case in g["value_cases"].items():
+        texts, _, _ = P.replace_ptlist_cells([case["in"]], backend)
+        assert texts[0] == case["out"], name
+    for name, case in g["raising_cases"].items():
+        with pytest.raises(EXC[case["raises"]]):
+            P.replace_ptlist_cells(['{"objects": []}', case["in"]], backend)
+
+
+def run_iou_golden(backend, tmp_path):
+    g = load_golden("iou_cases.json")
+    for run in g["runs"]:
+        stats = {}
+        mask = P.iou_high_mask(g["cells"], run["min_boxes"], run["thr"], backend, stats)
+        assert mask.astype(int).tolist() == run["high"], (run["min_boxes"], run["thr"])
+        assert stats["host_rows"] == 1            # only the >2^25 integer row is resolved on the host
+        if "input_csv" in run:
+            inp, hi, lo = (str(tmp_path / n) for n in ("in.csv", "hi.csv", "lo.csv"))
+            write_csv_text(inp, run["input_csv"])
+            assert P.filter_by_box_count_and_iou(inp, hi, lo, run["min_boxes"], run["thr"], backend=backend) is None
+            assert read_text(hi) == run["high_csv"]
+            assert read_text(lo) == run["other_csv"]
+    for name, case in g["raising"].items():
+        with pytest.raises(EXC[case["raises"]]):
+            P.iou_high_mask([case["in"]], 2, 0.98, backend)
+
+
+def run_dedup_golden(backend, tmp_path):
+    g = load_golden("dedup_cases.json")
+    for name, case in g.items():
+        inp = str(tmp_path / f"{name}.csv")
+        write_csv_text(inp, case["input_csv"])
+        for keep_s, want in case["keep"].items():
+            keep = False if keep_s == "False" else keep_s
+            out = str(tmp_path / "o.csv")
+            res = P.deduplicate_csv_by_source(inp, out, keep=keep, verbose=False, backend=backend)
+            assert len(res) == want["rows"], (name, keep)
+            assert read_text(out) == want["output_csv"], (name, keep)
+            # the frame twin agrees with pandas itself (the reference's call at processor.py:140)
+            df = pd.read_csv(inp, encoding="utf-8-sig", parse_dates=False)
+            pd.testing.assert_frame_equal(P.dedup_frame(df, keep, backend),
+                                          df.drop_duplicates(subset=["source"], keep=keep, ignore_index=True))
+
+
+def run_ref_filter_golden(backend, tmp_path):
+    g = load_golden("ref_filter_cases.json")
+    for name, case in g.items():
+        m, r, o = (str(tmp_path / n) for n in ("m.csv", "r.csv", "o.csv"))
+        write_csv_text(m, case["main_csv"])
+        write_csv_text(r, case["ref_csv"])
+        res = P.remove_duplicates_between_csv(m, r, o, compare_col=case["compare_col"], verbose=False, backend=backend)
+        assert len(res) == case["rows"], name
+        assert read_text(o) == case["output_csv"], name
+
+
+def _frames_equal(got, want_records, ctx):
+    assert list(got.columns) == list(want_records["columns"]), ctx
+    data = json.loads(got.reset_index(drop=True).to_json(orient="split", force_ascii=False))["data"]
+    assert data == want_records["data"], ctx
+
+
+def run_split_golden(backend):
+    g = load_golden("split_case.json")
+    df = pd.DataFrame(g["input"]["data"], columns=g["input"]["columns"])
+    rules = pd.DataFrame(g["rules"]["data"], columns=g["rules"]["columns"])
+    res = P.split_frames(df, P.rules_to_label_map(rules), random_seed=g["seed"], backend=backend)
+    assert res["category_counts"] == g["summary"]["category_counts"]
+    assert list(res["categories"]) == [f[:-5] for f in g["category_files"]]       # first-appearance order
+    for cat, frames in res["categories"].items():
+        for name, frame in zip(("train", "val", "test"), frames):
+            _frames_equal(frame, g["sheets"][f"{cat}.xlsx"][name], (cat, name))
+    _frames_equal(res["unclassified"], g["sheets"]["unclassified.xlsx"]["Sheet1"], "unclassified")
+    _frames_equal(res["split_counts"], g["sheets"]["split_counts.xlsx"]["Sheet1"], "split_counts")
+
+
+def run_e2e_golden(backend, tmp_path):
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    for n in ("merged", "ref"):
+        write_csv_text(Q(n + ".csv"), golden_csv_text(f"e2e_{n}.csv.gz"))
+    P.deduplicate_csv_by_source(Q("merged.csv"), Q("dedup.csv"), verbose=False, backend=backend)
+    P.remove_duplicates_between_csv(Q("dedup.csv"), Q("ref.csv"), Q("filtered.csv"), verbose=False, backend=backend)
+    P.process_csv_replace_ptlist(Q("filtered.csv"), Q("processed.csv"), Q("excluded.csv"), backend=backend)
+    P.filter_by_box_count_and_iou(Q("processed.csv"), Q("high.csv"), Q("other.csv"), 2, 0.98, backend=backend)
+    for n in ("dedup", "filtered", "processed", "excluded", "high", "other"):
+        assert read_text(Q(n + ".csv")) == golden_csv_text(f"e2e_{n}.csv.gz"), n
+    g = load_golden("e2e_split.json")
+    other = pd.read_csv(Q("other.csv"), encoding="utf-8-sig")
+    rules = pd.DataFrame(g["rules"]["data"], columns=g["rules"]["columns"])
+    res = P.split_frames(other, P.rules_to_label_map(rules), backend=backend)
+    assert res["category_counts"] == g["summary"]["category_counts"]
+    for cat, frames in res["categories"].items():
+        for name, frame in zip(("train", "val", "test"), frames):
+            want = g["sheets"][f"{cat}.xlsx"][name]
+            _frames_equal(frame[want["columns"]], want, (cat, name))
+
+
+# ---------------------------------------------------------------------------------- CPU runs
+def test_replace_golden(oracle_backend, tmp_path):
+    run_replace_golden(oracle_backend, tmp_path)
+
+
+def test_iou_golden(oracle_backend, tmp_path):
+    run_iou_golden(oracle_backend, tmp_path)
+
+
+def test_dedup_golden(oracle_backend, tmp_path):
+    run_dedup_golden(oracle_backend, tmp_path)
+
+
+def test_ref_filter_golden(oracle_backend, tmp_path):
+    run_ref_filter_golden(oracle_backend, tmp_path)
+
+
+def test_split_golden(oracle_backend):
+    run_split_golden(oracle_backend)
+
+
+def test_e2e_golden(oracle_backend, tmp_path):
+    run_e2e_golden(oracle_backend, tmp_path)
+
+
+def test_error_conventions(oracle_backend, tmp_path):
+    """reference processor.py:118-137, :174-192, :237-247, :380-387, :668-671"""
+    be = oracle_backend
+    with pytest.raises(FileNotFoundError):
+        P.deduplicate_csv_by_source(str(tmp_path / "missing.csv"), backend=be)
+    txt = tmp_path / "a.txt"
+    txt.write_text("source\n1\n")
+    with pytest.raises(ValueError):
+        P.deduplicate_csv_by_source(str(txt), backend=be)
+    nos = tmp_path / "nosource.csv"
+    nos.write_text("a,b\n1,2\n")
+    with pytest.raises(KeyError):
+        P.deduplicate_csv_by_source(str(nos), None, backend=be)
+    with pytest.raises(ValueError):
+        P.dedup_keep_mask(pd.Series(["a"]), keep="bogus", backend=be)
+    with pytest.raises(FileNotFoundError):
+        P.remove_duplicates_between_csv(str(nos), str(tmp_path / "missing.csv"), backend=be)
+    with pytest.raises(KeyError):
+        P.remove_duplicates_between_csv(str(nos), str(nos), str(tmp_path / "o.csv"), backend=be)
+    assert P.process_csv_replace_ptlist(str(tmp_path / "missing.csv"), backend=be) is None
+    assert P.process_csv_replace_ptlist(str(nos), str(tmp_path / "o.csv"), backend=be) is None
+    assert P.filter_by_box_count_and_iou(str(tmp_path / "missing.csv"), backend=be) is None
+    assert P.filter_by_box_count_and_iou(str(nos), str(tmp_path / "h.csv"), str(tmp_path / "o.csv"), backend=be) is None
+    assert not (tmp_path / "h.csv").exists()
+    with pytest.raises(FileNotFoundError):
+        P.split_dataset_by_rules(str(tmp_path / "missing.csv"), str(nos), str(tmp_path / "out"), backend=be)
+
+
+def test_no_device_means_failure_not_fallback(monkeypatch, tmp_path):
+    """Without the HIP library / a gfx950 device the product raises; it never computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by the gpu suite")
+    from deal_yolo_daya_amd import _native
+    with pytest.raises(_native.NativeUnavailable):
+        P.dedup_keep_mask(pd.Series(["a", "b", "a"]))
+    with pytest.raises(_native.NativeUnavailable):
+        P.replace_ptlist_cells(['{"objects": []}'])
+
+
+def test_flatten_layout():
+    cells = ['{"objects": [{"polygon": {"ptList": [{"x": 1, "y": 2}, {"x": 3.5, "y": -4}]}}, {"polygon": {}}]}',
+             None, '{"objects": [', '{"objects": [{"polygon": {"ptList": [{"x": true, "y": 9007199254740993}]}}]}']
+    b = flatten.flatten_polygons(cells)
+    assert b.xy.tolist() == [[1.0, 2.0], [3.5, -4.0]]
+    assert b.pt_off.tolist() == [0, 2, 2, 2]
+    assert b.cell_box_off.tolist() == [0, 2, 2, 2, 3]
+    assert b.stats["host_boxes"] == 1 and list(b.host_boxes) == [2]
+    assert b.docs[1] is None and b.docs[2] is None
+
+
+def test_synth_is_regular_and_deterministic(oracle_backend):
+    from deal_yolo_daya_amd import synth
+    a, b = synth.generate(300, seed=5), synth.generate(300, seed=5)
+    assert np.array_equal(a.xy, b.xy) and np.array_equal(a.pt_off, b.pt_off)
+    df = synth.to_frame(a)
+    stats = {}
+    kept, _ = P.replace_ptlist_frame(df, oracle_backend, stats)
+    assert stats["host_boxes"] == 0 and stats["boxes"] == a.n_boxes and stats["points"] == a.n_points
+    batch = flatten.flatten_polygons(df[P.ANNOTATION_COL].tolist())
+    assert np.array_equal(batch.xy, a.xy) and np.array_equal(batch.pt_off, a.pt_off)   # frame == SoA view
+    stats = {}
+    mask = P.iou_high_mask(kept[P.BBOX_COL].tolist(), 2, 0.98, oracle_backend, stats)
+    assert stats["host_rows"] == 0
+    assert 0 < mask.sum() < len(mask)
