@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on one MI355X (device-resident inputs, HIP-event timing,
+interleaved A/B rounds in one process).  Prints one JSON line per kernel/variant.
+
+    python tools/kbench.py [--rows 1000000] [--iters 20] [--only k1,k2,...]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="k1,k2,k3,k4,k5,k6")
+    ap.add_argument("--bpr", type=int, default=0, help="fixed boxes per row (0 = U{1..32})")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+
+    import torch
+    from deal_yolo_daya_amd import _native, synth
+
+    dev = torch.device("cuda", 0)
+    L = _native.lib()
+    sp = torch.cuda.current_stream().cuda_stream
+    ck = _native.check
+
+    def timeit(fn, iters=args.iters, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts)), float(np.min(ts))
+
+    def report(name, nbytes, med, mn, **kw):
+        print(json.dumps({"kernel": name, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                          "alg_GB": round(nbytes / 1e9, 4), "GBs_median": round(nbytes / med / 1e6, 1),
+                          "frac_of_8TBs": round(nbytes / med / 1e6 / 8000, 4), **kw}), flush=True)
+
+    rows = args.rows
+    parts = []
+    for ci, s in enumerate(range(0, rows, 1_000_000)):
+        parts.append(synth.generate(min(1_000_000, rows - s), seed=synth.SEED + ci,
+                                    boxes_per_row=args.bpr or None))
+    xy = torch.cat([torch.from_numpy(t.xy) for t in parts]).to(dev)
+    npts = torch.cat([torch.from_numpy(np.diff(t.pt_off)) for t in parts]).to(dev)
+    nbox = torch.cat([torch.from_numpy(np.diff(t.box_off)) for t in parts]).to(dev)
+    url_id = np.concatenate([t.url_id for t in parts])
+    labels = torch.cat([torch.from_numpy(t.label) for t in parts]).to(dev)
+    del parts
+    P, B, N = xy.shape[0], npts.shape[0], nbox.shape[0]
+    pt_off = torch.zeros(B + 1, dtype=torch.int32, device=dev); pt_off[1:] = torch.cumsum(npts, 0).to(torch.int32)
+    box_off = torch.zeros(N + 1, dtype=torch.int32, device=dev); box_off[1:] = torch.cumsum(nbox, 0).to(torch.int32)
+    out_box = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    out_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    out_high = torch.empty(N, dtype=torch.uint8, device=dev)
+    print(json.dumps({"rows": N, "boxes": B, "points": P, "device": _native.device_name()}), flush=True)
+
+    if "k1" in only:
+        k1_bytes = 16 * P + 4 * (B + 1) + 48 * B
+        res = {}
+        for rnd in range(2):                      # interleaved rounds (guide rule 24)
+            for variant in (0, 1):
+                ck(L.dyd_set_option(b"k1_variant", variant), "opt")
+                med, mn = timeit(lambda: ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B,
+                                                                   out_box.data_ptr(), out_arg.data_ptr(), sp), "k1"))
+                res.setdefault(variant, []).append((med, mn))
+        ck(L.dyd_set_option(b"k1_variant", 0), "opt")
+        for variant, name in ((0, "k1_bbox_lds"), (1, "k1_bbox_direct")):
+            med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
+            report(name, k1_bytes, med, mn, rows_per_s=round(N / med * 1e3))
+        # copy ceiling on the same byte count for reference (torch memcpy d2d reads+writes)
+        src = torch.empty(k1_bytes // 2 // 8, dtype=torch.float64, device=dev); dst = torch.empty_like(src)
+        med, mn = timeit(lambda: dst.copy_(src))
+        report("d2d_copy_same_bytes", k1_bytes // 2 // 8 * 16, med, mn)
+        del src, dst
+
+    if "k2" in only:
+        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
+        k2_bytes = 32 * B + 4 * (N + 1) + N
+        nb64 = nbox.to(torch.int64)
+        pairs = int((nb64 * (nb64 - 1) // 2).sum().item())
+        med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, 2, 0.98,
+                                                          out_high.data_ptr(), None, sp), "k2"))
+        report("k2_iou", k2_bytes, med, mn, rows_per_s=round(N / med * 1e3), pairs=pairs,
+               gpairs_per_s=round(pairs / med / 1e6, 2), high=int(out_high.sum().item()))
+        mx = torch.empty(N, dtype=torch.float64, device=dev)
+        med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, 2, 0.98,
+                                                          out_high.data_ptr(), mx.data_ptr(), sp), "k2max"))
+        report("k2_iou_want_max", k2_bytes + 8 * N, med, mn, gpairs_per_s=round(pairs / med / 1e6, 2))
+
+    if only & {"k3", "k4", "k5"}:
+        urls = [f"http://img.example/{k}.jpg".encode() for k in url_id.tolist()]
+        off_np = np.zeros(N + 1, np.int64); np.cumsum([len(u) for u in urls], out=off_np[1:])
+        data = torch.from_numpy(np.frombuffer(b"".join(urls), np.uint8).copy()).to(dev)
+        off = torch.from_numpy(off_np).to(dev)
+        h = torch.empty((N, 2), dtype=torch.int64, device=dev)
+        k3_bytes = int(off_np[-1]) + 8 * (N + 1) + 16 * N
+        med, mn = timeit(lambda: ck(L.dyd_hash128_dev(data.data_ptr(), off.data_ptr(), N, h.data_ptr(), sp), "k3"))
+        if "k3" in only:
+            report("k3_hash128", k3_bytes, med, mn, rows_per_s=round(N / med * 1e3))
+        keep = torch.empty(N, dtype=torch.uint8, device=dev)
+        U = len(np.unique(url_id))
+        if "k4" in only:
+            for mode, nm in ((0, "first"), (1, "last"), (2, "none")):
+                med, mn = timeit(lambda: ck(L.dyd_dedup_dev(h.data_ptr(), N, mode, keep.data_ptr(), sp), "k4"))
+                report(f"k4_dedup_{nm}", 16 * N + N + 48 * U, med, mn, rows_per_s=round(N / med * 1e3),
+                       kept=int(keep.sum().item()), distinct=U)
+        if "k5" in only:
+            R = max(1, N // 10)
+            ref = h[torch.randperm(N, device=dev)[:R]].contiguous()
+            med, mn = timeit(lambda: ck(L.dyd_isin_dev(h.data_ptr(), N, ref.data_ptr(), R, keep.data_ptr(), sp), "k5"))
+            report("k5_isin", 16 * N + N + 16 * R, med, mn, rows_per_s=round(N / med * 1e3), hits=int(keep.sum().item()))
+
+    if "k6" in only:
+        E = B
+        cat = torch.where(labels < 10, 0, torch.where(labels < 18, 1, -1)).to(torch.int32).contiguous()
+        sizes = [int((cat == c).sum().item()) for c in (0, 1)]
+        perm = torch.from_numpy(np.concatenate([_native.mt19937_permutation(42, s) for s in sizes])).to(dev)
+        cat_off = torch.tensor([0, sizes[0], sizes[0] + sizes[1]], dtype=torch.int64, device=dev)
+        n_train = torch.tensor([int(s * 0.8) for s in sizes], dtype=torch.int64, device=dev)
+        n_val = torch.tensor([int(s * 0.1) for s in sizes], dtype=torch.int64, device=dev)
+        split = torch.empty(E, dtype=torch.uint8, device=dev); pos = torch.empty(E, dtype=torch.int64, device=dev)
+        med, mn = timeit(lambda: ck(L.dyd_split_ids_dev(cat.data_ptr(), E, perm.data_ptr(), cat_off.data_ptr(),
+                                                         n_train.data_ptr(), n_val.data_ptr(), 2, split.data_ptr(),
+                                                         pos.data_ptr(), sp), "k6"))
+        report("k6_split_ids", 21 * E, med, mn, expanded_rows=E, rows_per_s=round(E / med * 1e3))
+
+
+if __name__ == "__main__":
+    main()
