@@ -40,7 +40,9 @@ int ensure_init();
 // previous user of the scratch; call release_scratch(st) after the last launch that touches it.
 int get_scratch(size_t bytes, void **out, hipStream_t st);
 void release_scratch(hipStream_t st);
-inline hipStream_t pick_stream(void *s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+// `_dev` entry points launch on exactly the hipStream_t they are given (NULL = HIP's null stream,
+// which is also torch's default stream); the library's own stream serves the host-pointer calls.
+inline hipStream_t pick_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define DYD_HIP(call)                                                                      \
     do {                                                                                   \

@@ -1,0 +1,48 @@
+// k0_membench.hip — measurement aid, not part of the hot path: plain streaming kernels that
+// establish the HBM ceiling of the box the roofline fractions are quoted against
+// (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured for a float4 copy).
+#include "dyd_common.h"
+
+namespace dyd {
+
+constexpr int K0_BLOCK = 256;
+
+// mode 0: dst[i] = src[i] (16 B per lane);  mode 1: read-only (sum folded into dst[0] only if
+// non-zero to keep the loads alive);  mode 2: write-only.
+template <int MODE>
+__global__ __launch_bounds__(K0_BLOCK) void k0_stream(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                      int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * K0_BLOCK;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int64_t i = (int64_t)blockIdx.x * K0_BLOCK + threadIdx.x; i < n16; i += stride) {
+        if (MODE == 0) {
+            dst[i] = src[i];
+        } else if (MODE == 1) {
+            const uint4 v = src[i];
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        } else {
+            dst[i] = make_uint4((unsigned)i, 1u, 2u, 3u);
+        }
+    }
+    if (MODE == 1 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) dst[0] = acc;
+}
+
+}  // namespace dyd
+
+using namespace dyd;
+
+extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(mode >= 0 && mode <= 2 && bytes >= 0 && dst, "bad membench arguments");
+    const int64_t n16 = bytes / 16;
+    if (n16 == 0) return DYD_OK;
+    if (blocks <= 0) blocks = ctx().num_cu * 8;
+    hipStream_t st = pick_stream(stream);
+    const uint4 *s = static_cast<const uint4 *>(src);
+    uint4 *d = static_cast<uint4 *>(dst);
+    if (mode == 0) hipLaunchKernelGGL(k0_stream<0>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    else if (mode == 1) hipLaunchKernelGGL(k0_stream<1>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    else hipLaunchKernelGGL(k0_stream<2>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
+}

@@ -15,8 +15,8 @@
  *   - all buffers are caller-owned and contiguous.  Functions without a suffix take
  *     HOST pointers and stage H2D / D2H themselves; `_dev` twins take DEVICE
  *     pointers (from dyd_malloc, or any hipMalloc'ed memory of the same device, e.g.
- *     a torch tensor's data_ptr) plus the hipStream_t to launch on (NULL = the
- *     library's own stream).  `_dev` calls are asynchronous on that stream.
+ *     a torch tensor's data_ptr) plus the hipStream_t to launch on, used as given
+ *     (NULL = HIP's null stream).  `_dev` calls are asynchronous on that stream.
  *   - offsets arrays have n+1 entries, start at 0 and are non-decreasing.
  *   - the library keeps one lazily created context per process (device, stream,
  *     scratch); entry points are serialised by a process-wide mutex, so they may be
@@ -159,6 +159,9 @@ int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_con
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging. */
 int dyd_set_option(const char *key, int64_t value);
+/* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 16 B per
+ * lane) used to record the box's HBM ceiling next to the kernels' achieved GB/s. */
+int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream);
 
 #ifdef __cplusplus
 }

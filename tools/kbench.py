@@ -80,10 +80,15 @@ def main():
         for variant, name in ((0, "k1_bbox_lds"), (1, "k1_bbox_direct")):
             med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
             report(name, k1_bytes, med, mn, rows_per_s=round(N / med * 1e3))
-        # copy ceiling on the same byte count for reference (torch memcpy d2d reads+writes)
-        src = torch.empty(k1_bytes // 2 // 8, dtype=torch.float64, device=dev); dst = torch.empty_like(src)
+        # streaming ceilings of this box on a comparable byte count (each array 1.4 GB >> 256 MiB L3)
+        nb_ = k1_bytes // 2 // 16 * 16
+        src = torch.empty(nb_ // 8, dtype=torch.float64, device=dev).normal_(); dst = torch.empty_like(src)
+        for blocks in (2048, 8192):
+            for mode, nm, tot in ((0, "copy", 2 * nb_), (1, "read", nb_), (2, "write", nb_)):
+                med, mn = timeit(lambda: ck(L.dyd_membench_dev(mode, src.data_ptr(), dst.data_ptr(), nb_, blocks, sp), "mb"))
+                report(f"membench_{nm}_b{blocks}", tot, med, mn)
         med, mn = timeit(lambda: dst.copy_(src))
-        report("d2d_copy_same_bytes", k1_bytes // 2 // 8 * 16, med, mn)
+        report("torch_d2d_copy", 2 * nb_, med, mn)
         del src, dst
 
     if "k2" in only:
