@@ -180,6 +180,16 @@ def main():
         else:
             k1_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
             k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes over this same
+        # command (tools/gpu_profile.sh -> tools/collect_profiles.py), FETCH_SIZE doubled as the
+        # microarch guide prescribes for gfx950; reported only for the workload it was measured on.
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "k1_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                tj = json.load(fh)
+            if tj.get("rows_per_gpu") == rows and tj.get("workload") == args.workload and not args.fused:
+                traffic = tj["traffic_bytes_per_launch"]
         k1_bytes = 16 * P + 4 * (B + 1) + 48 * B
         k2_bytes = 32 * B + 4 * (N + 1) + N
         alg_bytes = k1_bytes + (k2_bytes if args.fused else 0)
@@ -205,7 +215,7 @@ def main():
                        "device": _native.device_name()},
             "roofline": {"bound": "hbm", "kernel": "k1_bbox_lds" if not args.fused else "fused",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_achievable_6290": achieved / 6290.0},
         }

@@ -73,6 +73,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p]),
     "dyd_split_ids_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_split_ids_sharded_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "dyd_membench_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
 }

@@ -101,13 +101,17 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_assign(const int32_t *__restrict_
                                                       const int64_t *__restrict__ cat_off,
                                                       const int64_t *__restrict__ n_train,
                                                       const int64_t *__restrict__ n_val,
+                                                      const int64_t *__restrict__ rank_base,
                                                       uint8_t *__restrict__ out_split, int64_t *__restrict__ out_pos) {
     __shared__ unsigned int s_cnt[K6_WAVES][K6_CATS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * K6_WAVES + wave;
     if (tile >= n_tiles) return;  // no workgroup barrier below: waves are independent
     const int32_t nc = c1 - c0;
-    for (int c = lane; c < nc; c += kWave) s_cnt[wave][c] = hist[(int64_t)c * n_tiles + tile];
+    // running in-category rank at the start of this tile; rank_base (multi-GPU) = rows of the
+    // category held by lower ranks
+    for (int c = lane; c < nc; c += kWave)
+        s_cnt[wave][c] = hist[(int64_t)c * n_tiles + tile] + (rank_base ? (unsigned int)rank_base[c0 + c] : 0u);
     __builtin_amdgcn_wave_barrier();
     const int64_t r0 = tile * K6_TILE;
     const int64_t r1 = (r0 + K6_TILE < n) ? r0 + K6_TILE : n;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_unclassified(const int32_t *__res
 
 static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, const int64_t *cat_off,
                         const int64_t *n_train, const int64_t *n_val, int32_t n_cat, int64_t total,
-                        uint8_t *out_split, int64_t *out_pos, hipStream_t st) {
+                        const int64_t *rank_base, uint8_t *out_split, int64_t *out_pos, hipStream_t st) {
     const int64_t n_tiles = ceil_div(n, K6_TILE);
     const int64_t blocks = ceil_div(n_tiles, K6_WAVES);
     const int32_t win = n_cat < K6_CATS ? n_cat : K6_CATS;
@@ -187,7 +191,7 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
         hipLaunchKernelGGL(k6_scan, dim3((unsigned)(c1 - c0)), dim3(K6_BLOCK), 0, st, hist, n_tiles);
         DYD_HIP(hipGetLastError());
         hipLaunchKernelGGL(k6_assign, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist, inv,
-                           cat_off, n_train, n_val, out_split, out_pos);
+                           cat_off, n_train, n_val, rank_base, out_split, out_pos);
         DYD_HIP(hipGetLastError());
     }
     release_scratch(st);
@@ -210,7 +214,7 @@ int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_con
     if (n == 0) return DYD_OK;
     DYD_REQUIRE(cat && out_split && out_pos, "null pointer");
     DYD_REQUIRE(n_cat == 0 || (cat_perm_concat && cat_off && n_train && n_val), "null pointer");
-    DYD_REQUIRE(n < (1LL << 40), "n too large");
+    DYD_REQUIRE(n < (1LL << 32), "n too large");
     hipStream_t st = pick_stream(stream);
     int64_t total = 0;
     if (n_cat > 0) {
@@ -218,7 +222,28 @@ int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_con
         DYD_HIP(hipStreamSynchronize(st));
         DYD_REQUIRE(total >= 0, "cat_off[n_cat] < 0");
     }
-    return split_launch(cat, n, cat_perm_concat, cat_off, n_train, n_val, n_cat, total, out_split, out_pos, st);
+    return split_launch(cat, n, cat_perm_concat, cat_off, n_train, n_val, n_cat, total, nullptr, out_split, out_pos,
+                        st);
+}
+
+int dyd_split_ids_sharded_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat, const int64_t *cat_off,
+                              const int64_t *n_train, const int64_t *n_val, int32_t n_cat,
+                              const int64_t *cat_rank_base, uint8_t *out_split, int64_t *out_pos, void *stream) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0 && n_cat >= 0, "negative size");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(cat && out_split && out_pos, "null pointer");
+    DYD_REQUIRE(n_cat == 0 || (cat_perm_concat && cat_off && n_train && n_val && cat_rank_base), "null pointer");
+    DYD_REQUIRE(n < (1LL << 32), "n too large");
+    hipStream_t st = pick_stream(stream);
+    int64_t total = 0;
+    if (n_cat > 0) {
+        DYD_HIP(hipMemcpyAsync(&total, cat_off + n_cat, 8, hipMemcpyDeviceToHost, st));
+        DYD_HIP(hipStreamSynchronize(st));
+        DYD_REQUIRE(total >= 0, "cat_off[n_cat] < 0");
+    }
+    return split_launch(cat, n, cat_perm_concat, cat_off, n_train, n_val, n_cat, total, cat_rank_base, out_split,
+                        out_pos, st);
 }
 
 int dyd_split_ids(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat, const int64_t *cat_off,
@@ -251,7 +276,7 @@ int dyd_split_ids(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat,
     }
     KernelTimer t(st);
     rc = split_launch(d_cat.as<int32_t>(), n, d_perm.as<int64_t>(), d_off.as<int64_t>(), d_tr.as<int64_t>(),
-                      d_va.as<int64_t>(), n_cat, total, d_split.as<uint8_t>(), d_pos.as<int64_t>(), st);
+                      d_va.as<int64_t>(), n_cat, total, nullptr, d_split.as<uint8_t>(), d_pos.as<int64_t>(), st);
     if (rc) return rc;
     t.finish();
     DYD_HIP(hipMemcpyAsync(out_split, d_split.p, (size_t)n, hipMemcpyDeviceToHost, st));

@@ -1,0 +1,182 @@
+"""Multi-GPU (one process per GPU) execution of the hot path — SURVEY §8e.
+
+Rows shard contiguously: rank r owns global rows [r*N/G, (r+1)*N/G), so "first occurrence" is the
+lowest (rank, local index).  The poly->bbox (K1) and IoU (K2) stages are independent per row and
+need no communication.  The two set-valued stages exchange hashes exactly once:
+
+    dedup       K3 hash local rows -> ONE all-gather of 16-B keys (RCCL over xGMI) -> every rank
+                inserts all keys into its table, resolves only its own rows (dyd_dedup_global_dev)
+    ref filter  K3 hash local main rows and local reference rows -> ONE all-gather of the
+                reference keys -> K5 probe of the local main keys
+    split       ONE all-gather of per-rank per-category counts (n_cat x 8 B) -> each rank's
+                in-category ranks start at the sum of the lower ranks' counts
+                (dyd_split_ids_sharded_dev); the MT19937 permutation of each GLOBAL category size
+                is computed on every host identically.
+
+``torch.distributed`` is the plumbing (backend "nccl" is RCCL on ROCm; tests use "gloo" on CPU).
+The device work goes through an ``ops`` object: ``HipOps`` (below) drives the ``_dev`` entry
+points of libdyd_gfx950.so on tensors resident in HBM; the CPU test-suite injects its own.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import flatten as _fl
+
+_KEEP = {"first": 0, "last": 1, False: 2}
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple:
+    """Contiguous row range of `rank`: sizes differ by at most one row."""
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi
+
+
+def shard_bounds_weighted(weight_prefix: np.ndarray, world: int, rank: int) -> tuple:
+    """Contiguous row range with ~equal total weight (e.g. boxes per row): weight_prefix is the
+    inclusive prefix sum of the per-row weights (the box offsets without the leading 0)."""
+    n = len(weight_prefix)
+    total = int(weight_prefix[-1]) if n else 0
+    cut = lambda r: int(np.searchsorted(weight_prefix, total * r / world, side="left")) if r < world else n  # noqa: E731
+    return (0 if rank == 0 else cut(rank)), cut(rank + 1)
+
+
+class HipOps:
+    """Device stage on the rank's GPU through the C ABI (_dev entry points, torch tensors in HBM)."""
+
+    def __init__(self, device=None):
+        from . import _native
+
+        self.native = _native
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.L = _native.load_library()
+        _native.check(self.L.dyd_init(self.device.index or 0), "dyd_init")
+        self.L = _native.lib()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def tensor(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def hash128(self, data: torch.Tensor, off: torch.Tensor) -> torch.Tensor:
+        n = off.numel() - 1
+        out = torch.empty((n, 2), dtype=torch.int64, device=self.device)
+        if n:
+            self.native.check(self.L.dyd_hash128_dev(data.data_ptr(), off.data_ptr(), n, out.data_ptr(), self._stream()),
+                              "dyd_hash128_dev")
+        return out
+
+    def dedup_global(self, all_h: torch.Tensor, first: int, n_local: int, keep) -> torch.Tensor:
+        out = torch.empty(n_local, dtype=torch.uint8, device=self.device)
+        if n_local:
+            self.native.check(self.L.dyd_dedup_global_dev(all_h.data_ptr(), all_h.shape[0], first, n_local, _KEEP[keep],
+                                                          out.data_ptr(), self._stream()), "dyd_dedup_global_dev")
+        return out
+
+    def isin(self, h: torch.Tensor, ref_h: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(h.shape[0], dtype=torch.uint8, device=self.device)
+        if h.shape[0]:
+            self.native.check(self.L.dyd_isin_dev(h.data_ptr(), h.shape[0], ref_h.data_ptr() if ref_h.shape[0] else None,
+                                                  ref_h.shape[0], out.data_ptr(), self._stream()), "dyd_isin_dev")
+        return out
+
+    def split_ids_sharded(self, cat, perm, cat_off, n_train, n_val, rank_base):
+        n = cat.numel()
+        split = torch.empty(n, dtype=torch.uint8, device=self.device)
+        pos = torch.empty(n, dtype=torch.int64, device=self.device)
+        if n:
+            self.native.check(self.L.dyd_split_ids_sharded_dev(
+                cat.data_ptr(), n, perm.data_ptr(), cat_off.data_ptr(), n_train.data_ptr(), n_val.data_ptr(),
+                n_train.numel(), rank_base.data_ptr(), split.data_ptr(), pos.data_ptr(), self._stream()),
+                "dyd_split_ids_sharded_dev")
+        return split, pos
+
+    def permutation(self, seed: int, n: int) -> np.ndarray:
+        return self.native.mt19937_permutation(seed, n)
+
+
+def all_gather_rows(t: torch.Tensor, group=None) -> tuple:
+    """Concatenate every rank's [n_r, ...] tensor in rank order with ONE data collective
+    (all_gather_into_tensor on shards padded to the largest; shards differ by <= 1 row).
+    -> (gathered [sum n_r, ...], counts per rank)"""
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts_t = torch.empty(world, dtype=torch.int64, device=t.device)
+    dist.all_gather_into_tensor(counts_t, n_local, group=group)
+    counts = counts_t.tolist()
+    m = max(counts)
+    padded = t
+    if t.shape[0] != m:
+        padded = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        padded[: t.shape[0]] = t
+    out = torch.empty((world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(c == m for c in counts):
+        return out, counts
+    return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)]), counts
+
+
+def _local_keys(col, ops, for_isin: bool = False, drop_na: bool = False) -> torch.Tensor:
+    """K3 over this rank's cells -> [n, 2] int64 keys resident on the device."""
+    if for_isin:
+        data, off = _fl.column_str_bytes(col, drop_na=drop_na)
+        na = None
+    else:
+        data, off, na = _fl.column_key_bytes(col)
+    h = ops.hash128(ops.tensor(np.ascontiguousarray(data)), ops.tensor(off))
+    if na is not None and na.any():
+        h[ops.tensor(na)] = ops.tensor(_fl.NA_KEY.view(np.int64))
+    return h
+
+
+def dedup_keep_mask_sharded(local_col, keep="first", ops=None, group=None) -> np.ndarray:
+    """keep-mask of this rank's shard of ``drop_duplicates(keep=keep)`` over the GLOBAL column
+    (reference core/processor.py:140-144)."""
+    if keep not in _KEEP:
+        raise ValueError('keep must be either "first", "last" or False')
+    ops = ops or HipOps()
+    h = _local_keys(local_col, ops)
+    all_h, counts = all_gather_rows(h, group)
+    rank = dist.get_rank(group)
+    first = int(sum(counts[:rank]))
+    return ops.dedup_global(all_h, first, counts[rank], keep).cpu().numpy().astype(bool)
+
+
+def ref_hit_mask_sharded(local_main_col, local_ref_col, ops=None, group=None) -> np.ndarray:
+    """``main.astype(str).isin(set(ref.dropna().astype(str)))`` for this rank's main rows, with
+    the reference column sharded too (reference core/processor.py:194-198)."""
+    ops = ops or HipOps()
+    hm = _local_keys(local_main_col, ops, for_isin=True)
+    hr = _local_keys(local_ref_col, ops, for_isin=True, drop_na=True)
+    all_ref, _ = all_gather_rows(hr, group)
+    return ops.isin(hm, all_ref).cpu().numpy().astype(bool)
+
+
+def split_ids_sharded(local_cat: np.ndarray, n_cat: int, train_ratio=0.8, val_ratio=0.1, test_ratio=0.1,
+                      random_seed: int = 42, ops=None, group=None) -> tuple:
+    """(split id u8, shuffled position i64) for this rank's shard of the expanded rows; category
+    ids are GLOBAL ids in [0, n_cat) (-1 = unclassified) (reference core/processor.py:796-806)."""
+    from .core.processor import split_cut_sizes
+
+    ops = ops or HipOps()
+    rank = dist.get_rank(group)
+    local_cat = np.ascontiguousarray(local_cat, dtype=np.int32)
+    counts = np.bincount(local_cat[local_cat >= 0], minlength=n_cat).astype(np.int64)
+    all_counts, _ = all_gather_rows(ops.tensor(counts.reshape(1, -1)), group)       # [world, n_cat]
+    all_counts = all_counts.cpu().numpy()
+    sizes = all_counts.sum(axis=0)
+    rank_base = all_counts[:rank].sum(axis=0).astype(np.int64)
+    cat_off = np.zeros(n_cat + 1, np.int64)
+    np.cumsum(sizes, out=cat_off[1:])
+    perm = (np.concatenate([ops.permutation(random_seed, int(s)) for s in sizes])
+            if n_cat else np.zeros(0, np.int64))
+    cuts = [split_cut_sizes(int(s), train_ratio, val_ratio, test_ratio) for s in sizes]
+    n_train = np.asarray([c[0] for c in cuts], np.int64)
+    n_val = np.asarray([c[1] for c in cuts], np.int64)
+    split, pos = ops.split_ids_sharded(ops.tensor(local_cat), ops.tensor(perm), ops.tensor(cat_off),
+                                       ops.tensor(n_train), ops.tensor(n_val), ops.tensor(rank_base))
+    return split.cpu().numpy(), pos.cpu().numpy()

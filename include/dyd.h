@@ -156,6 +156,14 @@ int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_con
                       const int64_t *cat_off, const int64_t *n_train, const int64_t *n_val,
                       int32_t n_cat, uint8_t *out_split, int64_t *out_pos, void *stream);
 
+/* multi-GPU K6: the rank holds a contiguous shard of the expanded rows; cat_rank_base[c] = number
+ * of rows of category c held by lower ranks (from one allgather of per-rank category counts),
+ * cat_off / perm / n_train / n_val describe the GLOBAL categories. */
+int dyd_split_ids_sharded_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat,
+                              const int64_t *cat_off, const int64_t *n_train, const int64_t *n_val,
+                              int32_t n_cat, const int64_t *cat_rank_base, uint8_t *out_split,
+                              int64_t *out_pos, void *stream);
+
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging. */
 int dyd_set_option(const char *key, int64_t value);

@@ -226,3 +226,59 @@ def test_default_backend_is_native(native):
     assert default_backend() is native
     from deal_yolo_daya_amd.core import processor as P
     assert P.dedup_keep_mask(pd.Series(["a", "b", "a", None, None])).tolist() == [True, True, False, True, False]
+
+
+# ------------------------------------------------------------------------------------- multi-GPU pieces on one GPU
+def test_sharded_device_stage_one_process(native):
+    """The device side of the sharded path (global-key table, rank-based split) with the
+    all-gather emulated in-process: G shards of one table must reproduce the unsharded masks."""
+    import torch
+    from deal_yolo_daya_amd import distributed as D
+    from deal_yolo_daya_amd import flatten
+
+    ops = D.HipOps("cuda:0")
+    rng = np.random.default_rng(77)
+    n, G = 40007, 4
+    ids = rng.integers(0, 15000, size=n)
+    src = pd.Series([None if k % 211 == 0 else f"http://img.example/{k}.jpg" for k in ids.tolist()], dtype=object)
+    bounds = [D.shard_bounds(n, G, r) for r in range(G)]
+    keys = [D._local_keys(src.iloc[lo:hi], ops) for lo, hi in bounds]
+    all_h = torch.cat(keys)
+    for keep in ("first", "last", False):
+        got = np.concatenate([ops.dedup_global(all_h, lo, hi - lo, keep).cpu().numpy() for lo, hi in bounds])
+        assert np.array_equal(got.astype(bool), ~src.duplicated(keep=keep).to_numpy()), keep
+    cat = rng.integers(-1, 5, size=n).astype(np.int32)
+    sizes = np.bincount(cat[cat >= 0], minlength=5).astype(np.int64)
+    off = np.zeros(6, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    perm = np.concatenate([native.mt19937_permutation(7, int(s)) for s in sizes])
+    tr, va = (sizes * 0.8).astype(np.int64), (sizes * 0.1).astype(np.int64)
+    want = olib.split_ids(cat, perm, off, tr, va)
+    got_s, got_p = [], []
+    for lo, hi in bounds:
+        base = np.bincount(cat[:lo][cat[:lo] >= 0], minlength=5).astype(np.int64)
+        s, p = ops.split_ids_sharded(ops.tensor(cat[lo:hi]), ops.tensor(perm), ops.tensor(off), ops.tensor(tr),
+                                     ops.tensor(va), ops.tensor(base))
+        got_s.append(s.cpu().numpy()); got_p.append(p.cpu().numpy())
+    assert np.array_equal(np.concatenate(got_s), want[0]) and np.array_equal(np.concatenate(got_p), want[1])
+
+
+def test_sharded_functions_world1_rccl(native):
+    """The collective plumbing on the GPU: a world_size-1 RCCL group (one rank per GPU)."""
+    import torch
+    import torch.distributed as dist
+    from deal_yolo_daya_amd import distributed as D
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                                device_id=torch.device("cuda:0"))
+    try:
+        ops = D.HipOps("cuda:0")
+        src = pd.Series(["a", "b", "a", None, "c", None, "b"], dtype=object)
+        assert D.dedup_keep_mask_sharded(src, "first", ops).tolist() == [True, True, False, True, True, False, False]
+        assert D.ref_hit_mask_sharded(src, pd.Series(["b", "nan", None], dtype=object), ops).tolist() == \
+            [False, True, False, True, False, True, True]
+        split, pos = D.split_ids_sharded(np.array([0, 1, 0, -1, 0, 1], np.int32), 2, ops=ops)
+        assert split[3] == 255 and sorted(pos[[0, 2, 4]].tolist()) == [0, 1, 2]
+    finally:
+        dist.destroy_process_group()

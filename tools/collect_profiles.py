@@ -48,3 +48,12 @@ if os.path.exists(bl):
     if lines:
         with open(os.path.join(prof, f"{tag}_bench.json"), "w") as fh:
             fh.write(lines[-1])
+
+k1 = summary.get("dyd::k1_bbox_lds", {}).get("hbm_traffic_bytes_per_launch")
+bj = os.path.join(prof, f"{tag}_bench.json")
+if k1 and os.path.exists(bj):
+    cfg = json.load(open(bj))["config"]
+    with open(os.path.join(prof, "k1_traffic.json"), "w") as fh:
+        json.dump({"workload": "c2", "rows_per_gpu": cfg["rows_per_gpu"], "traffic_bytes_per_launch": k1["total_corrected"],
+                   "read_bytes_fetch_size_x2": k1["read_corrected_x2"], "write_bytes": k1["write"],
+                   "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}, fh, indent=1)
