@@ -5,12 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (K1 polygon->bbox, then K2 all-pairs IoU flag on K1's
-boxes) over one batch of synthetic rows that is already resident in HBM.  Default workload =
+boxes; by default both run inside ONE fused launch) over one batch of synthetic rows that is
+already resident in HBM.  Default workload =
 BASELINE.json configs[1]: 1M rows per GPU, <=32 boxes/image (weak scaling: every rank owns its
 own 1M-row shard, no data-path collective — rows are independent).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     : dominant kernel (K1) — algorithmic bytes / HIP-event time vs 8 TB/s HBM peak
+  roofline     : dominant kernel (the fused K1+K2 kernel; K1 with --fused 0) — algorithmic bytes /
+                 HIP-event time vs 8 TB/s HBM peak
   cpu_baseline : the CPU port of the reference path (oracle/steps.py) timed on this box's host,
                  rank 0 at N=1 only, on a bounded sample of the same synthetic rows.
 """
@@ -72,7 +74,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (overrides the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="rows for the CPU baseline (0 = skip)")
-    ap.add_argument("--fused", type=int, default=0, help="1 = launch K1+K2 through dyd_bbox_iou_fused_dev")
+    ap.add_argument("--fused", type=int, default=1,
+                    help="1 = one fused K1+K2 launch (dyd_bbox_iou_fused_dev, default); 0 = K1 launch then K2 launch")
     args = ap.parse_args()
 
     import torch
@@ -150,7 +153,10 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        k1(); k2()
+        if args.fused:
+            fused()
+        else:
+            k1(); k2()
     torch.cuda.synchronize()
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -188,11 +194,13 @@ def main():
         if os.path.exists(tf):
             with open(tf) as fh:
                 tj = json.load(fh)
-            if tj.get("rows_per_gpu") == rows and tj.get("workload") == args.workload and not args.fused:
+            if (tj.get("rows_per_gpu") == rows and tj.get("workload") == args.workload
+                    and bool(tj.get("fused")) == bool(args.fused)):
                 traffic = tj["traffic_bytes_per_launch"]
         k1_bytes = 16 * P + 4 * (B + 1) + 48 * B
         k2_bytes = 32 * B + 4 * (N + 1) + N
-        alg_bytes = k1_bytes + (k2_bytes if args.fused else 0)
+        # fused launch: K2's 32*B box read is not compulsory traffic (the boxes were just produced)
+        alg_bytes = (k1_bytes + 4 * (N + 1) + N) if args.fused else k1_bytes
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         line = {
             "metric": "annotation rows/sec through poly->bbox + IoU-filter path",
@@ -213,7 +221,7 @@ def main():
                        "k1_ms": k1_ms, "k2_ms": k2_ms,
                        "k2_gbs": (k2_bytes / (k2_ms * 1e-3) / 1e9) if k2_ms else None,
                        "device": _native.device_name()},
-            "roofline": {"bound": "hbm", "kernel": "k1_bbox_lds" if not args.fused else "fused",
+            "roofline": {"bound": "hbm", "kernel": "k1_bbox_lds" if not args.fused else "k12_fused_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes,

@@ -91,11 +91,26 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _one_hip_runtime_per_process():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If this library pulled in
+    /opt/rocm's copy first and torch initialised its bundled copy afterwards, the process would hold
+    two HIP runtimes and the second one finds no GPU.  Importing torch first (when it is installed)
+    makes libdyd_gfx950.so bind to the runtime torch uses, so device pointers and streams are shared."""
+    import sys
+
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional plumbing; without it /opt/rocm's runtime is used
+            pass
+
+
 def load_library():
     """dlopen the library and declare every prototype.  Does not touch the GPU."""
     global _lib
     with _lock:
         if _lib is None:
+            _one_hip_runtime_per_process()
             if not os.path.exists(LIB_PATH):
                 raise NativeUnavailable(
                     f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

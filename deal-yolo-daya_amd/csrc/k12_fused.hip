@@ -1,19 +1,89 @@
-// k12_fused.hip — poly -> bbox -> IoU flag for rows whose boxes all come from K1
-// (reference ui/pages/processing.py:580-598 runs process_csv_replace_ptlist and
-// filter_by_box_count_and_iou back to back on the same rows), plus the tuning hook.
+// k12_fused.hip — K1+K2 fused: poly -> bbox -> IoU flag in ONE launch, plus the tuning hook.
 //
-// K1's out_box4 is (min_x, min_y, max_x, max_y), which is exactly the two-point ptList the
-// reference's IoU step reads back (processor.py:260 -> :354-362), so K2 consumes it directly.
+// reference ui/pages/processing.py:580-598 runs process_csv_replace_ptlist and
+// filter_by_box_count_and_iou back to back on the same rows; K1's out_box4 =
+// (min_x, min_y, max_x, max_y) is exactly the two-point ptList the IoU step reads back
+// (processor.py:260 -> :354-362), so K2 can consume it directly.
+//
+// Mapping: a 256-thread workgroup owns K2_WAVES * K2_WROWS = 64 consecutive image rows, i.e. one
+// contiguous box range and one contiguous point range.
+//   phase 1 (K1, HBM-bound): the box range is processed in tiles of 256 boxes exactly as
+//     k1_bbox_lds does (points streamed HBM -> LDS, lane-per-box first-wins scan), results go to
+//     out_box4 / out_arg4;
+//   phase 2 (K2, VALU-bound): after one workgroup barrier each wave runs the wave-autonomous IoU
+//     code on its 16 rows, reading the boxes the workgroup has just written — they are still in
+//     the XCD's L2, so K2's 32 B/box never come from HBM again.
+// The two phases use the same LDS bytes (point chunk, then the waves' box columns), so the
+// occupancy is that of K2 alone (4 workgroups per CU), and while one workgroup's waves are busy
+// with pair arithmetic the other workgroups of the CU keep the memory pipeline streaming:
+// the VALU-bound part hides under the HBM-bound part.
+// Algorithmic bytes per launch: 16*P + 4*(B+1) + 48*B + 4*(N+1) + N.
 #include <cstring>
 
-#include "dyd_common.h"
+#include "k1_tile.h"
+#include "k2_wave.h"
 
 namespace dyd {
+
+// CHUNK = K1 point-chunk size, (WROWS, WCAP) = K2 per-wave tile.  The two phases alias one LDS
+// buffer, so its size — and the number of workgroups a CU can hold — is the larger of the two.
+template <int CHUNK, int WROWS, int WCAP>
+__global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__restrict__ xy,
+                                                             const int32_t *__restrict__ pt_off,
+                                                             const int32_t *__restrict__ box_off, int64_t n_rows,
+                                                             int32_t min_boxes, double thr, double *out_box4,
+                                                             int32_t *__restrict__ out_arg4,
+                                                             uint8_t *__restrict__ out_high) {
+    using Slice = WaveLdsT<WROWS, WCAP>;
+    constexpr size_t kLds = sizeof(double2) * CHUNK > sizeof(Slice) * K2_WAVES ? sizeof(double2) * CHUNK
+                                                                              : sizeof(Slice) * K2_WAVES;
+    constexpr int kRows = K2_WAVES * WROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kLds];
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    const int64_t row1 = (row0 + kRows < n_rows) ? row0 + kRows : n_rows;
+    const int64_t bA = box_off[row0], bB = box_off[row1];  // workgroup-uniform
+    // ---- phase 1: K1 over the workgroup's boxes ------------------------------------------------
+    double2 *s_pts = reinterpret_cast<double2 *>(s_raw);
+    for (int64_t b0 = bA; b0 < bB; b0 += K1_BLOCK)
+        k1_process_tile<CHUNK>(xy, pt_off, b0, bB, out_box4, out_arg4, s_pts);
+    // every wave's box stores are complete and visible to the workgroup; LDS may be reused
+    __syncthreads();
+    // ---- phase 2: K2, one wave per WROWS rows, no further workgroup barrier ------------------------
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = row0 + (int64_t)wave * WROWS;
+    if (r0 >= n_rows) return;
+    const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
+    Slice *S = reinterpret_cast<Slice *>(s_raw);
+    k2_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
+}
+
+template <int CHUNK, int WROWS, int WCAP>
+static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
+                        int32_t min_boxes, double thr, double *out_box4, int32_t *out_arg4, uint8_t *out_high,
+                        hipStream_t st) {
+    const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
+    if (blocks > 0x7fffffffLL) {
+        set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
+        return DYD_ERR_RANGE;
+    }
+    hipLaunchKernelGGL((k12_fused_kernel<CHUNK, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K1_BLOCK), 0, st,
+                       reinterpret_cast<const double2 *>(xy), pt_off, box_off, n_rows, min_boxes, thr, out_box4,
+                       out_arg4, out_high);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
+}
+
 int launch_k1(const double *xy, const int32_t *pt_off, int64_t n_boxes, double *out_box4, int32_t *out_arg4,
               hipStream_t st);
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
               uint8_t *out_high, double *out_max, hipStream_t st);
 void set_k1_variant(int v);
+void set_k2_variant(int v);
+
+// -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
+// 2 = fused <1024,8,128>, 3 = fused <1024,16,256>
+static int g_fused_variant = -1;
+
 }  // namespace dyd
 
 using namespace dyd;
@@ -31,9 +101,18 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
                   reinterpret_cast<uintptr_t>(out_arg4)) & 15) == 0,
                 "xy / out_box4 / out_arg4 must be 16-byte aligned");
     hipStream_t st = pick_stream(stream);
-    int rc = launch_k1(xy, pt_off, n_boxes, out_box4, out_arg4, st);
-    if (rc) return rc;
-    return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st);
+    if (g_fused_variant == 1) {
+        int rc = launch_k1(xy, pt_off, n_boxes, out_box4, out_arg4, st);
+        if (rc) return rc;
+        return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st);
+    }
+    int v = g_fused_variant;
+    if (v < 0) v = (n_boxes <= 24 * n_rows) ? 2 : 0;  // sparse rows: the small tiles give twice the occupancy
+    if (v == 2)
+        return launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    if (v == 3)
+        return launch_fused<1024, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    return launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
 }
 
 // Tuning / A-B hook (not part of the reference-facing ABI): selects kernel variants.
@@ -42,6 +121,14 @@ int dyd_set_option(const char *key, int64_t value) {
     if (!key) return DYD_ERR_INVALID;
     if (!strcmp(key, "k1_variant")) {
         set_k1_variant((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "k2_variant")) {
+        set_k2_variant((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "fused_variant")) {
+        g_fused_variant = (int)value;
         return DYD_OK;
     }
     set_error("unknown option %s", key);

@@ -13,80 +13,18 @@
 // with strict </> compares — exactly CPython's sequential builtin min/max, so the first
 // extremal element wins, -0.0/0.0 and int/float ties keep the lower index and a NaN survives
 // only from position 0.  A box longer than a chunk simply spans several chunks.
-#include "dyd_common.h"
+#include "k1_tile.h"
 
 namespace dyd {
 
-constexpr int K1_BLOCK = 256;
-constexpr int K1_CHUNK = 2048;  // points per LDS chunk: 32 KiB -> 5 workgroups (20 waves) per CU
-
-struct BoxAcc {
-    double mnx, mny, mxx, mxy;
-    int32_t imnx, imny, imxx, imxy;
-    __device__ __forceinline__ void first(double x, double y) {
-        mnx = mxx = x;
-        mny = mxy = y;
-        imnx = imny = imxx = imxy = 0;
-    }
-    __device__ __forceinline__ void next(double x, double y, int32_t k) {
-        if (x < mnx) { mnx = x; imnx = k; }
-        if (x > mxx) { mxx = x; imxx = k; }
-        if (y < mny) { mny = y; imny = k; }
-        if (y > mxy) { mxy = y; imxy = k; }
-    }
-    __device__ __forceinline__ void empty() {
-        mnx = mny = mxx = mxy = __builtin_nan("");
-        imnx = imny = imxx = imxy = -1;
-    }
-    __device__ __forceinline__ void store(double *out_box4, int32_t *out_arg4, int64_t b) const {
-        double2 *ob = reinterpret_cast<double2 *>(out_box4 + 4 * b);
-        ob[0] = make_double2(mnx, mny);
-        ob[1] = make_double2(mxx, mxy);
-        *reinterpret_cast<int4 *>(out_arg4 + 4 * b) = make_int4(imnx, imny, imxx, imxy);
-    }
-};
-
-// LDS-staged tile kernel (the product path).
+// LDS-staged tile kernel (the product path): one tile of K1_BLOCK boxes per workgroup.
 __global__ __launch_bounds__(K1_BLOCK) void k1_bbox_lds(const double2 *__restrict__ xy,
                                                         const int32_t *__restrict__ pt_off,
                                                         int64_t n_boxes,
                                                         double *__restrict__ out_box4,
                                                         int32_t *__restrict__ out_arg4) {
     __shared__ double2 s_pts[K1_CHUNK];
-    const int tid = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * K1_BLOCK;
-    const int64_t b = b0 + tid;
-    const bool active = b < n_boxes;
-    const int64_t b1 = (b0 + K1_BLOCK < n_boxes) ? b0 + K1_BLOCK : n_boxes;
-    const int32_t ts = pt_off[b0];  // tile's point range (wave-uniform)
-    const int32_t te = pt_off[b1];
-    int32_t s = 0, e = 0;
-    if (active) {
-        s = pt_off[b];
-        e = pt_off[b + 1];
-    }
-    BoxAcc acc;
-    acc.empty();
-    for (int32_t cs = ts; cs < te; cs += K1_CHUNK) {
-        const int32_t ce = (te - cs > K1_CHUNK) ? cs + K1_CHUNK : te;
-        if (cs != ts) __syncthreads();  // previous chunk fully consumed
-        for (int32_t p = cs + tid; p < ce; p += K1_BLOCK) s_pts[p - cs] = xy[p];
-        __syncthreads();
-        int32_t lo = s > cs ? s : cs;
-        const int32_t hi = e < ce ? e : ce;
-        if (lo < hi) {
-            if (lo == s) {
-                const double2 v = s_pts[lo - cs];
-                acc.first(v.x, v.y);
-                ++lo;
-            }
-            for (int32_t p = lo; p < hi; ++p) {
-                const double2 v = s_pts[p - cs];
-                acc.next(v.x, v.y, p - s);
-            }
-        }
-    }
-    if (active) acc.store(out_box4, out_arg4, b);
+    k1_process_tile(xy, pt_off, (int64_t)blockIdx.x * K1_BLOCK, n_boxes, out_box4, out_arg4, s_pts);
 }
 
 // Direct variant (no LDS): lane t reads box t's points straight from global memory.  Kept for

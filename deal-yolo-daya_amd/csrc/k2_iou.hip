@@ -26,281 +26,51 @@
 // Arithmetic is f64 in the reference's operation order, built with -ffp-contract=off; the IEEE
 // division is only executed when a conservative bound (inter < 0.999*thr*union) cannot already
 // rule the pair out.
-#include "dyd_common.h"
+#include "k2_wave.h"
 
 namespace dyd {
 
-constexpr int K2_BLOCK = 256;
-constexpr int K2_WAVES = K2_BLOCK / kWave;
-constexpr int K2_WROWS = 16;   // image rows per wave
-constexpr int K2_WCAP = 256;   // boxes staged in LDS per sub-tile (4 f64 columns = 8 KiB per wave)
-
-struct Corners {
-    double x1, y1, x2, y2;
-};
-
-struct alignas(16) WaveLds {
-    double x1[K2_WCAP], y1[K2_WCAP], x2[K2_WCAP], y2[K2_WCAP];
-    unsigned long long mx[K2_WROWS];
-    int32_t off[K2_WROWS + 4];
-    int32_t flag[K2_WROWS];
-    int32_t nan[K2_WROWS];
-    int32_t sst[K2_WROWS];
-    unsigned short row[K2_WCAP];
-    unsigned short perm[K2_WCAP];
-};
-
-// LDS hand-off between lanes of ONE wave: the hardware executes a wave's LDS operations in
-// order, so only the compiler must be kept from moving accesses across this point.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// extract_boxes :359-362 — builtin two-argument min/max: first argument unless the second is
-// strictly better.
-__device__ __forceinline__ Corners normalise(double2 a, double2 b) {
-    Corners o;
-    o.x1 = (b.x < a.x) ? b.x : a.x;
-    o.y1 = (b.y < a.y) ? b.y : a.y;
-    o.x2 = (b.x > a.x) ? b.x : a.x;
-    o.y2 = (b.y > a.y) ? b.y : a.y;
-    return o;
-}
-// the area expression of :336-337
-__device__ __forceinline__ double area_of(const Corners &c) { return (c.x2 - c.x1) * (c.y2 - c.y1); }
-__device__ __forceinline__ bool has_nan(const Corners &c) {
-    return c.x1 != c.x1 || c.y1 != c.y1 || c.x2 != c.x2 || c.y2 != c.y2;
-}
-
-// Single-instruction IEEE maxNum / minNum.  __builtin_fmax would do, but hipcc (ROCm 7.2) puts a
-// canonicalising v_max_f64 x,x in front of every operand that comes from memory, doubling the
-// instruction count of the pair loop; the asm form issues exactly one VALU op.
-__device__ __forceinline__ double vmax(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double vmin(double a, double b) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double vmax0(double a) {
-    double r;
-    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
-    return r;
-}
-
-// calculate_iou :328-339 for p = lower-index box, q = higher-index box.  `me_ar` is the area of
-// the lane's own box (either p or q), `oth` the partner whose area is only needed once the
-// boxes intersect.  Returns true iff IoU >= thr; when WANT_MAX also folds the exact IoU into mx.
-//
-// NO_NAN: none of the eight corners is NaN.  Then CPython's first-wins max(a, b) / min(a, b)
-// and max(0, v) return the same VALUE as IEEE maxNum / minNum (they can differ only in the sign
-// of a zero, which cannot change w*h == 0, the sums or the quotient), so one v_max_f64 /
-// v_min_f64 replaces each compare + select pair; max(0, NaN) = 0 also holds for maxNum when
-// inf - inf produces a NaN width.  With a NaN corner the exact compare/select order is kept.
-template <bool WANT_MAX, bool NO_NAN>
-__device__ __forceinline__ bool pair_hits(const Corners &p, const Corners &q, double me_ar,
-                                          const Corners &oth, double thr, double thr_lo, bool zero_hits,
-                                          double &mx) {
-    double ix1, iy1, ix2, iy2, w, h;
-    if (NO_NAN) {
-        ix1 = vmax(p.x1, q.x1);
-        iy1 = vmax(p.y1, q.y1);
-        ix2 = vmin(p.x2, q.x2);
-        iy2 = vmin(p.y2, q.y2);
-        w = vmax0(ix2 - ix1);
-        h = vmax0(iy2 - iy1);
-    } else {
-        ix1 = (q.x1 > p.x1) ? q.x1 : p.x1;
-        iy1 = (q.y1 > p.y1) ? q.y1 : p.y1;
-        ix2 = (q.x2 < p.x2) ? q.x2 : p.x2;
-        iy2 = (q.y2 < p.y2) ? q.y2 : p.y2;
-        w = ix2 - ix1;
-        h = iy2 - iy1;
-        w = (w > 0.0) ? w : 0.0;
-        h = (h > 0.0) ? h : 0.0;
-    }
-    const double inter = w * h;
-    if (inter == 0.0) return zero_hits;  // :334-335 -> 0.0
-    const double uni = me_ar + area_of(oth) - inter;  // area1 + area2 - inter; IEEE + commutes
-    if (!WANT_MAX) {
-        // certainly below the threshold: skip the division.  thr_lo = thr * 0.999 (0 when thr <= 0,
-        // which disables the shortcut); the 1e-3 margin dwarfs every rounding involved.
-        if (inter < thr_lo * uni) return false;
-    }
-    const double iou = (uni != 0.0) ? inter / uni : 0.0;
-    if (WANT_MAX) {
-        if (iou > mx) mx = iou;
-    }
-    return iou >= thr;
-}
-
-template <bool WANT_MAX>
+template <bool WANT_MAX, int WROWS, int WCAP>
 __global__ __launch_bounds__(K2_BLOCK) void k2_iou_kernel(const double *__restrict__ box4,
                                                           const int32_t *__restrict__ row_off,
                                                           int64_t n_rows, int32_t min_boxes, double thr,
                                                           uint8_t *__restrict__ out_high,
                                                           double *__restrict__ out_max) {
-    __shared__ WaveLds s_all[K2_WAVES];
-    const int lane = threadIdx.x & 63;
-    WaveLds &S = s_all[threadIdx.x >> 6];
-    const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + (threadIdx.x >> 6)) * K2_WROWS;
+    __shared__ WaveLdsT<WROWS, WCAP> s_all[K2_WAVES];
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * WROWS;
     if (r0 >= n_rows) return;  // whole wave leaves; no workgroup barrier exists in this kernel
-    const int nr = (n_rows - r0 < K2_WROWS) ? (int)(n_rows - r0) : K2_WROWS;
-
-    // lane L (L <= nr) keeps row_off[r0 + L] in a register and in LDS
-    int32_t my_off = 0;
-    if (lane <= nr) {
-        my_off = row_off[r0 + lane];
-        S.off[lane] = my_off;
-    }
-    if (lane < K2_WROWS) {
-        S.flag[lane] = 0;
-        S.nan[lane] = 0;
-        S.mx[lane] = 0ull;
-    }
-    const int32_t my_n = __shfl_down(my_off, 1) - my_off;  // size of row L for L < nr
-    wave_sync();
-    const bool zero_hits = (0.0 >= thr);  // an empty intersection yields IoU 0.0 (:334-335)
-    const double thr_lo = (thr > 0.0) ? thr * 0.999 : 0.0;
-
-    int ra = 0;
-    while (ra < nr) {  // every condition below is wave-uniform
-        const int32_t base = __builtin_amdgcn_readlane(my_off, ra);
-        // rows ra .. rb-1 fit the LDS tile together: offsets are monotone, so the qualifying lanes
-        // are contiguous and their count is the number of rows taken
-        const unsigned long long fits = __ballot(lane > ra && lane <= nr && my_off - base <= K2_WCAP);
-        const int taken = __popcll(fits);
-        if (taken == 0) {
-            // ---- one row larger than the LDS tile: stream partner tiles through LDS ----------
-            const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            const bool counted = WANT_MAX || n >= min_boxes;
-            bool hit = false;
-            double mx = 0.0;
-            for (int32_t tj = 0; tj < n && counted; tj += K2_WCAP) {
-                const int32_t tn = (n - tj < K2_WCAP) ? n - tj : K2_WCAP;
-                wave_sync();
-                for (int32_t k = lane; k < tn; k += kWave) {
-                    const double2 *g = reinterpret_cast<const double2 *>(box4 + 4 * (int64_t)(base + tj + k));
-                    const Corners v = normalise(g[0], g[1]);
-                    S.x1[k] = v.x1; S.y1[k] = v.y1; S.x2[k] = v.x2; S.y2[k] = v.y2;
-                }
-                wave_sync();
-                for (int32_t i = lane; i < tj + tn - 1; i += kWave) {
-                    const double2 *g = reinterpret_cast<const double2 *>(box4 + 4 * (int64_t)(base + i));
-                    const Corners me = normalise(g[0], g[1]);
-                    const double me_ar = area_of(me);
-                    for (int32_t j = (i + 1 > tj) ? i + 1 : tj; j < tj + tn; ++j) {
-                        const int32_t k = j - tj;
-                        const Corners o = {S.x1[k], S.y1[k], S.x2[k], S.y2[k]};
-                        hit |= pair_hits<WANT_MAX, false>(me, o, me_ar, o, thr, thr_lo, zero_hits, mx);  // i < j
-                    }
-                }
-            }
-            if (hit && n >= min_boxes) S.flag[ra] = 1;
-            if (WANT_MAX) atomicMax(&S.mx[ra], (unsigned long long)__double_as_longlong(mx));
-            wave_sync();
-            ra += 1;
-            continue;
-        }
-        const int rb = ra + taken;
-        const int32_t nb = __builtin_amdgcn_readlane(my_off, rb) - base;
-
-        // ---- rank the sub-tile's rows by size (largest first, stable) in registers -------------
-        int rank = 0, sorted_start = 0;
-        for (int r2 = ra; r2 < rb; ++r2) {
-            const int32_t n2 = __builtin_amdgcn_readlane(my_n, r2);
-            rank += (n2 > my_n || (n2 == my_n && r2 < lane)) ? 1 : 0;
-        }
-        for (int r2 = ra; r2 < rb; ++r2) {
-            const int32_t n2 = __builtin_amdgcn_readlane(my_n, r2);
-            const int rank2 = __builtin_amdgcn_readlane(rank, r2);
-            sorted_start += (rank2 < rank) ? n2 : 0;
-        }
-        if (lane >= ra && lane < rb) S.sst[lane] = sorted_start;
-        wave_sync();
-
-        // ---- stage the sub-tile's boxes: normalised corners as SoA columns in LDS -------------
-        for (int32_t k = lane; k < nb; k += kWave) {
-            const double2 *g = reinterpret_cast<const double2 *>(box4 + 4 * (int64_t)(base + k));
-            const Corners v = normalise(g[0], g[1]);
-            S.x1[k] = v.x1; S.y1[k] = v.y1; S.x2[k] = v.x2; S.y2[k] = v.y2;
-            int lo = ra, hi = rb;  // the row r in [ra, rb) with off[r] - base <= k < off[r+1] - base
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (S.off[mid] - base <= k) lo = mid; else hi = mid;
-            }
-            S.row[k] = (unsigned short)lo;
-            S.perm[S.sst[lo] + (k - (S.off[lo] - base))] = (unsigned short)k;
-            if (has_nan(v)) S.nan[lo] = 1;
-        }
-        wave_sync();
-
-        // ---- pairs: boxes are taken in descending trip count, 64 per pass -----------------------
-        for (int32_t q = lane; q < nb; q += kWave) {
-            const int32_t k = S.perm[q];
-            const int lr = S.row[k];
-            const int32_t rs = S.off[lr] - base;
-            const int32_t n = S.off[lr + 1] - S.off[lr];
-            if (n < 2 || (!WANT_MAX && n < min_boxes)) continue;
-            const int32_t i = k - rs;
-            const Corners me = {S.x1[k], S.y1[k], S.x2[k], S.y2[k]};
-            const double me_ar = area_of(me);
-            const int32_t half = n >> 1;
-            const int32_t trips = ((n & 1) == 0 && i >= half) ? half - 1 : half;
-            bool hit = false;
-            double mx = 0.0;
-            if (S.nan[lr] == 0) {
-                int32_t j = (i + 1 >= n) ? i + 1 - n : i + 1;
-                Corners nxt = {S.x1[rs + j], S.y1[rs + j], S.x2[rs + j], S.y2[rs + j]};
-                for (int32_t d = 1; d <= trips; ++d) {
-                    const Corners o = nxt;
-                    j = (j + 1 >= n) ? 0 : j + 1;
-                    const int32_t kj = rs + j;
-                    nxt.x1 = S.x1[kj]; nxt.y1 = S.y1[kj]; nxt.x2 = S.x2[kj]; nxt.y2 = S.y2[kj];
-                    hit |= pair_hits<WANT_MAX, true>(me, o, me_ar, o, thr, thr_lo, zero_hits, mx);
-                }
-            } else {  // a NaN in the row: keep the reference's (i < j) argument order
-                for (int32_t d = 1; d <= trips; ++d) {
-                    int32_t j = i + d;
-                    if (j >= n) j -= n;
-                    const int32_t kj = rs + j;
-                    const Corners o = {S.x1[kj], S.y1[kj], S.x2[kj], S.y2[kj]};
-                    hit |= (j > i) ? pair_hits<WANT_MAX, false>(me, o, me_ar, o, thr, thr_lo, zero_hits, mx)
-                                   : pair_hits<WANT_MAX, false>(o, me, me_ar, o, thr, thr_lo, zero_hits, mx);
-                }
-            }
-            if (hit && n >= min_boxes) S.flag[lr] = 1;
-            if (WANT_MAX) atomicMax(&S.mx[lr], (unsigned long long)__double_as_longlong(mx));
-        }
-        wave_sync();
-        ra = rb;
-    }
-    if (lane < nr) {
-        out_high[r0 + lane] = (uint8_t)(S.flag[lane] != 0);
-        if (WANT_MAX) out_max[r0 + lane] = __longlong_as_double((long long)S.mx[lane]);
-    }
+    const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
+    k2_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave]);
 }
 
-int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st) {
-    if (n_rows == 0) return DYD_OK;
-    const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * K2_WROWS);
+template <int WROWS, int WCAP>
+static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
+                       uint8_t *out_high, double *out_max, hipStream_t st) {
+    const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
         return DYD_ERR_RANGE;
     }
     if (out_max)
-        hipLaunchKernelGGL(k2_iou_kernel<true>, dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4, row_off,
-                           n_rows, min_boxes, thr, out_high, out_max);
+        hipLaunchKernelGGL((k2_iou_kernel<true, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
+                           row_off, n_rows, min_boxes, thr, out_high, out_max);
     else
-        hipLaunchKernelGGL(k2_iou_kernel<false>, dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4, row_off,
-                           n_rows, min_boxes, thr, out_high, out_max);
+        hipLaunchKernelGGL((k2_iou_kernel<false, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
+                           row_off, n_rows, min_boxes, thr, out_high, out_max);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
+}
+
+// tile variant: 0 = 16 rows / 256 boxes per wave (16 waves per CU), 1 = 8 rows / 128 boxes (32 waves per CU)
+static int g_k2_variant = 0;
+void set_k2_variant(int v) { g_k2_variant = v; }
+
+int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
+              uint8_t *out_high, double *out_max, hipStream_t st) {
+    if (n_rows == 0) return DYD_OK;
+    if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
+    return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
 }
 
 }  // namespace dyd

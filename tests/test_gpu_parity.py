@@ -274,10 +274,12 @@ def test_sharded_functions_world1_rccl(native):
                                 device_id=torch.device("cuda:0"))
     try:
         ops = D.HipOps("cuda:0")
-        src = pd.Series(["a", "b", "a", None, "c", None, "b"], dtype=object)
+        src = pd.Series(["a", "b", "a", np.nan, "c", np.nan, "b"], dtype=object)
+        ref = pd.Series(["b", "nan", np.nan], dtype=object)
         assert D.dedup_keep_mask_sharded(src, "first", ops).tolist() == [True, True, False, True, True, False, False]
-        assert D.ref_hit_mask_sharded(src, pd.Series(["b", "nan", None], dtype=object), ops).tolist() == \
-            [False, True, False, True, False, True, True]
+        want = src.astype(str).isin(set(ref.dropna().astype(str))).tolist()     # NaN -> "nan" hits the literal
+        assert want == [False, True, False, True, False, True, True]
+        assert D.ref_hit_mask_sharded(src, ref, ops).tolist() == want
         split, pos = D.split_ids_sharded(np.array([0, 1, 0, -1, 0, 1], np.int32), 2, ops=ops)
         assert split[3] == 255 and sorted(pos[[0, 2, 4]].tolist()) == [0, 1, 2]
     finally:

@@ -16,7 +16,7 @@ os.makedirs(prof, exist_ok=True)
 
 stats = glob.glob(os.path.join(out, "prof_bench", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
-    df = pd.read_csv(stats[0])
+    df = pd.read_csv(max(stats, key=os.path.getmtime))
     df = df[df["Name"].str.contains("dyd::")]
     df.to_csv(os.path.join(prof, f"{tag}_bench_kernel_stats.csv"), index=False)
     print(df[["Name", "Calls", "AverageNs", "Percentage"]].to_string())
@@ -49,11 +49,17 @@ if os.path.exists(bl):
         with open(os.path.join(prof, f"{tag}_bench.json"), "w") as fh:
             fh.write(lines[-1])
 
-k1 = summary.get("dyd::k1_bbox_lds", {}).get("hbm_traffic_bytes_per_launch")
 bj = os.path.join(prof, f"{tag}_bench.json")
-if k1 and os.path.exists(bj):
-    cfg = json.load(open(bj))["config"]
-    with open(os.path.join(prof, "k1_traffic.json"), "w") as fh:
-        json.dump({"workload": "c2", "rows_per_gpu": cfg["rows_per_gpu"], "traffic_bytes_per_launch": k1["total_corrected"],
-                   "read_bytes_fetch_size_x2": k1["read_corrected_x2"], "write_bytes": k1["write"],
-                   "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}, fh, indent=1)
+if os.path.exists(bj):
+    bench = json.load(open(bj))
+    cfg = bench["config"]
+    fused = cfg.get("launch", "").startswith("fused")
+    key = next((k for k in summary if ("k12_fused_kernel" in k) == fused and ("k12_fused" in k or "k1_bbox_lds" in k)), None)
+    t = summary.get(key, {}).get("hbm_traffic_bytes_per_launch") if key else None
+    if t:
+        with open(os.path.join(prof, "k1_traffic.json"), "w") as fh:
+            json.dump({"workload": "c2", "fused": fused, "kernel": key, "rows_per_gpu": cfg["rows_per_gpu"],
+                       "traffic_bytes_per_launch": t["total_corrected"], "read_bytes_fetch_size_x2": t["read_corrected_x2"],
+                       "write_bytes": t["write"],
+                       "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"},
+                      fh, indent=1)
