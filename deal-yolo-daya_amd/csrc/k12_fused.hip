@@ -20,8 +20,7 @@
 // Algorithmic bytes per launch: 16*P + 4*(B+1) + 48*B + 4*(N+1) + N.
 #include <cstring>
 
-#include "k1_tile.h"
-#include "k2_wave.h"
+#include "k12_wave.h"
 
 namespace dyd {
 
@@ -57,6 +56,21 @@ __global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__re
     k2_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
 }
 
+// wave-autonomous variant: boxes go from K1 to K2 through LDS, no workgroup barrier (k12_wave.h)
+__global__ __launch_bounds__(K1_BLOCK) void k12_wave_kernel(const double2 *__restrict__ xy,
+                                                            const int32_t *__restrict__ pt_off,
+                                                            const int32_t *__restrict__ box_off, int64_t n_rows,
+                                                            int32_t min_boxes, double thr, double *out_box4,
+                                                            int32_t *__restrict__ out_arg4,
+                                                            uint8_t *__restrict__ out_high) {
+    __shared__ WaveFuse s_all[K2_WAVES];
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * KW_ROWS;
+    if (r0 >= n_rows) return;
+    const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
+    k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave]);
+}
+
 template <int CHUNK, int WROWS, int WCAP>
 static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
                         int32_t min_boxes, double thr, double *out_box4, int32_t *out_arg4, uint8_t *out_high,
@@ -81,7 +95,7 @@ void set_k1_variant(int v);
 void set_k2_variant(int v);
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
-// 2 = fused <1024,8,128>, 3 = fused <1024,16,256>
+// 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off)
 static int g_fused_variant = -1;
 
 }  // namespace dyd
@@ -107,7 +121,21 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st);
     }
     int v = g_fused_variant;
-    if (v < 0) v = (n_boxes <= 24 * n_rows) ? 2 : 0;  // sparse rows: the small tiles give twice the occupancy
+    // sparse rows (<= 24 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
+    // handed to K2 through LDS); dense rows: 256-box wave tiles
+    if (v < 0) v = (n_boxes <= 24 * n_rows) ? 4 : 0;
+    if (v == 4) {
+        const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * KW_ROWS);
+        if (blocks > 0x7fffffffLL) {
+            set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
+            return DYD_ERR_RANGE;
+        }
+        hipLaunchKernelGGL(k12_wave_kernel, dim3((unsigned)blocks), dim3(K1_BLOCK), 0, st,
+                           reinterpret_cast<const double2 *>(xy), pt_off, box_off, n_rows, min_boxes, thr, out_box4,
+                           out_arg4, out_high);
+        DYD_HIP(hipGetLastError());
+        return DYD_OK;
+    }
     if (v == 2)
         return launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
     if (v == 3)

@@ -1,0 +1,190 @@
+// k12_wave.h — wave-autonomous fused K1+K2: poly -> bbox -> IoU flag with the boxes handed from
+// K1 to K2 through LDS (no re-read from memory) and no workgroup barrier.
+//
+// Every 64-lane wave owns KW_ROWS consecutive image rows and a private 4.4 KiB LDS slice, so a
+// CU holds 32 independent waves.  A wave walks its rows in tiles of whole rows with at most 64
+// boxes, one box per lane:
+//   K1  the tile's contiguous point range is streamed HBM -> LDS in KW_CHUNK-point pieces
+//       (coalesced 16-B lanes); each lane walks its own box's points in order (first-wins
+//       min/max, reference core/processor.py:252-260) and stores box4/arg4 to global memory;
+//   K2  the same lanes write their corner-normalised box over the (now dead) point buffer and
+//       run the all-pairs loop of k2_wave.h on it: lane i visits partners i+d (mod n), d = 1..n/2
+//       (reference :328-339, :359-362, :368-376).
+// A row with more than 64 boxes takes a slower general path: K1 in 64-box passes to global
+// memory, then K2 streaming 64-box partner tiles through LDS.
+#pragma once
+
+#include "k1_tile.h"
+#include "k2_wave.h"
+
+namespace dyd {
+
+constexpr int KW_ROWS = 16;    // image rows per wave
+constexpr int KW_CHUNK = 256;  // points per LDS piece (4 KiB)
+
+struct alignas(16) WaveFuse {
+    union {
+        double2 pts[KW_CHUNK];
+        struct {
+            double x1[kWave], y1[kWave], x2[kWave], y2[kWave];
+        } c;
+    };
+    int32_t off[KW_ROWS + 4];
+    int32_t flag[KW_ROWS];
+    int32_t nan[KW_ROWS];
+};
+
+// K1 for up to 64 consecutive boxes [b0, b0 + cnt): lane l < cnt owns box b0 + l.  Returns the
+// lane's accumulator (already stored to out_box4 / out_arg4).
+__device__ __forceinline__ BoxAcc k12_wave_boxes(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
+                                                 int64_t b0, int cnt, double *out_box4,
+                                                 int32_t *__restrict__ out_arg4, WaveFuse &S) {
+    const int lane = threadIdx.x & 63;
+    int32_t s = 0, e = 0;
+    if (lane < cnt) {
+        s = pt_off[b0 + lane];
+        e = pt_off[b0 + lane + 1];
+    }
+    const int32_t ts = __builtin_amdgcn_readlane(s, 0);
+    const int32_t te = __builtin_amdgcn_readlane(e, cnt - 1);
+    BoxAcc acc;
+    acc.empty();
+    for (int32_t cs = ts; cs < te; cs += KW_CHUNK) {
+        const int32_t ce = (te - cs > KW_CHUNK) ? cs + KW_CHUNK : te;
+        wave_sync();  // the buffer's previous content is fully consumed
+        for (int32_t p = cs + lane; p < ce; p += kWave) S.pts[p - cs] = xy[p];
+        wave_sync();
+        int32_t lo = s > cs ? s : cs;
+        const int32_t hi = e < ce ? e : ce;
+        if (lo < hi) {
+            if (lo == s) {
+                const double2 v = S.pts[lo - cs];
+                acc.first(v.x, v.y);
+                ++lo;
+            }
+            for (int32_t p = lo; p < hi; ++p) {
+                const double2 v = S.pts[p - cs];
+                acc.next(v.x, v.y, p - s);
+            }
+        }
+    }
+    if (lane < cnt) acc.store(out_box4, out_arg4, b0 + lane);
+    return acc;
+}
+
+__device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
+                                              const int32_t *__restrict__ box_off, int64_t r0, int nr,
+                                              int32_t min_boxes, double thr, double *out_box4,
+                                              int32_t *__restrict__ out_arg4, uint8_t *__restrict__ out_high,
+                                              WaveFuse &S) {
+    const int lane = threadIdx.x & 63;
+    int32_t my_off = 0;
+    if (lane <= nr) {
+        my_off = box_off[r0 + lane];
+        S.off[lane] = my_off;
+    }
+    if (lane < KW_ROWS) {
+        S.flag[lane] = 0;
+        S.nan[lane] = 0;
+    }
+    wave_sync();
+    const bool zero_hits = (0.0 >= thr);
+    const double thr_lo = (thr > 0.0) ? thr * 0.999 : 0.0;
+    double unused_mx = 0.0;
+
+    int ra = 0;
+    while (ra < nr) {  // every condition below is wave-uniform
+        const int32_t base = __builtin_amdgcn_readlane(my_off, ra);
+        const unsigned long long fits = __ballot(lane > ra && lane <= nr && my_off - base <= kWave);
+        const int taken = __popcll(fits);
+        if (taken == 0) {
+            // ---- a row with more than 64 boxes: K1 in passes, then K2 over partner tiles ---------
+            const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
+            for (int32_t g = 0; g < n; g += kWave)
+                k12_wave_boxes(xy, pt_off, (int64_t)base + g, (n - g < kWave) ? n - g : kWave, out_box4, out_arg4, S);
+            // this wave re-reads its own stores below: wait for them and drop any stale L1 lines
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            bool hit = false;
+            if (n >= min_boxes) {
+                for (int32_t tj = 0; tj < n; tj += kWave) {
+                    const int32_t tn = (n - tj < kWave) ? n - tj : kWave;
+                    wave_sync();
+                    if (lane < tn) {
+                        const double2 *g2 = reinterpret_cast<const double2 *>(out_box4 + 4 * (int64_t)(base + tj + lane));
+                        const Corners v = normalise(g2[0], g2[1]);
+                        S.c.x1[lane] = v.x1; S.c.y1[lane] = v.y1; S.c.x2[lane] = v.x2; S.c.y2[lane] = v.y2;
+                    }
+                    wave_sync();
+                    for (int32_t i = lane; i < tj + tn - 1; i += kWave) {
+                        const double2 *g2 = reinterpret_cast<const double2 *>(out_box4 + 4 * (int64_t)(base + i));
+                        const Corners me = normalise(g2[0], g2[1]);
+                        const double me_ar = area_of(me);
+                        for (int32_t j = (i + 1 > tj) ? i + 1 : tj; j < tj + tn; ++j) {
+                            const int32_t k = j - tj;
+                            const Corners o = {S.c.x1[k], S.c.y1[k], S.c.x2[k], S.c.y2[k]};
+                            hit |= pair_hits<false, false>(me, o, me_ar, o, thr, thr_lo, zero_hits, unused_mx);
+                        }
+                    }
+                }
+            }
+            if (hit) S.flag[ra] = 1;
+            wave_sync();
+            ra += 1;
+            continue;
+        }
+        const int rb = ra + taken;
+        const int32_t nb = __builtin_amdgcn_readlane(my_off, rb) - base;  // 0 .. 64 boxes in the tile
+        if (nb > 0) {
+            // ---- K1: one box per lane ---------------------------------------------------------
+            const BoxAcc acc = k12_wave_boxes(xy, pt_off, (int64_t)base, nb, out_box4, out_arg4, S);
+            // ---- hand-off: the lanes overwrite the dead point buffer with their normalised box ------
+            int lr = ra;  // the tile row that holds box `lane`
+            for (int r2 = ra + 1; r2 < rb; ++r2) lr += (__builtin_amdgcn_readlane(my_off, r2) - base <= lane) ? 1 : 0;
+            const Corners me = normalise(make_double2(acc.mnx, acc.mny), make_double2(acc.mxx, acc.mxy));
+            wave_sync();
+            if (lane < nb) {
+                S.c.x1[lane] = me.x1; S.c.y1[lane] = me.y1; S.c.x2[lane] = me.x2; S.c.y2[lane] = me.y2;
+                if (has_nan(me)) S.nan[lr] = 1;
+            }
+            wave_sync();
+            // ---- K2: lane owns box i of its row, partners j = i+d (mod n), d = 1..n/2 ---------------
+            if (lane < nb) {
+                const int32_t rs = S.off[lr] - base;
+                const int32_t n = S.off[lr + 1] - S.off[lr];
+                if (n >= 2 && n >= min_boxes) {
+                    const int32_t i = lane - rs;
+                    const double me_ar = area_of(me);
+                    const int32_t half = n >> 1;
+                    const int32_t trips = ((n & 1) == 0 && i >= half) ? half - 1 : half;
+                    bool hit = false;
+                    if (S.nan[lr] == 0) {
+                        int32_t j = (i + 1 >= n) ? i + 1 - n : i + 1;
+                        Corners nxt = {S.c.x1[rs + j], S.c.y1[rs + j], S.c.x2[rs + j], S.c.y2[rs + j]};
+                        for (int32_t d = 1; d <= trips; ++d) {
+                            const Corners o = nxt;
+                            j = (j + 1 >= n) ? 0 : j + 1;
+                            const int32_t kj = rs + j;
+                            nxt.x1 = S.c.x1[kj]; nxt.y1 = S.c.y1[kj]; nxt.x2 = S.c.x2[kj]; nxt.y2 = S.c.y2[kj];
+                            hit |= pair_hits<false, true>(me, o, me_ar, o, thr, thr_lo, zero_hits, unused_mx);
+                        }
+                    } else {  // a NaN in the row: keep the reference's (i < j) argument order
+                        for (int32_t d = 1; d <= trips; ++d) {
+                            int32_t j = i + d;
+                            if (j >= n) j -= n;
+                            const int32_t kj = rs + j;
+                            const Corners o = {S.c.x1[kj], S.c.y1[kj], S.c.x2[kj], S.c.y2[kj]};
+                            hit |= (j > i) ? pair_hits<false, false>(me, o, me_ar, o, thr, thr_lo, zero_hits, unused_mx)
+                                           : pair_hits<false, false>(o, me, me_ar, o, thr, thr_lo, zero_hits, unused_mx);
+                        }
+                    }
+                    if (hit) S.flag[lr] = 1;
+                }
+            }
+            wave_sync();
+        }
+        ra = rb;
+    }
+    if (lane < nr) out_high[r0 + lane] = (uint8_t)(S.flag[lane] != 0);
+}
+
+}  // namespace dyd

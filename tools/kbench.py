@@ -112,7 +112,7 @@ def main():
         k12_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N
         res = {}
         for rnd in range(2):
-            for variant in (0, 1, 2, 3):
+            for variant in (0, 1, 2, 3, 4):
                 ck(L.dyd_set_option(b"fused_variant", variant), "opt")
                 med, mn = timeit(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(),
                                                                       N, B, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
@@ -120,7 +120,7 @@ def main():
                 res.setdefault(variant, []).append((med, mn))
         ck(L.dyd_set_option(b"fused_variant", -1), "opt")
         for variant, name in ((0, "k12_fused<2048,16,256>"), (2, "k12_fused<1024,8,128>"), (3, "k12_fused<1024,16,256>"),
-                              (1, "k1_then_k2_two_launches")):
+                              (4, "k12_wave_kernel"), (1, "k1_then_k2_two_launches")):
             med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
             report(name, k12_bytes, med, mn, rows_per_s=round(N / med * 1e3), high=int(out_high.sum().item()))
 
