@@ -75,6 +75,19 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_split_ids_sharded_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_json_scan_polygons": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "dyd_json_emit_polygons": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dyd_json_scan_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "dyd_scan_n_boxes": (C.c_int64, [C.c_void_p]),
+    "dyd_scan_n_points": (C.c_int64, [C.c_void_p]),
+    "dyd_scan_xy": (C.c_void_p, [C.c_void_p]),
+    "dyd_scan_pt_off": (C.c_void_p, [C.c_void_p]),
+    "dyd_scan_cell_box_off": (C.c_void_p, [C.c_void_p]),
+    "dyd_scan_status": (C.c_void_p, [C.c_void_p]),
+    "dyd_scan_wh_kind": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dyd_scan_wh_value": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dyd_scan_free": (None, [C.c_void_p]),
     "dyd_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "dyd_membench_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
 }

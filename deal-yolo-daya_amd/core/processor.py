@@ -28,6 +28,7 @@ import numpy as np
 import pandas as pd
 
 from .. import flatten as _fl
+from .. import native_json as _nj
 from ..backend import resolve as _backend
 from .utils import _parse_data_objects, _split_label_cell, _split_object_labels, safe_filename
 
@@ -163,12 +164,10 @@ def remove_duplicates_between_csv(
 
 
 # =============================================================================== a3  polygon -> bbox
-def replace_ptlist_cells(cells, backend=None, stats: Optional[dict] = None) -> tuple:
-    """(new JSON text or None, width, height) per annotation cell: flatten -> K1 -> emit."""
-    be = _backend(backend)
-    cells = list(cells)
+def _replace_cells_python(cells, be, totals) -> tuple:
+    """flatten.py path (CPython json, reference accessor order): used for the cells the native scanner
+    calls irregular, and for everything when DYD_NATIVE_JSON=0."""
     texts, widths, heights = [], [], []
-    totals = {"cells": 0, "boxes": 0, "points": 0, "host_boxes": 0}
     for start in range(0, len(cells), _CHUNK_CELLS):
         batch = _fl.flatten_polygons(cells[start:start + _CHUNK_CELLS])
         if len(batch.pt_off) > 1:
@@ -179,11 +178,53 @@ def replace_ptlist_cells(cells, backend=None, stats: Optional[dict] = None) -> t
         for doc in batch.docs:                         # :285-292 (doc is a dict here, or the step raised)
             widths.append(doc.get("width") if doc is not None else None)
             heights.append(doc.get("height") if doc is not None else None)
-        for k in totals:
+        for k in ("boxes", "points", "host_boxes"):
             totals[k] += batch.stats[k]
+    return texts, widths, heights
+
+
+def replace_ptlist_cells(cells, backend=None, stats: Optional[dict] = None) -> tuple:
+    """(new JSON text or None, width, height) per annotation cell: flatten -> K1 -> emit.
+
+    Flatten / emit run in the native scanner (csrc/host_json.cpp) for regular cells; the cells it
+    classifies as irregular go through flatten.py in row order, so the first exception the reference
+    would raise is the one raised here."""
+    be = _backend(backend)
+    cells = list(cells)
+    totals = {"cells": len(cells), "boxes": 0, "points": 0, "host_boxes": 0, "python_cells": 0}
+    scan = None
+    if _nj.enabled() and cells:
+        try:
+            scan = _nj.scan_polygons(cells)
+        except UnicodeEncodeError:                     # a lone surrogate somewhere: CPython path for the batch
+            scan = None
+    if scan is None:
+        totals["python_cells"] = len(cells)
+        out = _replace_cells_python(cells, be, totals)
+    else:
+        irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+        totals["python_cells"] = int(len(irregular))
+        # irregular cells first: they are the only ones that can raise, and they must raise before any output
+        py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
+        if scan.n_boxes:
+            _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
+        else:
+            arg4 = np.zeros((0, 4), np.int32)
+        texts = scan.emit(arg4)
+        widths, heights = scan.width_height(0), scan.width_height(1)
+        for col in (widths, heights):                  # rare value kinds (str / container / huge int): ask CPython
+            for i, v in enumerate(col):
+                if v is Ellipsis:
+                    col[i] = json.loads(cells[i]).get("width" if col is widths else "height")
+        for j, i in enumerate(irregular.tolist()):
+            texts[i], widths[i], heights[i] = py[0][j], py[1][j], py[2][j]
+        totals["boxes"] += scan.n_boxes
+        totals["points"] += int(scan.xy.shape[0])
+        out = (texts, widths, heights)
+        scan.close()
     if stats is not None:
         stats.update(totals)
-    return texts, widths, heights
+    return out
 
 
 def replace_ptlist_frame(df: pd.DataFrame, backend=None, stats: Optional[dict] = None):
@@ -231,13 +272,9 @@ def process_csv_replace_ptlist(
 
 
 # =============================================================================== a4  IoU filter
-def iou_high_mask(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
-                  stats: Optional[dict] = None) -> np.ndarray:
-    """HIGH flag per bbox-JSON cell (:392-398): flatten -> K2."""
-    be = _backend(backend)
-    cells = list(cells)
+def _iou_mask_python(cells, min_boxes, iou_threshold, be, totals) -> np.ndarray:
+    """flatten.py path for the IoU step (see _replace_cells_python)."""
     out = np.zeros(len(cells), bool)
-    totals = {"rows": 0, "boxes": 0, "host_rows": 0}
     for start in range(0, len(cells), _CHUNK_CELLS):
         batch = _fl.flatten_boxes(cells[start:start + _CHUNK_CELLS])
         n = len(batch.row_off) - 1
@@ -245,8 +282,36 @@ def iou_high_mask(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backen
             out[start:start + n] = be.iou_any_ge(batch.box4, batch.row_off, min_boxes, iou_threshold).astype(bool)
         for ri, boxes in batch.host_rows.items():
             out[start + ri] = _fl.host_row_is_high(boxes, min_boxes, iou_threshold)
-        for k in totals:
-            totals[k] += batch.stats[k]
+        totals["boxes"] += batch.stats["boxes"]
+        totals["host_rows"] += batch.stats["host_rows"]
+    return out
+
+
+def iou_high_mask(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
+                  stats: Optional[dict] = None) -> np.ndarray:
+    """HIGH flag per bbox-JSON cell (:392-398): flatten -> K2 (native scanner for regular cells,
+    flatten.py for the irregular ones)."""
+    be = _backend(backend)
+    cells = list(cells)
+    totals = {"rows": len(cells), "boxes": 0, "host_rows": 0, "python_cells": 0}
+    scan = None
+    if _nj.enabled() and cells:
+        try:
+            scan = _nj.scan_boxes(cells)
+        except UnicodeEncodeError:
+            scan = None
+    if scan is None:
+        totals["python_cells"] = len(cells)
+        out = _iou_mask_python(cells, min_boxes, iou_threshold, be, totals)
+    else:
+        irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+        totals["python_cells"] = int(len(irregular))
+        py = (_iou_mask_python([cells[i] for i in irregular.tolist()], min_boxes, iou_threshold, be, totals)
+              if len(irregular) else np.zeros(0, bool))
+        out = be.iou_any_ge(scan.box4, scan.row_off, min_boxes, iou_threshold).astype(bool)
+        out[irregular] = py
+        totals["boxes"] += int(scan.row_off[-1])
+        scan.close()
     if stats is not None:
         stats.update(totals)
     return out

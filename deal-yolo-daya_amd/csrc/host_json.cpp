@@ -1,0 +1,1111 @@
+// host_json.cpp — native flatten / emit for the annotation cells (host code, no HIP).
+//
+// the reference spends ~45 % of its replace step and ~35 % of its IoU step inside
+// CPython's json.loads / json.dumps (core/processor.py:266, :279, :289, :346).  This file is a
+// schema-specialised JSON scanner + canonical re-emitter that produces, for REGULAR cells,
+//   * the SoA buffers K1 / K2 consume (points + offsets, two-point boxes + row offsets), and
+//   * byte-for-byte the text json.dumps(doc, ensure_ascii=False) would produce after the reference's
+//     rewrite of every ptList (core/processor.py:262-279),
+// and classifies every other cell as IRREGULAR so that the Python flatten/emit of flatten.py
+// (which follows the reference accessor by accessor, including the exceptions it raises) handles
+// it.  A cell is regular when: it decodes under Python's json grammar; the top level is an object;
+// "objects" is absent or an array; every dict element's "polygon" is absent or an object whose
+// "ptList" is absent or an array; every point that has both "x" and "y" carries plain numbers
+// (ints of magnitude <= 2^53, floats, NaN/Infinity literals); no object on the rewritten path has
+// a duplicate key; strings hold no lone surrogate.  Cells that fail to decode are regular too: the
+// reference maps them to None (:280-281).
+//
+// Threads: cells are independent; both entry points split the cell range over std::threads.
+#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cstdio>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dyd.h"
+
+namespace {
+
+enum CellStatus : uint8_t { CELL_OK = 0, CELL_UNDECODABLE = 1, CELL_IRREGULAR = 2, CELL_MISSING = 3 };
+
+struct Span {
+    const char *b, *e;
+};
+
+struct Fail {  // thrown as plain ints to keep the parser small: 1 = JSON decode error, 2 = irregular
+    int code;
+};
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+
+// ---------------------------------------------------------------------------------------------------
+// number / string canonicalisation (what json.dumps prints for the value json.loads produced)
+// ---------------------------------------------------------------------------------------------------
+// float.__repr__: shortest digits that round-trip; fixed notation for -4 < decpt <= 16, else d.ddde±XX
+void append_py_float(std::string &out, double v) {
+    if (std::isnan(v)) { out += "NaN"; return; }
+    if (std::isinf(v)) { out += (v < 0 ? "-Infinity" : "Infinity"); return; }
+    if (v == 0.0) { out += (std::signbit(v) ? "-0.0" : "0.0"); return; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf) - 1, v, std::chars_format::scientific);  // d[.ddd]e±XX, shortest
+    *r.ptr = 0;
+    const char *p = buf, *end = r.ptr;
+    if (*p == '-') { out += '-'; ++p; }
+    const char *epos = static_cast<const char *>(memchr(p, 'e', end - p));
+    std::string digits;
+    digits += p[0];
+    if (p + 1 < epos && p[1] == '.') digits.append(p + 2, epos);
+    const int exp10 = atoi(epos + 1);
+    const int nd = (int)digits.size();
+    const int decpt = exp10 + 1;  // value = 0.DIGITS * 10^decpt
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            out += "0.";
+            out.append((size_t)(-decpt), '0');
+            out += digits;
+        } else if (decpt >= nd) {
+            out += digits;
+            out.append((size_t)(decpt - nd), '0');
+            out += ".0";
+        } else {
+            out.append(digits, 0, (size_t)decpt);
+            out += '.';
+            out.append(digits, (size_t)decpt, std::string::npos);
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) {
+            out += '.';
+            out.append(digits, 1, std::string::npos);
+        }
+        char eb[16];
+        const int e = decpt - 1;
+        snprintf(eb, sizeof(eb), "e%c%02d", e < 0 ? '-' : '+', e < 0 ? -e : e);
+        out += eb;
+    }
+}
+
+struct Num {
+    bool is_int;
+    double v;       // value as double (exact for ints within 2^53)
+    bool exact;     // ints only: |value| <= 2^53
+};
+
+// token = a JSON number as matched by Python's NUMBER_RE, or NaN / Infinity / -Infinity
+Num classify_number(Span t) {
+    Num n{};
+    const size_t len = (size_t)(t.e - t.b);
+    if ((len == 3 && !memcmp(t.b, "NaN", 3))) { n.is_int = false; n.v = NAN; return n; }
+    if ((len == 8 && !memcmp(t.b, "Infinity", 8))) { n.is_int = false; n.v = INFINITY; return n; }
+    if ((len == 9 && !memcmp(t.b, "-Infinity", 9))) { n.is_int = false; n.v = -INFINITY; return n; }
+    bool is_int = true;
+    for (const char *p = t.b; p < t.e; ++p)
+        if (*p == '.' || *p == 'e' || *p == 'E') { is_int = false; break; }
+    n.is_int = is_int;
+    // fast path: <= 15 significant digits and |10^k| <= 10^22 -> mantissa and power are exact doubles, so
+    // one IEEE multiply / divide is correctly rounded (Clinger); everything else goes to strtod
+    {
+        const char *q = t.b;
+        const bool neg = (*q == '-');
+        if (neg) ++q;
+        uint64_t mant = 0;
+        int nd = 0, frac = 0;
+        bool seen_dot = false, simple = true;
+        for (; q < t.e; ++q) {
+            const char c = *q;
+            if (c >= '0' && c <= '9') {
+                if (nd < 19) { mant = mant * 10 + (uint64_t)(c - '0'); }
+                if (mant != 0 || nd > 0) ++nd;
+                if (seen_dot) ++frac;
+            } else if (c == '.') {
+                seen_dot = true;
+            } else {
+                simple = false;  // exponent: rare, take strtod
+                break;
+            }
+        }
+        static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                     1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+        if (simple && nd <= 15 && frac <= 22) {
+            double v = (double)mant;
+            if (frac) v /= p10[frac];
+            n.v = neg ? -v : v;
+            if (is_int) n.exact = true;
+            return n;
+        }
+    }
+    char tmp[48];
+    const size_t tl = (size_t)(t.e - t.b);
+    if (tl < sizeof(tmp)) {
+        memcpy(tmp, t.b, tl);
+        tmp[tl] = 0;
+        n.v = strtod(tmp, nullptr);  // glibc: correctly rounded, like float()
+    } else {
+        std::string big(t.b, t.e);
+        n.v = strtod(big.c_str(), nullptr);
+    }
+    if (is_int) {
+        const char *d = t.b + (*t.b == '-');
+        const size_t nd = (size_t)(t.e - d);
+        if (nd <= 15) n.exact = true;
+        else if (nd > 16) n.exact = false;
+        else n.exact = std::fabs(n.v) <= 9007199254740992.0 && (nd < 16 || memcmp(d, "9007199254740992", 16) <= 0);
+    }
+    return n;
+}
+
+void append_number(std::string &out, Span t) {
+    const Num n = classify_number(t);
+    if (n.is_int) {
+        if (t.e - t.b == 2 && t.b[0] == '-' && t.b[1] == '0') out += '0';  // int("-0") == 0
+        else out.append(t.b, t.e);
+    } else {
+        append_py_float(out, n.v);
+    }
+}
+
+void append_utf8(std::string &out, uint32_t cp) {
+    if (cp < 0x80) out += (char)cp;
+    else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+    else if (cp < 0x10000) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+    else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+}
+
+// json.dumps(..., ensure_ascii=False) escaping of one decoded code point
+void append_escaped_cp(std::string &out, uint32_t cp) {
+    switch (cp) {
+        case '"': out += "\\\""; return;
+        case '\\': out += "\\\\"; return;
+        case '\n': out += "\\n"; return;
+        case '\r': out += "\\r"; return;
+        case '\t': out += "\\t"; return;
+        case '\b': out += "\\b"; return;
+        case '\f': out += "\\f"; return;
+        default: break;
+    }
+    if (cp < 0x20) {
+        char b[8];
+        snprintf(b, sizeof(b), "\\u%04x", cp);
+        out += b;
+    } else {
+        append_utf8(out, cp);
+    }
+}
+
+int hex4(const char *p) {
+    int v = 0;
+    for (int i = 0; i < 4; ++i) {
+        const char c = p[i];
+        int d;
+        if (c >= '0' && c <= '9') d = c - '0';
+        else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+        else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+        else return -1;
+        v = v * 16 + d;
+    }
+    return v;
+}
+
+// Duplicate-key detection.  json.loads keeps the LAST value of a repeated key at the position of the
+// FIRST, which a streaming re-emitter cannot reproduce, so any object with a repeated key makes the cell
+// irregular (an escaped key spelling could alias another key, so it is treated the same way).
+struct KeySet {
+    Span small[12];
+    int n = 0;
+    std::vector<Span> more;
+    static bool has_escape(Span s) { return memchr(s.b, '\\', (size_t)(s.e - s.b)) != nullptr; }
+    bool add_is_dup(Span k) {  // true -> irregular
+        if (has_escape(k)) return true;
+        const size_t len = (size_t)(k.e - k.b);
+        for (int i = 0; i < n && i < 12; ++i)
+            if ((size_t)(small[i].e - small[i].b) == len && !memcmp(small[i].b, k.b, len)) return true;
+        for (const Span &o : more)
+            if ((size_t)(o.e - o.b) == len && !memcmp(o.b, k.b, len)) return true;
+        if (n < 12) small[n] = k; else more.push_back(k);
+        ++n;
+        return false;
+    }
+    template <class P>
+    void add(P &ps, Span k) { if (add_is_dup(k)) ps.irregular(); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// the parser: Python's json grammar (strict=True), streaming, no DOM
+// ---------------------------------------------------------------------------------------------------
+struct Parser {
+    const char *p, *end;
+    int depth = 0;
+
+    void ws() { while (p < end && is_ws(*p)) ++p; }
+    [[noreturn]] void bad() { throw Fail{1}; }
+    [[noreturn]] void irregular() { throw Fail{2}; }
+
+    // scans a string token at p ('"' ... '"'); returns the raw span between the quotes
+    Span string_token() {
+        if (p >= end || *p != '"') bad();
+        const char *b = ++p;
+        while (true) {
+            if (p >= end) bad();
+            const unsigned char c = (unsigned char)*p;
+            if (c == '"') break;
+            if (c < 0x20) bad();  // strict: raw control characters are invalid
+            if (c == '\\') {
+                if (p + 1 >= end) bad();
+                const char esc = p[1];
+                if (esc == 'u') {
+                    if (p + 6 > end) bad();
+                    const int cp = hex4(p + 2);
+                    if (cp < 0) bad();
+                    p += 6;
+                    if (cp >= 0xD800 && cp <= 0xDBFF) {
+                        // a high surrogate must be completed by \uDC00-\uDFFF; a lone one survives json.dumps
+                        // but makes to_csv raise UnicodeEncodeError -> leave such cells to the Python path
+                        const int lo = (p + 6 <= end && p[0] == '\\' && p[1] == 'u') ? hex4(p + 2) : -1;
+                        if (lo >= 0xDC00 && lo <= 0xDFFF) p += 6;
+                        else irregular();
+                    } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                        irregular();
+                    }
+                } else if (strchr("\"\\/bfnrt", esc) && esc != 0) {
+                    p += 2;
+                } else {
+                    bad();
+                }
+            } else {
+                ++p;
+            }
+        }
+        Span s{b, p};
+        ++p;
+        return s;
+    }
+
+    // decoded + re-escaped form of a raw string span (between the quotes), with quotes
+    void emit_string(std::string &out, Span s) {
+        out += '"';
+        const char *q = s.b;
+        while (q < s.e) {
+            const unsigned char c = (unsigned char)*q;
+            if (c == '\\') {
+                const char esc = q[1];
+                if (esc == 'u') {
+                    uint32_t cp = (uint32_t)hex4(q + 2);
+                    q += 6;
+                    if (cp >= 0xD800 && cp <= 0xDBFF) {
+                        if (q + 6 <= s.e && q[0] == '\\' && q[1] == 'u') {
+                            const int lo = hex4(q + 2);
+                            if (lo >= 0xDC00 && lo <= 0xDFFF) {
+                                cp = 0x10000 + ((cp - 0xD800) << 10) + ((uint32_t)lo - 0xDC00);
+                                q += 6;
+                            } else {
+                                irregular();  // lone surrogate: to_csv would raise UnicodeEncodeError
+                            }
+                        } else {
+                            irregular();
+                        }
+                    } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                        irregular();
+                    }
+                    append_escaped_cp(out, cp);
+                } else {
+                    uint32_t cp;
+                    switch (esc) {
+                        case 'b': cp = '\b'; break;
+                        case 'f': cp = '\f'; break;
+                        case 'n': cp = '\n'; break;
+                        case 'r': cp = '\r'; break;
+                        case 't': cp = '\t'; break;
+                        default: cp = (unsigned char)esc; break;  // " \ /
+                    }
+                    q += 2;
+                    append_escaped_cp(out, cp);
+                }
+            } else if (c == 0x7f || c >= 0x20) {
+                // raw byte of a UTF-8 sequence (or ASCII): " and \ cannot occur raw here
+                out += (char)c;
+                ++q;
+            } else {
+                bad();
+            }
+        }
+        out += '"';
+    }
+
+    // raw-span equality with an ASCII literal (a key written with escapes compares unequal -> such
+    // a cell is sent to the Python path by the callers' `has_escape` check)
+    static bool span_is(Span s, const char *lit) {
+        const size_t n = strlen(lit);
+        return (size_t)(s.e - s.b) == n && !memcmp(s.b, lit, n);
+    }
+    static bool has_escape(Span s) { return memchr(s.b, '\\', (size_t)(s.e - s.b)) != nullptr; }
+
+    Span number_token() {
+        const char *b = p;
+        if (p < end && *p == '-') ++p;
+        if (p < end && *p == 'I') {  // -Infinity / Infinity
+            if (end - p >= 8 && !memcmp(p, "Infinity", 8)) { p += 8; return Span{b, p}; }
+            bad();
+        }
+        if (p >= end) bad();
+        if (*p == '0') ++p;
+        else if (*p >= '1' && *p <= '9') { while (p < end && *p >= '0' && *p <= '9') ++p; }
+        else bad();
+        if (p + 1 < end && *p == '.' && p[1] >= '0' && p[1] <= '9') {
+            ++p;
+            while (p < end && *p >= '0' && *p <= '9') ++p;
+        }
+        if (p < end && (*p == 'e' || *p == 'E')) {
+            const char *q = p + 1;
+            if (q < end && (*q == '+' || *q == '-')) ++q;
+            if (q < end && *q >= '0' && *q <= '9') {
+                while (q < end && *q >= '0' && *q <= '9') ++q;
+                p = q;
+            }
+        }
+        return Span{b, p};
+    }
+
+    // skips one value, optionally emitting its canonical form
+    void value(std::string *out) {
+        ws();
+        if (p >= end) bad();
+        const char c = *p;
+        if (c == '{') {
+            if (++depth > 256) irregular();
+            ++p;
+            if (out) *out += '{';
+            ws();
+            if (p < end && *p == '}') { ++p; if (out) *out += '}'; --depth; return; }
+            bool first = true;
+            KeySet ks;
+            while (true) {
+                ws();
+                Span k = string_token();
+                if (ks.add_is_dup(k)) irregular();
+                if (out) { if (!first) *out += ", "; emit_string(*out, k); *out += ": "; }
+                first = false;
+                ws();
+                if (p >= end || *p != ':') bad();
+                ++p;
+                value(out);
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; break; }
+                bad();
+            }
+            if (out) *out += '}';
+            --depth;
+        } else if (c == '[') {
+            if (++depth > 256) irregular();
+            ++p;
+            if (out) *out += '[';
+            ws();
+            if (p < end && *p == ']') { ++p; if (out) *out += ']'; --depth; return; }
+            bool first = true;
+            while (true) {
+                if (out && !first) *out += ", ";
+                first = false;
+                value(out);
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; break; }
+                bad();
+            }
+            if (out) *out += ']';
+            --depth;
+        } else if (c == '"') {
+            Span s = string_token();
+            if (out) emit_string(*out, s);
+        } else if (c == 't') {
+            if (end - p >= 4 && !memcmp(p, "true", 4)) { p += 4; if (out) *out += "true"; } else bad();
+        } else if (c == 'f') {
+            if (end - p >= 5 && !memcmp(p, "false", 5)) { p += 5; if (out) *out += "false"; } else bad();
+        } else if (c == 'n') {
+            if (end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; if (out) *out += "null"; } else bad();
+        } else if (c == 'N') {
+            if (end - p >= 3 && !memcmp(p, "NaN", 3)) { p += 3; if (out) *out += "NaN"; } else bad();
+        } else if (c == '-' || c == 'I' || (c >= '0' && c <= '9')) {
+            Span t = number_token();
+            if (out) append_number(*out, t);
+        } else {
+            bad();
+        }
+    }
+
+    char peek() { ws(); return p < end ? *p : 0; }
+};
+
+// what a value token looks like from the outside
+enum Kind { K_OBJECT, K_ARRAY, K_STRING, K_NUMBER, K_TRUE, K_FALSE, K_NULL };
+Kind kind_of(char c) {
+    switch (c) {
+        case '{': return K_OBJECT;
+        case '[': return K_ARRAY;
+        case '"': return K_STRING;
+        case 't': return K_TRUE;
+        case 'f': return K_FALSE;
+        case 'n': return K_NULL;
+        default: return K_NUMBER;  // digits, '-', NaN, Infinity (validated by the parser)
+    }
+}
+
+struct PointTok {
+    Span x, y;
+};
+
+// Walks a ptList array (p at '['): collects the x/y number tokens of every valid point.
+// Regular means: every element that is an object with both keys has NUMBER values there.
+void walk_ptlist(Parser &ps, std::vector<PointTok> &pts) {
+    ++ps.p;
+    if (ps.peek() == ']') { ++ps.p; return; }
+    while (true) {
+        const char c = ps.peek();
+        if (c == '{') {
+            ++ps.p;
+            KeySet ks;
+            bool hx = false, hy = false, okx = false, oky = false;
+            PointTok t{};
+            if (ps.peek() == '}') {
+                ++ps.p;
+            } else {
+                while (true) {
+                    ps.ws();
+                    const Span k = ps.string_token();
+                    ks.add(ps, k);
+                    ps.ws();
+                    if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+                    ++ps.p;
+                    const bool isx = Parser::span_is(k, "x"), isy = Parser::span_is(k, "y");
+                    if (isx || isy) {
+                        const char v = ps.peek();
+                        const bool numeric = (kind_of(v) == K_NUMBER);
+                        const char *b = ps.p;
+                        ps.value(nullptr);
+                        if (isx) { hx = true; okx = numeric; t.x = Span{b, ps.p}; }
+                        else { hy = true; oky = numeric; t.y = Span{b, ps.p}; }
+                    } else {
+                        ps.value(nullptr);
+                    }
+                    const char d = ps.peek();
+                    if (d == ',') { ++ps.p; continue; }
+                    if (d == '}') { ++ps.p; break; }
+                    ps.bad();
+                }
+            }
+            if (hx && hy) {
+                if (!okx || !oky) ps.irregular();  // None / str / bool / container coordinate -> Python path
+                pts.push_back(t);
+            }
+        } else {
+            ps.value(nullptr);  // non-dict element: not a valid point (:253)
+        }
+        const char d = ps.peek();
+        if (d == ',') { ++ps.p; continue; }
+        if (d == ']') { ++ps.p; break; }
+        ps.bad();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// replace step: one traversal that either collects points (scan) or writes the rewritten text (emit)
+// ---------------------------------------------------------------------------------------------------
+struct WH {
+    uint8_t kind = 0;  // 0 absent / null, 1 int, 2 float, 3 something else (host re-reads it with CPython json)
+    double v = 0;
+};
+
+struct CellSink {
+    // scan mode
+    std::vector<double> *xy = nullptr;
+    std::vector<int32_t> *npts = nullptr;
+    // emit mode
+    std::string *out = nullptr;
+    const int32_t *arg4 = nullptr;  // arg indices of this cell's boxes
+    int box = 0;                    // boxes seen so far in this cell
+    WH w, h;
+};
+
+void corner_points(Parser &ps, CellSink &sk, const std::vector<PointTok> &pts) {
+    if (sk.xy) {  // scan: append the points
+        for (const PointTok &t : pts) {
+            const Num nx = classify_number(t.x), ny = classify_number(t.y);
+            if ((nx.is_int && !nx.exact) || (ny.is_int && !ny.exact)) ps.irregular();  // exact big-int compare
+            sk.xy->push_back(nx.v);
+            sk.xy->push_back(ny.v);
+        }
+        sk.npts->push_back((int32_t)pts.size());
+    } else {  // emit: the two corner points, original tokens re-printed (:256-260)
+        std::string &o = *sk.out;
+        if (pts.empty()) {
+            o += "[{\"x\": null, \"y\": null}, {\"x\": null, \"y\": null}]";
+        } else {
+            const int32_t *a = sk.arg4 + 4 * sk.box;
+            const int n = (int)pts.size();
+            for (int i = 0; i < 4; ++i)
+                if (a[i] < 0 || a[i] >= n) ps.irregular();
+            o += "[{\"x\": "; append_number(o, pts[a[0]].x);
+            o += ", \"y\": "; append_number(o, pts[a[1]].y);
+            o += "}, {\"x\": "; append_number(o, pts[a[2]].x);
+            o += ", \"y\": "; append_number(o, pts[a[3]].y);
+            o += "}]";
+        }
+    }
+    ++sk.box;
+}
+
+// polygon object (p at '{'): emits its members, replacing / appending ptList
+void walk_polygon(Parser &ps, CellSink &sk) {
+    std::string *out = sk.out;
+    ++ps.p;
+    if (out) *out += '{';
+    KeySet ks;
+    bool first = true, seen = false;
+    std::vector<PointTok> pts;
+    if (ps.peek() == '}') {
+        ++ps.p;
+    } else {
+        while (true) {
+            ps.ws();
+            const Span k = ps.string_token();
+            ks.add(ps, k);
+            if (out) { if (!first) *out += ", "; ps.emit_string(*out, k); *out += ": "; }
+            first = false;
+            ps.ws();
+            if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+            ++ps.p;
+            if (Parser::span_is(k, "ptList")) {
+                if (kind_of(ps.peek()) != K_ARRAY) ps.irregular();  // None / str / dict / number ptList
+                seen = true;
+                pts.clear();
+                walk_ptlist(ps, pts);
+                corner_points(ps, sk, pts);
+            } else {
+                ps.value(out);
+            }
+            const char d = ps.peek();
+            if (d == ',') { ++ps.p; continue; }
+            if (d == '}') { ++ps.p; break; }
+            ps.bad();
+        }
+    }
+    if (!seen) {  // obj.get("polygon", {}).get("ptList", []) -> [] ; ptList is appended (:276)
+        pts.clear();
+        if (out) { if (!first) *out += ", "; *out += "\"ptList\": "; }
+        corner_points(ps, sk, pts);
+    }
+    if (out) *out += '}';
+}
+
+// one element of "objects" that is an object (p at '{')
+void walk_object(Parser &ps, CellSink &sk) {
+    std::string *out = sk.out;
+    ++ps.p;
+    if (out) *out += '{';
+    KeySet ks;
+    bool first = true, seen = false;
+    if (ps.peek() == '}') {
+        ++ps.p;
+    } else {
+        while (true) {
+            ps.ws();
+            const Span k = ps.string_token();
+            ks.add(ps, k);
+            if (out) { if (!first) *out += ", "; ps.emit_string(*out, k); *out += ": "; }
+            first = false;
+            ps.ws();
+            if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+            ++ps.p;
+            if (Parser::span_is(k, "polygon")) {
+                if (kind_of(ps.peek()) != K_OBJECT) ps.irregular();  // None / list ... -> AttributeError in Python
+                seen = true;
+                walk_polygon(ps, sk);
+            } else {
+                ps.value(out);
+            }
+            const char d = ps.peek();
+            if (d == ',') { ++ps.p; continue; }
+            if (d == '}') { ++ps.p; break; }
+            ps.bad();
+        }
+    }
+    if (!seen) {  // :274-276 — a polygon dict is added at the end
+        std::vector<PointTok> none;
+        if (out) { if (!first) *out += ", "; *out += "\"polygon\": {\"ptList\": "; }
+        corner_points(ps, sk, none);
+        if (out) *out += '}';
+    }
+    if (out) *out += '}';
+}
+
+void read_wh(Parser &ps, WH &dst, std::string *out) {
+    const char c = ps.peek();
+    const Kind kd = kind_of(c);
+    const char *b = ps.p;
+    ps.value(out);
+    if (kd == K_NULL) { dst.kind = 0; return; }
+    if (kd != K_NUMBER) { dst.kind = 3; return; }
+    const Num n = classify_number(Span{b, ps.p});
+    if (n.is_int && !n.exact) { dst.kind = 3; return; }
+    dst.kind = n.is_int ? 1 : 2;
+    dst.v = n.v;
+}
+
+// whole cell.  Throws Fail{1} (undecodable) or Fail{2} (irregular).
+void walk_cell(Span cell, CellSink &sk) {
+    Parser ps{cell.b, cell.e};
+    std::string *out = sk.out;
+    ps.ws();
+    if (ps.p >= ps.end) ps.bad();
+    if (*ps.p != '{') {  // a list / scalar document: data.get raises AttributeError -> Python path decides
+        ps.value(nullptr);
+        ps.ws();
+        if (ps.p != ps.end) ps.bad();
+        ps.irregular();
+    }
+    ++ps.p;
+    if (out) *out += '{';
+    KeySet ks;
+    bool first = true, seen = false;
+    if (ps.peek() == '}') {
+        ++ps.p;
+    } else {
+        while (true) {
+            ps.ws();
+            const Span k = ps.string_token();
+            ks.add(ps, k);
+            if (out) { if (!first) *out += ", "; ps.emit_string(*out, k); *out += ": "; }
+            first = false;
+            ps.ws();
+            if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+            ++ps.p;
+            if (Parser::span_is(k, "objects")) {
+                if (kind_of(ps.peek()) != K_ARRAY) ps.irregular();  // null / dict / str / number "objects"
+                seen = true;
+                ++ps.p;
+                if (out) *out += '[';
+                bool efirst = true;
+                if (ps.peek() == ']') {
+                    ++ps.p;
+                } else {
+                    while (true) {
+                        if (ps.peek() == '{') {
+                            if (out && !efirst) *out += ", ";
+                            efirst = false;
+                            walk_object(ps, sk);
+                        } else {
+                            ps.value(nullptr);  // non-dict objects are dropped (:270)
+                        }
+                        const char d = ps.peek();
+                        if (d == ',') { ++ps.p; continue; }
+                        if (d == ']') { ++ps.p; break; }
+                        ps.bad();
+                    }
+                }
+                if (out) *out += ']';
+            } else if (Parser::span_is(k, "width")) {
+                read_wh(ps, sk.w, out);
+            } else if (Parser::span_is(k, "height")) {
+                read_wh(ps, sk.h, out);
+            } else {
+                ps.value(out);
+            }
+            const char d = ps.peek();
+            if (d == ',') { ++ps.p; continue; }
+            if (d == '}') { ++ps.p; break; }
+            ps.bad();
+        }
+    }
+    ps.ws();
+    if (ps.p != ps.end) ps.bad();  // "Extra data"
+    if (!seen && out) { if (!first) *out += ", "; *out += "\"objects\": []"; }  // data["objects"] = [] (:278)
+    if (out) *out += '}';
+}
+
+// ---------------------------------------------------------------------------------------------------
+// IoU step: two-point boxes of one cell with the reference's prefix-on-exception rule (:341-366)
+// ---------------------------------------------------------------------------------------------------
+enum BoxResult { BR_OK, BR_STOP, BR_IRREGULAR };  // STOP = the reference raises inside its try: keep the prefix
+
+// p at the '{' of a ptList element; consumes it; true when it has both "x" and "y"
+bool point_tokens(Parser &ps, PointTok &t) {
+    ++ps.p;
+    KeySet ks;
+    bool hx = false, hy = false;
+    if (ps.peek() == '}') { ++ps.p; return false; }
+    while (true) {
+        ps.ws();
+        const Span k = ps.string_token();
+        ks.add(ps, k);
+        ps.ws();
+        ++ps.p;  // ':' (the document was validated before)
+        ps.ws();
+        const char *b = ps.p;
+        ps.value(nullptr);
+        if (Parser::span_is(k, "x")) { hx = true; t.x = Span{b, ps.p}; }
+        if (Parser::span_is(k, "y")) { hy = true; t.y = Span{b, ps.p}; }
+        if (ps.peek() == ',') { ++ps.p; continue; }
+        ++ps.p;  // '}'
+        return hx && hy;
+    }
+}
+
+// p at the value of "ptList"; on BR_OK `is_box` tells whether v[4] holds a box
+BoxResult ptlist_box(Parser &ps, double v[4], bool &is_box) {
+    is_box = false;
+    const Kind lk = kind_of(ps.peek());
+    if (lk == K_NULL || lk == K_NUMBER || lk == K_TRUE || lk == K_FALSE) return BR_STOP;  // len() raises TypeError
+    if (lk != K_ARRAY) return BR_IRREGULAR;  // str / dict have a len(): leave them to Python
+    ++ps.p;
+    int n_elems = 0;
+    bool both = true;
+    PointTok pt[2] = {};
+    if (ps.peek() == ']') {
+        ++ps.p;
+    } else {
+        while (true) {
+            const bool dict = (ps.peek() == '{');
+            PointTok t{};
+            bool has_xy = false;
+            if (dict) has_xy = point_tokens(ps, t);
+            else ps.value(nullptr);
+            if (n_elems < 2) { pt[n_elems] = t; both = both && dict && has_xy; }
+            ++n_elems;
+            if (ps.peek() == ',') { ++ps.p; continue; }
+            ++ps.p;  // ']'
+            break;
+        }
+    }
+    if (n_elems != 2 || !both) return BR_OK;  // :352-358 -> continue
+    const Span toks[4] = {pt[0].x, pt[0].y, pt[1].x, pt[1].y};
+    bool any_null = false;
+    for (int i = 0; i < 4; ++i) {
+        const Kind kd = kind_of(*toks[i].b);
+        if (kd == K_NULL) { any_null = true; continue; }
+        if (kd != K_NUMBER) return BR_IRREGULAR;  // str / bool / container coordinates
+        const Num n = classify_number(toks[i]);
+        if (n.is_int && std::fabs(n.v) > 33554432.0) return BR_IRREGULAR;  // > 2^25: exact big-int arithmetic
+        v[i] = n.v;
+    }
+    if (any_null) {
+        // min(None, number) and min(None, None) both raise TypeError, but only if no earlier argument pair of
+        // the four min/max calls is fine first: every one of them involves x or y of BOTH points, and the
+        // first call, min(p1["x"], p2["x"]), raises iff one of the two x is None; otherwise a y is None and the
+        // second call raises.  Either way nothing was appended: prefix.
+        return BR_STOP;
+    }
+    is_box = true;
+    return BR_OK;
+}
+
+// p at the '{' of an "objects" element
+BoxResult object_box(Parser &ps, double v[4], bool &is_box) {
+    is_box = false;
+    ++ps.p;
+    KeySet ks;
+    BoxResult res = BR_OK;
+    if (ps.peek() == '}') { ++ps.p; return BR_OK; }
+    while (true) {
+        ps.ws();
+        const Span k = ps.string_token();
+        ks.add(ps, k);
+        ps.ws();
+        ++ps.p;
+        if (Parser::span_is(k, "polygon")) {
+            const Kind pk = kind_of(ps.peek());
+            if (pk != K_OBJECT) return BR_STOP;  // None / list / str / number .get -> AttributeError
+            ++ps.p;
+            KeySet pks;
+            if (ps.peek() == '}') {
+                ++ps.p;
+            } else {
+                while (true) {
+                    ps.ws();
+                    const Span pkey = ps.string_token();
+                    pks.add(ps, pkey);
+                    ps.ws();
+                    ++ps.p;
+                    if (Parser::span_is(pkey, "ptList")) {
+                        res = ptlist_box(ps, v, is_box);
+                        if (res != BR_OK) return res;
+                    } else {
+                        ps.value(nullptr);
+                    }
+                    if (ps.peek() == ',') { ++ps.p; continue; }
+                    ++ps.p;
+                    break;
+                }
+            }
+        } else {
+            ps.value(nullptr);
+        }
+        if (ps.peek() == ',') { ++ps.p; continue; }
+        ++ps.p;
+        return BR_OK;
+    }
+}
+
+// returns false when the cell must go to the Python path
+bool boxes_of_cell(Span cell, std::vector<double> &box4, int32_t &count) {
+    count = 0;
+    const size_t mark = box4.size();
+    Parser ps{cell.b, cell.e};
+    try {  // validate the whole document first: an undecodable cell yields no boxes at all
+        ps.value(nullptr);
+        ps.ws();
+        if (ps.p != ps.end) ps.bad();
+    } catch (Fail f) {
+        return f.code == 1;  // JSONDecodeError is swallowed by the blanket except -> []
+    }
+    ps = Parser{cell.b, cell.e};
+    try {
+        if (ps.peek() != '{') return true;  // list / scalar document: .get raises inside the try -> []
+        ++ps.p;
+        KeySet ks;
+        if (ps.peek() == '}') { return true; }
+        while (true) {
+            ps.ws();
+            const Span k = ps.string_token();
+            ks.add(ps, k);
+            ps.ws();
+            ++ps.p;
+            if (Parser::span_is(k, "objects")) {
+                const Kind kd = kind_of(ps.peek());
+                if (kd == K_NULL || kd == K_NUMBER || kd == K_TRUE || kd == K_FALSE) return true;  // iteration raises -> []
+                if (kd != K_ARRAY) { box4.resize(mark); count = 0; return false; }  // dict / str iterate: Python path
+                ++ps.p;
+                if (ps.peek() == ']') return true;
+                while (true) {
+                    if (ps.peek() == '{') {
+                        double v[4];
+                        bool is_box = false;
+                        const BoxResult r = object_box(ps, v, is_box);
+                        if (r == BR_STOP) return true;  // keep the prefix collected so far
+                        if (r == BR_IRREGULAR) { box4.resize(mark); count = 0; return false; }
+                        if (is_box) { box4.insert(box4.end(), v, v + 4); ++count; }
+                    } else {
+                        ps.value(nullptr);
+                    }
+                    if (ps.peek() == ',') { ++ps.p; continue; }
+                    return true;
+                }
+            }
+            ps.value(nullptr);
+            if (ps.peek() == ',') { ++ps.p; continue; }
+            return true;  // no "objects" member: []
+        }
+    } catch (Fail f) {
+        box4.resize(mark);
+        count = 0;
+        return false;
+    }
+}
+
+template <class F>
+void parallel_cells(int64_t n, int n_threads, F fn) {
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n / 256));
+    if (n_threads <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
+        th.emplace_back([=] { fn(t, lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+// ===================================================================================================
+// C ABI
+// ===================================================================================================
+struct dyd_scan {
+    int64_t n_cells = 0;
+    std::vector<double> xy;
+    std::vector<int32_t> pt_off;        // [n_boxes + 1]
+    std::vector<int32_t> cell_box_off;  // [n_cells + 1]
+    std::vector<uint8_t> status;        // CellStatus per cell
+    std::vector<uint8_t> w_kind, h_kind;
+    std::vector<double> w_val, h_val;
+    // emit output
+    std::string text;
+    std::vector<int64_t> text_off;
+};
+
+extern "C" {
+
+// Scan annotation cells for the replace step (processor.py:262-281).  text/cell_off: concatenated UTF-8
+// cells; missing[i] != 0 marks a NaN cell.  The handle owns every output array.
+int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                           int n_threads, dyd_scan **out) {
+    if (!out || n_cells < 0 || (n_cells > 0 && !cell_off)) return DYD_ERR_INVALID;
+    dyd_scan *h = new (std::nothrow) dyd_scan();
+    if (!h) return DYD_ERR_OOM;
+    h->n_cells = n_cells;
+    h->status.assign((size_t)n_cells, CELL_OK);
+    h->w_kind.assign((size_t)n_cells, 0); h->h_kind.assign((size_t)n_cells, 0);
+    h->w_val.assign((size_t)n_cells, 0.0); h->h_val.assign((size_t)n_cells, 0.0);
+    std::vector<int32_t> boxes_in_cell((size_t)n_cells, 0);
+    struct Part { std::vector<double> xy; std::vector<int32_t> npts; int64_t lo = 0, hi = 0; };
+    std::vector<Part> parts(64);
+    int used = 0;
+    const bool timing = getenv("DYD_JSON_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    try {
+        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            Part &pt = parts[(size_t)t];
+            pt.lo = lo; pt.hi = hi;
+            for (int64_t i = lo; i < hi; ++i) {
+                if (missing && missing[i]) { h->status[(size_t)i] = CELL_MISSING; continue; }
+                const size_t xy_mark = pt.xy.size(), np_mark = pt.npts.size();
+                CellSink sk;
+                sk.xy = &pt.xy; sk.npts = &pt.npts;
+                try {
+                    walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
+                    boxes_in_cell[(size_t)i] = sk.box;
+                    h->w_kind[(size_t)i] = sk.w.kind; h->w_val[(size_t)i] = sk.w.v;
+                    h->h_kind[(size_t)i] = sk.h.kind; h->h_val[(size_t)i] = sk.h.v;
+                } catch (Fail f) {
+                    pt.xy.resize(xy_mark); pt.npts.resize(np_mark);
+                    h->status[(size_t)i] = (f.code == 1) ? CELL_UNDECODABLE : CELL_IRREGULAR;
+                }
+            }
+        });
+        if (timing) fprintf(stderr, "scan parallel part: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
+        for (auto &pt : parts) if (pt.hi > pt.lo || !pt.npts.empty()) ++used;
+        size_t nb = 0, np2 = 0;
+        for (auto &pt : parts) { nb += pt.npts.size(); np2 += pt.xy.size(); }
+        if (np2 / 2 >= (size_t)1 << 31) { delete h; return DYD_ERR_RANGE; }
+        h->xy.reserve(np2);
+        h->pt_off.reserve(nb + 1);
+        h->pt_off.push_back(0);
+        std::sort(parts.begin(), parts.end(), [](const Part &a, const Part &b) { return a.lo < b.lo; });
+        int32_t run = 0;
+        for (auto &pt : parts) {
+            h->xy.insert(h->xy.end(), pt.xy.begin(), pt.xy.end());
+            for (int32_t c : pt.npts) { run += c; h->pt_off.push_back(run); }
+        }
+        h->cell_box_off.resize((size_t)n_cells + 1);
+        h->cell_box_off[0] = 0;
+        for (int64_t i = 0; i < n_cells; ++i) h->cell_box_off[(size_t)i + 1] = h->cell_box_off[(size_t)i] + boxes_in_cell[(size_t)i];
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    (void)used;
+    *out = h;
+    return DYD_OK;
+}
+
+int64_t dyd_scan_n_boxes(const dyd_scan *h) { return h ? (int64_t)h->pt_off.size() - 1 : 0; }
+int64_t dyd_scan_n_points(const dyd_scan *h) { return h ? (int64_t)h->xy.size() / 2 : 0; }
+const double *dyd_scan_xy(const dyd_scan *h) { return h->xy.data(); }
+const int32_t *dyd_scan_pt_off(const dyd_scan *h) { return h->pt_off.data(); }
+const int32_t *dyd_scan_cell_box_off(const dyd_scan *h) { return h->cell_box_off.data(); }
+const uint8_t *dyd_scan_status(const dyd_scan *h) { return h->status.data(); }
+const uint8_t *dyd_scan_wh_kind(const dyd_scan *h, int which) { return which ? h->h_kind.data() : h->w_kind.data(); }
+const double *dyd_scan_wh_value(const dyd_scan *h, int which) { return which ? h->h_val.data() : h->w_val.data(); }
+
+// Emit the rewritten JSON text of every CELL_OK cell (empty text for the others).  arg4 = K1's arg indices
+// for the boxes of the scan, in scan order.  Output stays owned by the handle.
+int dyd_json_emit_polygons(dyd_scan *h, const uint8_t *text, const int64_t *cell_off, const int32_t *arg4,
+                           int n_threads, const uint8_t **out_text, const int64_t **out_off) {
+    if (!h || !out_text || !out_off) return DYD_ERR_INVALID;
+    const int64_t n = h->n_cells;
+    std::vector<std::string> parts(64);
+    std::vector<int64_t> lens((size_t)n, 0);
+    std::vector<std::pair<int64_t, int>> order;
+    std::vector<std::pair<int64_t, int64_t>> ranges(64, {0, 0});
+    int bad = 0;
+    try {
+        parallel_cells(n, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            std::string &o = parts[(size_t)t];
+            ranges[(size_t)t] = {lo, hi};
+            for (int64_t i = lo; i < hi; ++i) {
+                if (h->status[(size_t)i] != CELL_OK) continue;
+                const size_t mark = o.size();
+                CellSink sk;
+                sk.out = &o;
+                sk.arg4 = arg4 + 4 * (int64_t)h->cell_box_off[(size_t)i];
+                try {
+                    walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
+                    lens[(size_t)i] = (int64_t)(o.size() - mark);
+                } catch (Fail) {
+                    o.resize(mark);
+                    __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+                }
+            }
+        });
+        if (bad) return DYD_ERR_INVALID;  // arg4 inconsistent with the scan
+        std::vector<int> idx;
+        for (int t = 0; t < 64; ++t) if (ranges[(size_t)t].second > ranges[(size_t)t].first) idx.push_back(t);
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return ranges[(size_t)a].first < ranges[(size_t)b].first; });
+        size_t total = 0;
+        for (int t : idx) total += parts[(size_t)t].size();
+        h->text.clear();
+        h->text.reserve(total);
+        for (int t : idx) h->text += parts[(size_t)t];
+        h->text_off.resize((size_t)n + 1);
+        h->text_off[0] = 0;
+        for (int64_t i = 0; i < n; ++i) h->text_off[(size_t)i + 1] = h->text_off[(size_t)i] + lens[(size_t)i];
+    } catch (const std::bad_alloc &) {
+        return DYD_ERR_OOM;
+    }
+    *out_text = reinterpret_cast<const uint8_t *>(h->text.data());
+    *out_off = h->text_off.data();
+    return DYD_OK;
+}
+
+void dyd_scan_free(dyd_scan *h) { delete h; }
+
+// Scan bbox-JSON cells for the IoU step (processor.py:341-366): two-point boxes per row with the
+// prefix-on-exception rule.  status[i] = 0 regular, 2 = Python path.  Arrays are owned by the handle
+// (xy = box4 [4*B], pt_off unused, cell_box_off = row offsets).
+int dyd_json_scan_boxes(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                        int n_threads, dyd_scan **out) {
+    if (!out || n_cells < 0 || (n_cells > 0 && !cell_off)) return DYD_ERR_INVALID;
+    dyd_scan *h = new (std::nothrow) dyd_scan();
+    if (!h) return DYD_ERR_OOM;
+    h->n_cells = n_cells;
+    h->status.assign((size_t)n_cells, CELL_OK);
+    std::vector<int32_t> counts((size_t)n_cells, 0);
+    struct Part { std::vector<double> b; int64_t lo = 0, hi = 0; };
+    std::vector<Part> parts(64);
+    try {
+        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            Part &pt = parts[(size_t)t];
+            pt.lo = lo; pt.hi = hi;
+            for (int64_t i = lo; i < hi; ++i) {
+                if (missing && missing[i]) continue;  // NaN cell: no boxes (:344-345)
+                int32_t c = 0;
+                if (!boxes_of_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, pt.b, c)) {
+                    h->status[(size_t)i] = CELL_IRREGULAR;
+                    c = 0;
+                }
+                counts[(size_t)i] = c;
+            }
+        });
+        std::sort(parts.begin(), parts.end(), [](const Part &a, const Part &b) { return a.lo < b.lo; });
+        size_t tot = 0;
+        for (auto &pt : parts) tot += pt.b.size();
+        if (tot / 4 >= (size_t)1 << 31) { delete h; return DYD_ERR_RANGE; }
+        h->xy.reserve(tot);
+        for (auto &pt : parts) h->xy.insert(h->xy.end(), pt.b.begin(), pt.b.end());
+        h->cell_box_off.resize((size_t)n_cells + 1);
+        h->cell_box_off[0] = 0;
+        for (int64_t i = 0; i < n_cells; ++i) h->cell_box_off[(size_t)i + 1] = h->cell_box_off[(size_t)i] + counts[(size_t)i];
+        h->pt_off.assign(1, 0);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    *out = h;
+    return DYD_OK;
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@
 //
 // Mapping: a wave owns a tile of K6_TILE consecutive rows and keeps one running counter per
 // category in LDS.  Pass A counts the tile per category; pass B is an exclusive scan over tiles
-// per category (one workgroup per category); pass C replays the tile 64 rows at a time: lanes
+// per category (chunked: shuffle scan inside 4096-tile chunks, then the few chunk totals); pass C replays the tile 64 rows at a time: lanes
 // holding the same category are found with ballots, a lane's rank is counter + popcount of the
 // lower lanes of its ballot.  Categories are processed in windows of K6_CATS so any n_cat fits.
 #include "dyd_common.h"
@@ -52,27 +52,59 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_count(const int32_t *__restrict__
         for (int c = lane; c < nc; c += kWave) hist[(int64_t)c * n_tiles + tile] = s_cnt[wave][c];
 }
 
-// pass B: in-place exclusive scan of hist[c][0..n_tiles) for every category of the window
-__global__ __launch_bounds__(K6_BLOCK) void k6_scan(unsigned int *hist, int64_t n_tiles) {
-    __shared__ unsigned long long s_part[K6_BLOCK];
-    unsigned int *row = hist + (int64_t)blockIdx.x * n_tiles;
-    unsigned long long carry = 0;
-    for (int64_t base = 0; base < n_tiles; base += K6_BLOCK) {
-        const int64_t i = base + threadIdx.x;
-        const unsigned int v = (i < n_tiles) ? row[i] : 0u;
-        s_part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < K6_BLOCK; off <<= 1) {  // Hillis-Steele inclusive scan
-            unsigned long long add = (threadIdx.x >= (unsigned)off) ? s_part[threadIdx.x - off] : 0ull;
-            __syncthreads();
-            s_part[threadIdx.x] += add;
-            __syncthreads();
+// pass B1: exclusive scan of hist[c][...] inside chunks of K6_SCAN_CHUNK tiles (one workgroup per
+// (chunk, category)); the chunk's total goes to chunk_tot[c][chunk]
+constexpr int K6_SCAN_PER_THREAD = 16;
+constexpr int K6_SCAN_CHUNK = K6_BLOCK * K6_SCAN_PER_THREAD;
+
+__global__ __launch_bounds__(K6_BLOCK) void k6_scan_chunks(unsigned int *hist, int64_t n_tiles, int64_t n_chunks,
+                                                           unsigned long long *__restrict__ chunk_tot) {
+    __shared__ unsigned int s_wave[K6_WAVES];
+    const int c = blockIdx.y;
+    const int64_t chunk = blockIdx.x;
+    unsigned int *row = hist + (int64_t)c * n_tiles;
+    const int64_t first = chunk * K6_SCAN_CHUNK + (int64_t)threadIdx.x * K6_SCAN_PER_THREAD;
+    unsigned int v[K6_SCAN_PER_THREAD];
+    unsigned int sum = 0;
+#pragma unroll
+    for (int k = 0; k < K6_SCAN_PER_THREAD; ++k) {
+        v[k] = (first + k < n_tiles) ? row[first + k] : 0u;
+        sum += v[k];
+    }
+    // inclusive scan of `sum` across the wave, then across the workgroup's four waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int incl = sum;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == kWave - 1) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned int wave_base = 0, total = 0;
+    for (int w = 0; w < K6_WAVES; ++w) {
+        if (w < wave) wave_base += s_wave[w];
+        total += s_wave[w];
+    }
+    unsigned int run = wave_base + incl - sum;  // exclusive prefix of this thread inside the chunk
+#pragma unroll
+    for (int k = 0; k < K6_SCAN_PER_THREAD; ++k) {
+        if (first + k < n_tiles) row[first + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) chunk_tot[(int64_t)c * n_chunks + chunk] = total;
+}
+
+// pass B2: exclusive scan of the chunk totals of every category (n_chunks is tiny: tiles / 4096)
+__global__ void k6_scan_totals(unsigned long long *chunk_tot, int64_t n_chunks) {
+    unsigned long long *row = chunk_tot + (int64_t)blockIdx.x * n_chunks;
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int64_t i = 0; i < n_chunks; ++i) {
+            const unsigned long long v = row[i];
+            row[i] = run;
+            run += v;
         }
-        const unsigned long long incl = s_part[threadIdx.x];
-        const unsigned long long total = s_part[K6_BLOCK - 1];
-        if (i < n_tiles) row[i] = (unsigned int)(carry + incl - v);
-        carry += total;
-        __syncthreads();
     }
 }
 
@@ -97,7 +129,8 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_invert(const int64_t *__restrict_
 __global__ __launch_bounds__(K6_BLOCK) void k6_assign(const int32_t *__restrict__ cat, int64_t n, int32_t c0,
                                                       int32_t c1, int64_t n_tiles,
                                                       const unsigned int *__restrict__ hist,
-                                                      const int64_t *__restrict__ inv,
+                                                      const unsigned long long *__restrict__ chunk_off,
+                                                      int64_t n_chunks, const int64_t *__restrict__ inv,
                                                       const int64_t *__restrict__ cat_off,
                                                       const int64_t *__restrict__ n_train,
                                                       const int64_t *__restrict__ n_val,
@@ -111,7 +144,9 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_assign(const int32_t *__restrict_
     // running in-category rank at the start of this tile; rank_base (multi-GPU) = rows of the
     // category held by lower ranks
     for (int c = lane; c < nc; c += kWave)
-        s_cnt[wave][c] = hist[(int64_t)c * n_tiles + tile] + (rank_base ? (unsigned int)rank_base[c0 + c] : 0u);
+        s_cnt[wave][c] = hist[(int64_t)c * n_tiles + tile] +
+                         (unsigned int)chunk_off[(int64_t)c * n_chunks + tile / K6_SCAN_CHUNK] +
+                         (rank_base ? (unsigned int)rank_base[c0 + c] : 0u);
     __builtin_amdgcn_wave_barrier();
     const int64_t r0 = tile * K6_TILE;
     const int64_t r1 = (r0 + K6_TILE < n) ? r0 + K6_TILE : n;
@@ -169,12 +204,16 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
     const int64_t blocks = ceil_div(n_tiles, K6_WAVES);
     const int32_t win = n_cat < K6_CATS ? n_cat : K6_CATS;
     const size_t inv_bytes = (size_t)(total > 0 ? total : 1) * 8;
-    const size_t hist_bytes = (size_t)(win > 0 ? win : 1) * (size_t)n_tiles * 4;
+    const size_t hist_bytes = (((size_t)(win > 0 ? win : 1) * (size_t)n_tiles * 4) + 15) & ~(size_t)15;
+    const int64_t n_chunks = ceil_div(n_tiles, K6_SCAN_CHUNK);
+    const size_t tot_bytes = (size_t)(win > 0 ? win : 1) * (size_t)n_chunks * 8;
     void *scr = nullptr;
-    int rc = get_scratch(inv_bytes + hist_bytes, &scr, st);
+    int rc = get_scratch(inv_bytes + hist_bytes + tot_bytes, &scr, st);
     if (rc) return rc;
     int64_t *inv = static_cast<int64_t *>(scr);
     unsigned int *hist = reinterpret_cast<unsigned int *>(static_cast<char *>(scr) + inv_bytes);
+    unsigned long long *chunk_tot =
+        reinterpret_cast<unsigned long long *>(static_cast<char *>(scr) + inv_bytes + hist_bytes);
     hipLaunchKernelGGL(k6_unclassified, dim3((unsigned)ceil_div(n, K6_BLOCK)), dim3(K6_BLOCK), 0, st, cat, n, n_cat,
                        out_split, out_pos);
     DYD_HIP(hipGetLastError());
@@ -188,10 +227,13 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
         const int32_t c1 = (n_cat - c0 < K6_CATS) ? n_cat : c0 + K6_CATS;
         hipLaunchKernelGGL(k6_count, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist);
         DYD_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k6_scan, dim3((unsigned)(c1 - c0)), dim3(K6_BLOCK), 0, st, hist, n_tiles);
+        hipLaunchKernelGGL(k6_scan_chunks, dim3((unsigned)n_chunks, (unsigned)(c1 - c0)), dim3(K6_BLOCK), 0, st, hist,
+                           n_tiles, n_chunks, chunk_tot);
         DYD_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k6_assign, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist, inv,
-                           cat_off, n_train, n_val, rank_base, out_split, out_pos);
+        hipLaunchKernelGGL(k6_scan_totals, dim3((unsigned)(c1 - c0)), dim3(kWave), 0, st, chunk_tot, n_chunks);
+        DYD_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k6_assign, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist,
+                           chunk_tot, n_chunks, inv, cat_off, n_train, n_val, rank_base, out_split, out_pos);
         DYD_HIP(hipGetLastError());
     }
     release_scratch(st);

@@ -1,0 +1,150 @@
+"""Python face of the native flatten / emit (csrc/host_json.cpp).
+
+``scan_polygons`` / ``scan_boxes`` turn a column of annotation cells into the SoA buffers of K1 / K2
+without CPython's ``json``; ``PolygonScan.emit`` writes the rewritten JSON text.  Cells the native
+scanner classifies as irregular (status 2) are NOT processed here: the callers in core/processor.py
+run them through flatten.py, which follows the reference accessor by accessor.
+
+This is host code inside libdyd_gfx950.so: it needs the library but no GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _native
+
+OK, UNDECODABLE, IRREGULAR, MISSING = 0, 1, 2, 3
+
+
+def enabled() -> bool:
+    return os.environ.get("DYD_NATIVE_JSON", "1") != "0"
+
+
+def cells_to_buffers(cells):
+    """list / Series of cells -> (utf-8 bytes u8, offsets i64, missing u8, keep-alive object).
+
+    Non-str cells count as missing (reference processor.py:264, :344).  Cells are joined with one
+    blank (legal trailing JSON whitespace) and encoded in ONE pass; byte offsets follow from the
+    str lengths, re-measured only for cells that are not pure ASCII.  Raises UnicodeEncodeError for
+    lone surrogates (the caller then takes the Python path, which reproduces to_csv's failure)."""
+    vals = [c if type(c) is str else "" for c in cells]
+    n = len(vals)
+    missing = np.fromiter((type(c) is not str for c in cells), dtype=np.uint8, count=n)
+    blob = " ".join(vals)
+    data = blob.encode("utf-8")
+    lens = np.fromiter(map(len, vals), dtype=np.int64, count=n)
+    if len(data) != len(blob):                     # some cell holds non-ASCII text: measure those in bytes
+        for i, v in enumerate(vals):
+            if not v.isascii():
+                lens[i] = len(v.encode("utf-8"))
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens + 1, out=off[1:])               # +1: the separator blank belongs to the cell before it
+    if n:
+        off[-1] -= 1                               # no blank after the last cell
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    return buf, off, missing, data
+
+
+def _view(ptr, dtype, count):
+    if count == 0 or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
+
+
+class _Scan:
+    def __init__(self, handle, n_cells, keep):
+        self._h = handle
+        self._keep = keep            # arrow array / numpy buffers the native side points into
+        L = _native.load_library()
+        self.n_cells = n_cells
+        self.n_boxes = int(L.dyd_scan_n_boxes(handle))
+        self.status = _view(L.dyd_scan_status(handle), np.uint8, n_cells).copy()
+        self.cell_box_off = _view(L.dyd_scan_cell_box_off(handle), np.int32, n_cells + 1).copy()
+
+    def close(self):
+        if self._h:
+            _native.load_library().dyd_scan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class PolygonScan(_Scan):
+    """Result of scan_polygons: SoA points of the regular cells + what emit needs."""
+
+    def __init__(self, handle, n_cells, keep, data, off):
+        super().__init__(handle, n_cells, keep)
+        L = _native.load_library()
+        n_pts = int(L.dyd_scan_n_points(handle))
+        self.xy = _view(L.dyd_scan_xy(handle), np.float64, 2 * n_pts).reshape(-1, 2)   # views into the handle
+        self.pt_off = _view(L.dyd_scan_pt_off(handle), np.int32, self.n_boxes + 1)
+        self._data, self._off = data, off
+        self.w_kind = _view(L.dyd_scan_wh_kind(handle, 0), np.uint8, n_cells).copy()
+        self.h_kind = _view(L.dyd_scan_wh_kind(handle, 1), np.uint8, n_cells).copy()
+        self.w_val = _view(L.dyd_scan_wh_value(handle, 0), np.float64, n_cells).copy()
+        self.h_val = _view(L.dyd_scan_wh_value(handle, 1), np.float64, n_cells).copy()
+
+    def emit(self, arg4: np.ndarray, n_threads: int = 0) -> list:
+        """Rewritten JSON text per cell: str for regular cells, None for undecodable / missing cells and
+        for irregular ones (the caller fills those in)."""
+        import pyarrow as pa
+
+        L = _native.load_library()
+        arg4 = np.ascontiguousarray(arg4, dtype=np.int32).reshape(-1)
+        if arg4.size != 4 * self.n_boxes:
+            raise ValueError("arg4 does not match the scan")
+        out_text, out_off = C.c_void_p(), C.c_void_p()
+        _native.check(L.dyd_json_emit_polygons(self._h, self._data.ctypes.data, self._off.ctypes.data,
+                                               arg4.ctypes.data if arg4.size else None, n_threads,
+                                               C.byref(out_text), C.byref(out_off)), "dyd_json_emit_polygons")
+        off = _view(out_off.value, np.int64, self.n_cells + 1)
+        total = int(off[-1])
+        text = _view(out_text.value, np.uint8, total)
+        arr = pa.LargeStringArray.from_buffers(self.n_cells, pa.py_buffer(off), pa.py_buffer(text if total else b""))
+        out = arr.to_pylist()
+        bad = np.flatnonzero(self.status != OK)
+        for i in bad.tolist():
+            out[i] = None
+        return out
+
+    def width_height(self, which: int) -> list:
+        """Python values of doc.get("width") / doc.get("height") for regular cells (None elsewhere);
+        kind 3 (string / container / huge int) is returned as the marker ``Ellipsis`` for the caller."""
+        kind = self.w_kind if which == 0 else self.h_kind
+        val = self.w_val if which == 0 else self.h_val
+        out = [None] * self.n_cells
+        for i in np.flatnonzero(kind).tolist():
+            k = kind[i]
+            out[i] = int(val[i]) if k == 1 else (float(val[i]) if k == 2 else Ellipsis)
+        return out
+
+
+class BoxScan(_Scan):
+    def __init__(self, handle, n_cells, keep):
+        super().__init__(handle, n_cells, keep)
+        L = _native.load_library()
+        nb = int(self.cell_box_off[-1]) if n_cells else 0
+        self.box4 = _view(L.dyd_scan_xy(handle), np.float64, 4 * nb).reshape(-1, 4)
+        self.row_off = self.cell_box_off
+
+
+def scan_polygons(cells, n_threads: int = 0) -> PolygonScan:
+    data, off, missing, keep = cells_to_buffers(cells)
+    L = _native.load_library()
+    h = C.c_void_p()
+    _native.check(L.dyd_json_scan_polygons(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1,
+                                           n_threads, C.byref(h)), "dyd_json_scan_polygons")
+    return PolygonScan(h, len(off) - 1, keep, data, off)
+
+
+def scan_boxes(cells, n_threads: int = 0) -> BoxScan:
+    data, off, missing, keep = cells_to_buffers(cells)
+    L = _native.load_library()
+    h = C.c_void_p()
+    _native.check(L.dyd_json_scan_boxes(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1,
+                                        n_threads, C.byref(h)), "dyd_json_scan_boxes")
+    return BoxScan(h, len(off) - 1, keep)

@@ -164,6 +164,31 @@ int dyd_split_ids_sharded_dev(const int32_t *cat, int64_t n, const int64_t *cat_
                               int32_t n_cat, const int64_t *cat_rank_base, uint8_t *out_split,
                               int64_t *out_pos, void *stream);
 
+/* ---- native flatten / emit (HOST code, multithreaded) ------------------------------
+ * Schema-specialised JSON scanner + canonical re-emitter that replaces json.loads / json.dumps inside
+ * parse_and_replace_ptlist (processor.py:262-281), extract_width_height (:285-292) and extract_boxes
+ * (:341-366).  Cells are passed as concatenated UTF-8 text + offsets; `missing[i]` marks NaN cells.
+ * status per cell: 0 regular, 1 undecodable JSON (the reference yields None / no boxes), 2 irregular
+ * (the caller must process the cell with the Python flatten of flatten.py), 3 missing.
+ * The handle owns every array the accessors return; free it with dyd_scan_free. */
+typedef struct dyd_scan dyd_scan;
+int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing,
+                           int64_t n_cells, int n_threads, dyd_scan **out);
+int dyd_json_emit_polygons(dyd_scan *scan, const uint8_t *text, const int64_t *cell_off,
+                           const int32_t *arg4, int n_threads, const uint8_t **out_text,
+                           const int64_t **out_off);
+int dyd_json_scan_boxes(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing,
+                        int64_t n_cells, int n_threads, dyd_scan **out);
+int64_t dyd_scan_n_boxes(const dyd_scan *scan);
+int64_t dyd_scan_n_points(const dyd_scan *scan);
+const double *dyd_scan_xy(const dyd_scan *scan);              /* points [2*P] (polygons) or box4 [4*B] (boxes) */
+const int32_t *dyd_scan_pt_off(const dyd_scan *scan);         /* [n_boxes+1] */
+const int32_t *dyd_scan_cell_box_off(const dyd_scan *scan);   /* [n_cells+1] */
+const uint8_t *dyd_scan_status(const dyd_scan *scan);         /* [n_cells] */
+const uint8_t *dyd_scan_wh_kind(const dyd_scan *scan, int which);   /* which: 0 width, 1 height; 0 none 1 int 2 float 3 other */
+const double *dyd_scan_wh_value(const dyd_scan *scan, int which);
+void dyd_scan_free(dyd_scan *scan);
+
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging. */
 int dyd_set_option(const char *key, int64_t value);

@@ -1,0 +1,244 @@
+"""Differential tests of the native flatten / emit (csrc/host_json.cpp) against CPython's json through
+the reference restatement (oracle/steps.py): every cell must give the same text / None / exception
+type, whether the native scanner handles it or hands it to flatten.py.  Host code: no GPU needed."""
+import json
+import math
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from deal_yolo_daya_amd import native_json as nj
+from deal_yolo_daya_amd.core import processor as P
+from oracle import steps as osteps
+
+NUMBERS = ["0", "-0", "1", "-1", "7", "10", "1920", "-35", "123456789", "9007199254740992", "9007199254740993",
+           "-9007199254740993", "12345678901234567890", "0.0", "-0.0", "1.0", "1.5", "10.50", "3.14159", "0.1", "0.30000000000000004",
+           "1e5", "1E5", "1e+5", "1.5e-7", "1e-5", "0.0001", "0.00001", "1e15", "1e16", "1e22", "1e23", "123456789012345.6",
+           "1234567890123456.7", "5e-324", "1.7976931348623157e308", "1e400", "-1e400", "2.5E+3", "100.0", "1e0", "0e0",
+           "4.35", "0.000001", "1.0e-6", "33554432", "33554433", "-33554433", "NaN", "Infinity", "-Infinity"]
+STRINGS = ['""', '"a"', '"中文"', '"\\u4e2d\\u6587"', '"\\ud83d\\ude00"', '"😀"', '"a\\"b"', '"back\\\\slash"', '"sl\\/ash"',
+           '"tab\\tnl\\ncr\\rbs\\bff\\f"', '"\\u0000\\u001f\\u007f"', '"é\\u00e9"', '"x"', '"y"', '"objects"', '"c1,c2"']
+LONE = ['"\\ud800"', '"\\udc00x"', '"\\ud83dabc"']
+KEYS = ['"objects"', '"polygon"', '"ptList"', '"x"', '"y"', '"width"', '"height"', '"name"', '"id"', '"k"', '"中"',
+        '"\\u0078"', '"a b"']
+
+
+class Gen:
+    def __init__(self, seed):
+        self.r = random.Random(seed)
+
+    def ws(self):
+        return self.r.choice(["", "", "", " ", "  ", "\n", "\t", " \r\n "])
+
+    def number(self):
+        return self.r.choice(NUMBERS)
+
+    def scalar(self):
+        r = self.r.random()
+        if r < 0.45:
+            return self.number()
+        if r < 0.7:
+            return self.r.choice(STRINGS)
+        if r < 0.72:
+            return self.r.choice(LONE)
+        return self.r.choice(["true", "false", "null"])
+
+    def value(self, depth=0):
+        r = self.r.random()
+        if depth > 3 or r < 0.55:
+            return self.scalar()
+        if r < 0.78:
+            return self.obj(depth + 1)
+        return self.arr(depth + 1)
+
+    def obj(self, depth, keys=None, vals=None):
+        n = self.r.randint(0, 4)
+        items = []
+        for _ in range(n):
+            k = self.r.choice(KEYS)
+            items.append(f"{self.ws()}{k}{self.ws()}:{self.ws()}{self.value(depth)}{self.ws()}")
+        if self.r.random() < 0.03 and items:
+            items.append(items[0])                      # duplicate key
+        return "{" + ",".join(items) + "}" if items else "{" + self.ws() + "}"
+
+    def arr(self, depth):
+        n = self.r.randint(0, 4)
+        return "[" + ",".join(f"{self.ws()}{self.value(depth)}{self.ws()}" for _ in range(n)) + "]"
+
+    def point(self):
+        r = self.r.random()
+        if r < 0.75:
+            items = [f'"x"{self.ws()}:{self.ws()}{self.number()}', f'"y": {self.number()}']
+        elif r < 0.85:
+            items = [f'"x": {self.scalar()}', f'"y": {self.scalar()}']
+        elif r < 0.9:
+            items = [f'"x": {self.number()}']
+        else:
+            return self.value(2)
+        if self.r.random() < 0.2:
+            items.append(f'{self.r.choice(KEYS)}: {self.value(2)}')
+        self.r.shuffle(items)
+        return "{" + ", ".join(items) + "}"
+
+    def ptlist(self, two=False):
+        r = self.r.random()
+        if r < 0.85:
+            n = 2 if two and self.r.random() < 0.8 else self.r.randint(0, 6)
+            return "[" + ("," + self.ws()).join(self.point() for _ in range(n)) + "]"
+        return self.value(2)
+
+    def annotation_object(self, two=False):
+        items = []
+        if self.r.random() < 0.9:
+            pg = []
+            if self.r.random() < 0.9:
+                pg.append(f'"ptList"{self.ws()}:{self.ws()}{self.ptlist(two)}')
+            if self.r.random() < 0.3:
+                pg.append(f'{self.r.choice(KEYS)}: {self.value(2)}')
+            self.r.shuffle(pg)
+            poly = "{" + ", ".join(pg) + "}" if self.r.random() < 0.93 else self.value(2)
+            items.append(f'"polygon": {poly}')
+        if self.r.random() < 0.7:
+            items.append(f'"name": {self.r.choice(STRINGS)}')
+        if self.r.random() < 0.3:
+            items.append(f'{self.r.choice(KEYS)}: {self.value(2)}')
+        self.r.shuffle(items)
+        return "{" + ("," + self.ws()).join(items) + "}"
+
+    def cell(self, two=False):
+        r = self.r.random()
+        if r < 0.04:
+            return self.value(0)
+        items = []
+        if self.r.random() < 0.92:
+            if self.r.random() < 0.93:
+                n = self.r.randint(0, 5)
+                objs = [self.annotation_object(two) if self.r.random() < 0.9 else self.value(1) for _ in range(n)]
+                items.append(f'"objects"{self.ws()}:{self.ws()}[' + ("," + self.ws()).join(objs) + "]")
+            else:
+                items.append(f'"objects": {self.value(1)}')
+        for key in ("width", "height"):
+            if self.r.random() < 0.6:
+                items.append(f'"{key}": {self.scalar() if self.r.random() < 0.8 else self.value(1)}')
+        if self.r.random() < 0.4:
+            items.append(f'{self.r.choice(KEYS)}: {self.value(1)}')
+        self.r.shuffle(items)
+        text = self.ws() + "{" + ("," + self.ws()).join(items) + "}" + self.ws()
+        m = self.r.random()
+        if m < 0.05 and text:                           # corrupt the text
+            k = self.r.randrange(len(text))
+            text = text[:k] + self.r.choice(['"', "}", ",", "x", "\\", "\x01", ""]) + text[k + self.r.randint(0, 2):]
+        elif m < 0.07:
+            text = text[: self.r.randrange(len(text) + 1)]
+        return text
+
+
+def _same(a, b):
+    if isinstance(a, float) and isinstance(b, float):
+        return (math.isnan(a) and math.isnan(b)) or (a == b and math.copysign(1, a) == math.copysign(1, b))
+    return type(a) is type(b) and a == b
+
+
+def _ref_replace(cell):
+    try:
+        return ("ok", osteps.replace_cell(cell), osteps.width_height_of_cell(cell))
+    except Exception as e:  # noqa: BLE001
+        return ("raise", type(e).__name__, None)
+
+
+def _our_replace(cell, backend):
+    stats = {}
+    try:
+        t, w, h = P.replace_ptlist_cells([cell], backend, stats)
+        return ("ok", t[0], (w[0], h[0])), stats
+    except Exception as e:  # noqa: BLE001
+        return ("raise", type(e).__name__, None), stats
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_replace_fuzz_matches_cpython(oracle_backend, seed):
+    g = Gen(seed)
+    native = 0
+    for _ in range(600):
+        cell = g.cell()
+        want = _ref_replace(cell)
+        got, stats = _our_replace(cell, oracle_backend)
+        if want[0] == "ok" and got[0] == "ok" and want[1] is not None:
+            try:
+                want[1].encode("utf-8")
+            except UnicodeEncodeError:
+                continue                      # lone surrogate survives json.dumps; to_csv would raise later
+        assert got[0] == want[0], cell
+        assert got[1] == want[1], cell
+        if want[0] == "ok":
+            assert _same(got[2][0], want[2][0]) and _same(got[2][1], want[2][1]), cell
+        native += stats.get("python_cells", 1) == 0
+    assert native > 150                       # the native scanner must be doing a good share of the work
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_iou_fuzz_matches_cpython(oracle_backend, seed):
+    g = Gen(1000 + seed)
+    native = 0
+    for _ in range(600):
+        cell = g.cell(two=True)
+        for mb, thr in ((2, 0.98), (1, 0.0)):
+            try:
+                want = ("ok", osteps.row_is_high(osteps.boxes_of_cell(cell), mb, thr))
+            except Exception as e:  # noqa: BLE001
+                want = ("raise", type(e).__name__)
+            stats = {}
+            try:
+                got = ("ok", bool(P.iou_high_mask([cell], mb, thr, oracle_backend, stats)[0]))
+            except Exception as e:  # noqa: BLE001
+                got = ("raise", type(e).__name__)
+            assert got == want, (cell, mb, thr)
+        native += stats.get("python_cells", 1) == 0
+    assert native > 150
+
+
+def test_batch_order_and_mixed_cells(oracle_backend):
+    """a batch mixing regular, irregular, undecodable and missing cells keeps every result in place"""
+    g = load_golden("replace_cases.json")
+    names = list(g["value_cases"])
+    cells = [g["value_cases"][n]["in"] for n in names] + [None, float("nan"), 7]
+    stats = {}
+    texts, w, h = P.replace_ptlist_cells(cells, oracle_backend, stats)
+    assert texts[:len(names)] == [g["value_cases"][n]["out"] for n in names]
+    assert texts[len(names):] == [None, None, None]
+    assert 0 < stats["python_cells"] < len(names)
+    scan = nj.scan_polygons(cells)
+    by = dict(zip(names, scan.status.tolist()))
+    assert by["int_polygon"] == nj.OK and by["undecodable_json"] == nj.UNDECODABLE
+    assert by["big_ints_exact"] == nj.IRREGULAR and by["dup_keys_last_wins"] == nj.IRREGULAR
+    assert scan.status[-3:].tolist() == [nj.MISSING] * 3
+
+
+def test_python_path_switch(oracle_backend, monkeypatch):
+    g = load_golden("replace_cases.json")
+    cells = [c["in"] for c in g["value_cases"].values()]
+    a = P.replace_ptlist_cells(cells, oracle_backend)
+    monkeypatch.setenv("DYD_NATIVE_JSON", "0")
+    stats = {}
+    b = P.replace_ptlist_cells(cells, oracle_backend, stats)
+    assert a[0] == b[0] and stats["python_cells"] == len(cells)
+
+
+def test_float_repr_matches_python():
+    """number tokens are re-printed exactly like repr(float(token)) / str(int(token))"""
+    r = random.Random(5)
+    toks = list(NUMBERS[:-3])
+    for _ in range(3000):
+        m = r.choice([r.random(), r.random() * 1e6, r.random() * 1e-6, r.uniform(-1e300, 1e300), r.randint(-10**6, 10**6) / 100,
+                      r.random() * 10 ** r.randint(-30, 30)])
+        toks.append(repr(m))
+        toks.append(f"{m:.3e}")
+        toks.append(f"{m:.2f}")
+    cells = ['{"objects": [], "v": [' + ", ".join(toks[i:i + 50]) + "]}" for i in range(0, len(toks), 50)]
+    scan = nj.scan_polygons(cells)
+    assert (scan.status == nj.OK).all()
+    out = scan.emit(np.zeros((0, 4), np.int32))
+    for cell, got in zip(cells, out):
+        assert got == json.dumps(json.loads(cell), ensure_ascii=False)
