@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the drop-in STEP FUNCTIONS (CSV in -> CSV out and DataFrame in -> DataFrame
+out) against the CPU port of the reference, on the same synthetic table.  Region (2) and (3) of
+SURVEY §8d: includes read_csv / flatten / H2D / kernels / D2H / emit / to_csv, so it is host-bound.
+
+    python tools/step_bench.py --rows 20000
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=20000)
+    ap.add_argument("--skip-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import pandas as pd
+    from deal_yolo_daya_amd import _native, synth
+    from deal_yolo_daya_amd.core import processor as P
+    from oracle import steps as osteps
+
+    _native.lib()
+    t = synth.generate(args.rows, seed=synth.SEED)
+    df = synth.to_frame(t)
+    out = {"rows": args.rows, "host_cores": os.cpu_count(), "device": _native.device_name()}
+
+    def clock(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        return time.perf_counter() - t0, r
+
+    with tempfile.TemporaryDirectory() as d:
+        Q = lambda n: os.path.join(d, n)  # noqa: E731
+        df.to_csv(Q("in.csv"), index=False, encoding="utf-8-sig")
+        out["input_csv_MB"] = round(os.path.getsize(Q("in.csv")) / 1e6, 1)
+
+        # ---- product, path level -------------------------------------------------------------------
+        for mode in ("1", "0"):
+            os.environ["DYD_NATIVE_JSON"] = mode
+            tag = "native_json" if mode == "1" else "cpython_json"
+            P.process_csv_replace_ptlist(Q("in.csv"), Q("w.csv"), Q("we.csv"))          # warm-up (page cache, HIP init)
+            s1, _ = clock(lambda: P.process_csv_replace_ptlist(Q("in.csv"), Q(f"p_{tag}.csv"), Q(f"e_{tag}.csv")))
+            s2, _ = clock(lambda: P.filter_by_box_count_and_iou(Q(f"p_{tag}.csv"), Q(f"h_{tag}.csv"), Q(f"o_{tag}.csv"), 2, 0.98))
+            out[f"product_path_{tag}"] = {"replace_s": round(s1, 3), "iou_s": round(s2, 3),
+                                          "rows_per_s": round(args.rows / (s1 + s2))}
+        os.environ["DYD_NATIVE_JSON"] = "1"
+        # ---- product, frame level + breakdown ---------------------------------------------------------
+        s_read, df_in = clock(lambda: pd.read_csv(Q("in.csv"), encoding="utf-8-sig"))
+        stats = {}
+        s1, (kept, _) = clock(lambda: P.replace_ptlist_frame(df_in, None, stats))
+        s2, (hi, lo) = clock(lambda: P.iou_filter_frame(kept, 2, 0.98))
+        s_write, _ = clock(lambda: kept[["source", P.ANNOTATION_COL, P.BBOX_COL, "width", "height"]].to_csv(
+            Q("x.csv"), index=False, encoding="utf-8-sig"))
+        out["product_frame_native_json"] = {"replace_s": round(s1, 3), "iou_s": round(s2, 3),
+                                            "rows_per_s": round(args.rows / (s1 + s2)), "python_cells": stats["python_cells"],
+                                            "pandas_read_csv_s": round(s_read, 3), "pandas_to_csv_s": round(s_write, 3)}
+        # pieces of the replace step
+        cells = df_in[P.ANNOTATION_COL].tolist()
+        from deal_yolo_daya_amd import native_json as nj
+        a, scan = clock(lambda: nj.scan_polygons(cells))
+        b, (_, arg4) = clock(lambda: _native.bbox_minmax(scan.xy, scan.pt_off))
+        c, texts = clock(lambda: scan.emit(arg4))
+        out["replace_breakdown_s"] = {"native_scan(incl. join+encode)": round(a, 3), "K1 host-pointer call (H2D+kernel+D2H)": round(b, 3),
+                                      "K1 kernel_ms": round(_native.last_kernel_ms(), 3), "native_emit(incl. str objects)": round(c, 3)}
+        # ---- CPU port of the reference, path level ------------------------------------------------------
+        if not args.skip_cpu:
+            s1, _ = clock(lambda: osteps.replace_csv(Q("in.csv"), Q("rp.csv"), Q("re.csv")))
+            s2, _ = clock(lambda: osteps.iou_filter_csv(Q("rp.csv"), Q("rh.csv"), Q("ro.csv"), 2, 0.98))
+            out["cpu_port_path"] = {"replace_s": round(s1, 3), "iou_s": round(s2, 3), "rows_per_s": round(args.rows / (s1 + s2))}
+            same = all(open(Q(a), "rb").read() == open(Q(b), "rb").read()
+                       for a, b in (("rp.csv", "p_native_json.csv"), ("rh.csv", "h_native_json.csv"), ("ro.csv", "o_native_json.csv"),
+                                    ("rp.csv", "p_cpython_json.csv")))
+            out["outputs_byte_identical_to_cpu_port"] = same
+    print(json.dumps(out, ensure_ascii=False))
+
+
+if __name__ == "__main__":
+    main()
