@@ -54,7 +54,7 @@ if os.path.exists(bj):
     bench = json.load(open(bj))
     cfg = bench["config"]
     fused = cfg.get("launch", "").startswith("fused")
-    key = next((k for k in summary if ("k12_fused_kernel" in k) == fused and ("k12_fused" in k or "k1_bbox_lds" in k)), None)
+    key = next((k for k in summary if ("k12_" in k) == fused and ("k12_" in k or "k1_bbox_lds" in k)), None)
     t = summary.get(key, {}).get("hbm_traffic_bytes_per_launch") if key else None
     if t:
         with open(os.path.join(prof, "k1_traffic.json"), "w") as fh:
