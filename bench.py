@@ -88,15 +88,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (one-GPU box): DYD_BENCH_DEVICE pins every rank to one card, DYD_BENCH_BACKEND=gloo
+    # avoids RCCL's one-rank-per-GPU rule; the driver's real runs leave both unset (RCCL, rank = GPU)
+    dev_index = int(os.environ.get("DYD_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DYD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from deal_yolo_daya_amd import _native, synth
     L = _native.load_library()
-    _native.check(L.dyd_init(local_rank), "dyd_init")
+    _native.check(L.dyd_init(dev_index), "dyd_init")
     L = _native.lib()
 
     rows, bpr, desc = WORKLOADS[args.workload]
@@ -221,7 +228,7 @@ def main():
                        "k1_ms": k1_ms, "k2_ms": k2_ms,
                        "k2_gbs": (k2_bytes / (k2_ms * 1e-3) / 1e9) if k2_ms else None,
                        "device": _native.device_name()},
-            "roofline": {"bound": "hbm", "kernel": "k1_bbox_lds" if not args.fused else "k12_fused_kernel",
+            "roofline": {"bound": "hbm", "kernel": "k1_bbox_lds" if not args.fused else "k12_wave_kernel (fused K1+K2)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes,
