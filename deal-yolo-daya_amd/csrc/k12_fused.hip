@@ -19,21 +19,23 @@
 // the VALU-bound part hides under the HBM-bound part.
 // Algorithmic bytes per launch: 16*P + 4*(B+1) + 48*B + 4*(N+1) + N.
 #include <cstring>
+#include <type_traits>
 
 #include "k12_wave.h"
+#include "k2_filter.h"
 
 namespace dyd {
 
 // CHUNK = K1 point-chunk size, (WROWS, WCAP) = K2 per-wave tile.  The two phases alias one LDS
 // buffer, so its size — and the number of workgroups a CU can hold — is the larger of the two.
-template <int CHUNK, int WROWS, int WCAP>
+template <int CHUNK, int WROWS, int WCAP, bool FILTER = false>
 __global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__restrict__ xy,
                                                              const int32_t *__restrict__ pt_off,
                                                              const int32_t *__restrict__ box_off, int64_t n_rows,
                                                              int32_t min_boxes, double thr, double *out_box4,
                                                              int32_t *__restrict__ out_arg4,
                                                              uint8_t *__restrict__ out_high) {
-    using Slice = WaveLdsT<WROWS, WCAP>;
+    using Slice = typename std::conditional<FILTER, WaveLdsF<WROWS, WCAP>, WaveLdsT<WROWS, WCAP>>::type;
     constexpr size_t kLds = sizeof(double2) * CHUNK > sizeof(Slice) * K2_WAVES ? sizeof(double2) * CHUNK
                                                                               : sizeof(Slice) * K2_WAVES;
     constexpr int kRows = K2_WAVES * WROWS;
@@ -53,7 +55,10 @@ __global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__re
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
     Slice *S = reinterpret_cast<Slice *>(s_raw);
-    k2_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
+    if constexpr (FILTER)
+        k2f_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
+    else
+        k2_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
 }
 
 // wave-autonomous variant: boxes go from K1 to K2 through LDS, no workgroup barrier (k12_wave.h)
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k12_wave_kernel(const double2 *__res
     k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave]);
 }
 
-template <int CHUNK, int WROWS, int WCAP>
+template <int CHUNK, int WROWS, int WCAP, bool FILTER = false>
 static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
                         int32_t min_boxes, double thr, double *out_box4, int32_t *out_arg4, uint8_t *out_high,
                         hipStream_t st) {
@@ -80,7 +85,7 @@ static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
         return DYD_ERR_RANGE;
     }
-    hipLaunchKernelGGL((k12_fused_kernel<CHUNK, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K1_BLOCK), 0, st,
+    hipLaunchKernelGGL((k12_fused_kernel<CHUNK, WROWS, WCAP, FILTER>), dim3((unsigned)blocks), dim3(K1_BLOCK), 0, st,
                        reinterpret_cast<const double2 *>(xy), pt_off, box_off, n_rows, min_boxes, thr, out_box4,
                        out_arg4, out_high);
     DYD_HIP(hipGetLastError());
@@ -95,7 +100,8 @@ void set_k1_variant(int v);
 void set_k2_variant(int v);
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
-// 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off)
+// 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off),
+// 5 / 6 = variants 0 / 2 with the f32 reject filter in K2 (k2_filter.h)
 static int g_fused_variant = -1;
 
 }  // namespace dyd
@@ -122,8 +128,8 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     }
     int v = g_fused_variant;
     // sparse rows (<= 24 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
-    // handed to K2 through LDS); dense rows: 256-box wave tiles
-    if (v < 0) v = (n_boxes <= 24 * n_rows) ? 4 : 0;
+    // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
+    if (v < 0) v = (n_boxes <= 24 * n_rows) ? 4 : 6;
     if (v == 4) {
         const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * KW_ROWS);
         if (blocks > 0x7fffffffLL) {
@@ -136,6 +142,10 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         DYD_HIP(hipGetLastError());
         return DYD_OK;
     }
+    if (v == 5)
+        return launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    if (v == 6)
+        return launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
     if (v == 2)
         return launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
     if (v == 3)

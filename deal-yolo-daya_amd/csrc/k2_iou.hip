@@ -26,7 +26,7 @@
 // Arithmetic is f64 in the reference's operation order, built with -ffp-contract=off; the IEEE
 // division is only executed when a conservative bound (inter < 0.999*thr*union) cannot already
 // rule the pair out.
-#include "k2_wave.h"
+#include "k2_filter.h"
 
 namespace dyd {
 
@@ -42,6 +42,39 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_iou_kernel(const double *__restri
     if (r0 >= n_rows) return;  // whole wave leaves; no workgroup barrier exists in this kernel
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
     k2_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave]);
+}
+
+// the same kernel with the f32 reject filter in front of the exact test (k2_filter.h)
+template <bool WANT_MAX, int WROWS, int WCAP>
+__global__ __launch_bounds__(K2_BLOCK) void k2f_iou_kernel(const double *__restrict__ box4,
+                                                           const int32_t *__restrict__ row_off,
+                                                           int64_t n_rows, int32_t min_boxes, double thr,
+                                                           uint8_t *__restrict__ out_high,
+                                                           double *__restrict__ out_max) {
+    __shared__ WaveLdsF<WROWS, WCAP> s_all[K2_WAVES];
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * WROWS;
+    if (r0 >= n_rows) return;
+    const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
+    k2f_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave]);
+}
+
+template <int WROWS, int WCAP>
+static int launch_k2f_t(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
+                        uint8_t *out_high, double *out_max, hipStream_t st) {
+    const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
+    if (blocks > 0x7fffffffLL) {
+        set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
+        return DYD_ERR_RANGE;
+    }
+    if (out_max)
+        hipLaunchKernelGGL((k2f_iou_kernel<true, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
+                           row_off, n_rows, min_boxes, thr, out_high, out_max);
+    else
+        hipLaunchKernelGGL((k2f_iou_kernel<false, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
+                           row_off, n_rows, min_boxes, thr, out_high, out_max);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
 }
 
 template <int WROWS, int WCAP>
@@ -62,15 +95,19 @@ static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_row
     return DYD_OK;
 }
 
-// tile variant: 0 = 16 rows / 256 boxes per wave (16 waves per CU), 1 = 8 rows / 128 boxes (32 waves per CU)
-static int g_k2_variant = 0;
+// tile variant: 0 = 16 rows / 256 boxes per wave (16 waves per CU), 1 = 8 rows / 128 boxes (32 waves per CU),
+// 2 / 3 = the same two tilings with the f32 reject filter (k2_filter.h)
+static int g_k2_variant = 3;  // default: 8-row tiles + f32 reject filter (best on dense rows, on par on sparse ones)
 void set_k2_variant(int v) { g_k2_variant = v; }
 
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
               uint8_t *out_high, double *out_max, hipStream_t st) {
     if (n_rows == 0) return DYD_OK;
+    if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
     if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
-    return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
+    if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
+    if (g_k2_variant == 3) return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
+    return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
 }
 
 }  // namespace dyd

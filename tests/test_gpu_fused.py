@@ -30,7 +30,7 @@ def _table(rng, n_rows, max_boxes, max_pts, special):
                                                               (65, 32, 12, True), (3000, 32, 12, True),
                                                               (700, 90, 30, False), (50, 300, 6, False),
                                                               (20, 4, 900, True)])
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, variant):
     import torch
 
@@ -87,19 +87,51 @@ def test_dev_entry_points_on_a_side_stream(native):
     assert np.array_equal(t_high.cpu().numpy(), olib.iou_any_ge(obox, box_off, 2, 0.9))
 
 
-@pytest.mark.parametrize("n_rows,max_boxes,fixed", [(500, 32, None), (40, None, 256), (3, None, 1500)])
-def test_k2_small_tile_variant(native, n_rows, max_boxes, fixed):
-    """K2 with 8-row / 128-box wave tiles (rows above 128 boxes take the streaming path)."""
+@pytest.mark.parametrize("n_rows,max_boxes,fixed", [(500, 32, None), (2000, 60, None), (40, None, 256), (3, None, 1500),
+                                                    (2, None, 700)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("special", [True, False])
+def test_k2_variants(native, n_rows, max_boxes, fixed, variant, special):
+    """K2 tile variants: 1 = 8-row / 128-box wave tiles, 2 / 3 = the f32 reject filter in front of the
+    exact test (16 / 8-row tiles).  Rows above the tile capacity take the streaming path."""
     from helpers import random_boxes
-    rng = np.random.default_rng(n_rows)
-    box, off = random_boxes(rng, n_rows, max_boxes or 1, fixed=fixed)
+    rng = np.random.default_rng(n_rows + (fixed or 0))
+    box, off = random_boxes(rng, n_rows, max_boxes or 1, fixed=fixed, special=special)
+    if not special:      # big coordinates: the outward f32 rounding matters (f32 has 24 bits)
+        box = box * 4096.0 + 0.123456789
     L = native.lib()
-    native.check(L.dyd_set_option(b"k2_variant", 1), "opt")
+    native.check(L.dyd_set_option(b"k2_variant", variant), "opt")
     try:
-        got = native.iou_any_ge(box, off, 2, 0.98)
+        res = {(mb, thr): native.iou_any_ge(box, off, mb, thr) for mb, thr in ((2, 0.98), (3, 0.5), (2, 0.0), (2, 1.0))}
         gmx = native.iou_any_ge(box, off, 2, 0.5, want_max=True)
     finally:
-        native.check(L.dyd_set_option(b"k2_variant", 0), "opt")
-    assert np.array_equal(got, olib.iou_any_ge(box, off, 2, 0.98))
+        native.check(L.dyd_set_option(b"k2_variant", 3), "opt")
+    for (mb, thr), got in res.items():
+        assert np.array_equal(got, olib.iou_any_ge(box, off, mb, thr)), (mb, thr)
     wmx = olib.iou_any_ge(box, off, 2, 0.5, want_max=True)
     assert np.array_equal(gmx[0], wmx[0]) and np.array_equal(gmx[1].view(np.uint64), wmx[1].view(np.uint64))
+
+
+def test_k2_filter_is_conservative_at_f32_resolution(native):
+    """boxes that overlap by less than one f32 ulp: the filter must keep them and the exact test decide"""
+    L = native.lib()
+    base = 16777216.0                                     # 2^24: f32 spacing is 2 here, f64 sees 1e-9
+    rows = []
+    for eps in (1e-9, 1e-6, 0.5, 1.0, 2.0, -1e-9, 0.0):
+        a = [base, base, base + 10.0, base + 10.0]
+        b = [base + 10.0 - eps, base, base + 20.0, base + 10.0]       # overlaps a by `eps` in x
+        c = list(a)                                                    # exact duplicate of a -> IoU 1
+        rows.append(np.array([a, b], np.float64))
+        rows.append(np.array([a, b, c], np.float64))
+    box = np.concatenate(rows)
+    off = np.zeros(len(rows) + 1, np.int32)
+    np.cumsum([len(r) for r in rows], out=off[1:])
+    for variant in (0, 2, 3):
+        native.check(L.dyd_set_option(b"k2_variant", variant), "opt")
+        try:
+            for thr in (1e-12, 0.5, 0.98):
+                assert np.array_equal(native.iou_any_ge(box, off, 2, thr), olib.iou_any_ge(box, off, 2, thr)), (variant, thr)
+            g = native.iou_any_ge(box, off, 2, 0.5, want_max=True)[1]
+        finally:
+            native.check(L.dyd_set_option(b"k2_variant", 3), "opt")
+        assert np.array_equal(g.view(np.uint64), olib.iou_any_ge(box, off, 2, 0.5, want_max=True)[1].view(np.uint64))

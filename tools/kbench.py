@@ -96,13 +96,14 @@ def main():
         k2_bytes = 32 * B + 4 * (N + 1) + N
         nb64 = nbox.to(torch.int64)
         pairs = int((nb64 * (nb64 - 1) // 2).sum().item())
-        for variant, nm in ((0, "k2_iou<16,256>"), (1, "k2_iou<8,128>")):
+        for variant, nm in ((0, "k2_iou<16,256>"), (1, "k2_iou<8,128>"), (2, "k2f_iou<16,256> (f32 filter)"),
+                            (3, "k2f_iou<8,128> (f32 filter)")):
             ck(L.dyd_set_option(b"k2_variant", variant), "opt")
             med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, 2, 0.98,
                                                               out_high.data_ptr(), None, sp), "k2"))
             report(nm, k2_bytes, med, mn, rows_per_s=round(N / med * 1e3), pairs=pairs,
                    gpairs_per_s=round(pairs / med / 1e6, 2), high=int(out_high.sum().item()))
-        ck(L.dyd_set_option(b"k2_variant", 0), "opt")
+        ck(L.dyd_set_option(b"k2_variant", 3), "opt")
         mx = torch.empty(N, dtype=torch.float64, device=dev)
         med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, 2, 0.98,
                                                           out_high.data_ptr(), mx.data_ptr(), sp), "k2max"))
@@ -112,7 +113,7 @@ def main():
         k12_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N
         res = {}
         for rnd in range(2):
-            for variant in (0, 1, 2, 3, 4):
+            for variant in (0, 1, 2, 3, 4, 5, 6):
                 ck(L.dyd_set_option(b"fused_variant", variant), "opt")
                 med, mn = timeit(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(),
                                                                       N, B, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
@@ -120,7 +121,8 @@ def main():
                 res.setdefault(variant, []).append((med, mn))
         ck(L.dyd_set_option(b"fused_variant", -1), "opt")
         for variant, name in ((0, "k12_fused<2048,16,256>"), (2, "k12_fused<1024,8,128>"), (3, "k12_fused<1024,16,256>"),
-                              (4, "k12_wave_kernel"), (1, "k1_then_k2_two_launches")):
+                              (4, "k12_wave_kernel"), (5, "k12_fused<2048,16,256,filter>"), (6, "k12_fused<1024,8,128,filter>"),
+                              (1, "k1_then_k2_two_launches")):
             med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
             report(name, k12_bytes, med, mn, rows_per_s=round(N / med * 1e3), high=int(out_high.sum().item()))
 
