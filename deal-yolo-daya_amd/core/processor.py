@@ -34,7 +34,8 @@ from .utils import _parse_data_objects, _split_label_cell, _split_object_labels,
 
 ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference processor.py:244
 BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
-_CHUNK_CELLS = 1 << 18                               # cells flattened per device batch
+_CHUNK_CELLS = 1 << 18                               # cells flattened per device batch (Python path)
+_NATIVE_CHUNK_CELLS = 1 << 21                        # cells per native scan (2M rows ~ 0.26 G points at 124 pts/row)
 
 
 # =============================================================================== a1  dedup
@@ -183,48 +184,56 @@ def _replace_cells_python(cells, be, totals) -> tuple:
     return texts, widths, heights
 
 
+def _replace_cells_native(cells, be, totals):
+    """one native scan -> K1 -> native emit pass over `cells` (see replace_ptlist_cells)"""
+    try:
+        scan = _nj.scan_polygons(cells)
+    except UnicodeEncodeError:                         # a lone surrogate somewhere: CPython path for the batch
+        totals["python_cells"] += len(cells)
+        return _replace_cells_python(cells, be, totals)
+    irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+    totals["python_cells"] += int(len(irregular))
+    # irregular cells first: they are the only ones that can raise, and they must raise before any output
+    py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
+    if scan.n_boxes:
+        _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
+    else:
+        arg4 = np.zeros((0, 4), np.int32)
+    texts = scan.emit(arg4)
+    widths, heights = scan.width_height(0), scan.width_height(1)
+    for col, key in ((widths, "width"), (heights, "height")):   # rare value kinds (str / container / huge int): ask CPython
+        for i, v in enumerate(col):
+            if v is Ellipsis:
+                col[i] = json.loads(cells[i]).get(key)
+    for j, i in enumerate(irregular.tolist()):
+        texts[i], widths[i], heights[i] = py[0][j], py[1][j], py[2][j]
+    totals["boxes"] += scan.n_boxes
+    totals["points"] += int(scan.xy.shape[0])
+    scan.close()
+    return texts, widths, heights
+
+
 def replace_ptlist_cells(cells, backend=None, stats: Optional[dict] = None) -> tuple:
     """(new JSON text or None, width, height) per annotation cell: flatten -> K1 -> emit.
 
     Flatten / emit run in the native scanner (csrc/host_json.cpp) for regular cells; the cells it
     classifies as irregular go through flatten.py in row order, so the first exception the reference
-    would raise is the one raised here."""
+    would raise is the one raised here.  Cells are processed in batches of _NATIVE_CHUNK_CELLS so that
+    one batch stays far below the 2^31-point limit of the int32 offsets."""
     be = _backend(backend)
     cells = list(cells)
     totals = {"cells": len(cells), "boxes": 0, "points": 0, "host_boxes": 0, "python_cells": 0}
-    scan = None
-    if _nj.enabled() and cells:
-        try:
-            scan = _nj.scan_polygons(cells)
-        except UnicodeEncodeError:                     # a lone surrogate somewhere: CPython path for the batch
-            scan = None
-    if scan is None:
-        totals["python_cells"] = len(cells)
-        out = _replace_cells_python(cells, be, totals)
+    texts, widths, heights = [], [], []
+    if _nj.enabled():
+        for start in range(0, len(cells), _NATIVE_CHUNK_CELLS):
+            t, w, h = _replace_cells_native(cells[start:start + _NATIVE_CHUNK_CELLS], be, totals)
+            texts.extend(t); widths.extend(w); heights.extend(h)
     else:
-        irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
-        totals["python_cells"] = int(len(irregular))
-        # irregular cells first: they are the only ones that can raise, and they must raise before any output
-        py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
-        if scan.n_boxes:
-            _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
-        else:
-            arg4 = np.zeros((0, 4), np.int32)
-        texts = scan.emit(arg4)
-        widths, heights = scan.width_height(0), scan.width_height(1)
-        for col in (widths, heights):                  # rare value kinds (str / container / huge int): ask CPython
-            for i, v in enumerate(col):
-                if v is Ellipsis:
-                    col[i] = json.loads(cells[i]).get("width" if col is widths else "height")
-        for j, i in enumerate(irregular.tolist()):
-            texts[i], widths[i], heights[i] = py[0][j], py[1][j], py[2][j]
-        totals["boxes"] += scan.n_boxes
-        totals["points"] += int(scan.xy.shape[0])
-        out = (texts, widths, heights)
-        scan.close()
+        totals["python_cells"] = len(cells)
+        texts, widths, heights = _replace_cells_python(cells, be, totals)
     if stats is not None:
         stats.update(totals)
-    return out
+    return texts, widths, heights
 
 
 def replace_ptlist_frame(df: pd.DataFrame, backend=None, stats: Optional[dict] = None):
@@ -287,31 +296,37 @@ def _iou_mask_python(cells, min_boxes, iou_threshold, be, totals) -> np.ndarray:
     return out
 
 
+def _iou_mask_native(cells, min_boxes, iou_threshold, be, totals) -> np.ndarray:
+    try:
+        scan = _nj.scan_boxes(cells)
+    except UnicodeEncodeError:
+        totals["python_cells"] += len(cells)
+        return _iou_mask_python(cells, min_boxes, iou_threshold, be, totals)
+    irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+    totals["python_cells"] += int(len(irregular))
+    py = (_iou_mask_python([cells[i] for i in irregular.tolist()], min_boxes, iou_threshold, be, totals)
+          if len(irregular) else np.zeros(0, bool))
+    out = be.iou_any_ge(scan.box4, scan.row_off, min_boxes, iou_threshold).astype(bool)
+    out[irregular] = py
+    totals["boxes"] += int(scan.row_off[-1])
+    scan.close()
+    return out
+
+
 def iou_high_mask(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
                   stats: Optional[dict] = None) -> np.ndarray:
     """HIGH flag per bbox-JSON cell (:392-398): flatten -> K2 (native scanner for regular cells,
-    flatten.py for the irregular ones)."""
+    flatten.py for the irregular ones), in batches of _NATIVE_CHUNK_CELLS cells."""
     be = _backend(backend)
     cells = list(cells)
     totals = {"rows": len(cells), "boxes": 0, "host_rows": 0, "python_cells": 0}
-    scan = None
-    if _nj.enabled() and cells:
-        try:
-            scan = _nj.scan_boxes(cells)
-        except UnicodeEncodeError:
-            scan = None
-    if scan is None:
+    if _nj.enabled():
+        parts = [_iou_mask_native(cells[s:s + _NATIVE_CHUNK_CELLS], min_boxes, iou_threshold, be, totals)
+                 for s in range(0, len(cells), _NATIVE_CHUNK_CELLS)]
+        out = np.concatenate(parts) if parts else np.zeros(0, bool)
+    else:
         totals["python_cells"] = len(cells)
         out = _iou_mask_python(cells, min_boxes, iou_threshold, be, totals)
-    else:
-        irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
-        totals["python_cells"] = int(len(irregular))
-        py = (_iou_mask_python([cells[i] for i in irregular.tolist()], min_boxes, iou_threshold, be, totals)
-              if len(irregular) else np.zeros(0, bool))
-        out = be.iou_any_ge(scan.box4, scan.row_off, min_boxes, iou_threshold).astype(bool)
-        out[irregular] = py
-        totals["boxes"] += int(scan.row_off[-1])
-        scan.close()
     if stats is not None:
         stats.update(totals)
     return out

@@ -216,6 +216,21 @@ def test_batch_order_and_mixed_cells(oracle_backend):
     assert scan.status[-3:].tolist() == [nj.MISSING] * 3
 
 
+def test_native_batches_are_stitched_in_order(oracle_backend, monkeypatch):
+    """small native batches (as used above 2M cells) give the same per-cell results in the same order"""
+    g = load_golden("replace_cases.json")
+    cells = [c["in"] for c in g["value_cases"].values()] * 3 + [None]
+    whole = P.replace_ptlist_cells(cells, oracle_backend)
+    kept_new = [t for t in whole[0]]
+    mask_whole = P.iou_high_mask(kept_new, 2, 0.5, oracle_backend)
+    monkeypatch.setattr(P, "_NATIVE_CHUNK_CELLS", 7)
+    stats = {}
+    parts = P.replace_ptlist_cells(cells, oracle_backend, stats)
+    assert parts[0] == whole[0] and parts[1] == whole[1] and parts[2] == whole[2]
+    assert stats["cells"] == len(cells) and stats["python_cells"] > 0
+    assert np.array_equal(P.iou_high_mask(kept_new, 2, 0.5, oracle_backend), mask_whole)
+
+
 def test_python_path_switch(oracle_backend, monkeypatch):
     g = load_golden("replace_cases.json")
     cells = [c["in"] for c in g["value_cases"].values()]

@@ -8,7 +8,7 @@ rocprofv3 -L > $OUT/counters_list.txt 2>&1
 grep -c . $OUT/counters_list.txt
 run_pass() { # name counters...
   local name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --rows ${ROWS:-1000000} --only ${KB:-k2} --iters 2 > $OUT/pmc_$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --rows ${ROWS:-1000000} --only ${KB:-k2} --iters 2 ${KBARGS:-} > $OUT/pmc_$name.log 2>&1
   echo "pass $name rc=$?"
 }
 run_pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
