@@ -104,4 +104,16 @@ struct KernelTimer {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+#if defined(__HIPCC__)
+// Streaming (read-once) 16-byte load: `global_load_dwordx4 ... nt`.  Measured on MI355X with
+// k0_membench: 6.6-6.9 TB/s for nt reads against 5.4-5.8 TB/s for plain ones (1.4 GB array), but a
+// copy (reads + writes) gains only 3-7 %, K1 nothing and the fused wave kernel loses ~6 %, so the
+// kernels use plain loads; kept for experiments.
+typedef double dyd_f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_stream(const double2 *p) {
+    const dyd_f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const dyd_f64x2 *>(p));
+    return make_double2(v.x, v.y);
+}
+#endif
+
 }  // namespace dyd

@@ -17,6 +17,18 @@ __global__ __launch_bounds__(K0_BLOCK) void k0_stream(const uint4 *__restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * K0_BLOCK + threadIdx.x; i < n16; i += stride) {
         if (MODE == 0) {
             dst[i] = src[i];
+        } else if (MODE == 3) {  // copy with non-temporal loads and stores
+            const uint4 v = make_uint4(__builtin_nontemporal_load(&src[i].x), __builtin_nontemporal_load(&src[i].y),
+                                       __builtin_nontemporal_load(&src[i].z), __builtin_nontemporal_load(&src[i].w));
+            __builtin_nontemporal_store(v.x, &dst[i].x); __builtin_nontemporal_store(v.y, &dst[i].y);
+            __builtin_nontemporal_store(v.z, &dst[i].z); __builtin_nontemporal_store(v.w, &dst[i].w);
+        } else if (MODE == 4) {  // nt read only
+            const uint4 v = make_uint4(__builtin_nontemporal_load(&src[i].x), __builtin_nontemporal_load(&src[i].y),
+                                       __builtin_nontemporal_load(&src[i].z), __builtin_nontemporal_load(&src[i].w));
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        } else if (MODE == 5) {  // nt write only
+            __builtin_nontemporal_store((unsigned)i, &dst[i].x); __builtin_nontemporal_store(1u, &dst[i].y);
+            __builtin_nontemporal_store(2u, &dst[i].z); __builtin_nontemporal_store(3u, &dst[i].w);
         } else if (MODE == 1) {
             const uint4 v = src[i];
             acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
@@ -24,7 +36,7 @@ __global__ __launch_bounds__(K0_BLOCK) void k0_stream(const uint4 *__restrict__ 
             dst[i] = make_uint4((unsigned)i, 1u, 2u, 3u);
         }
     }
-    if (MODE == 1 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) dst[0] = acc;
+    if ((MODE == 1 || MODE == 4) && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) dst[0] = acc;
 }
 
 }  // namespace dyd
@@ -33,7 +45,7 @@ using namespace dyd;
 
 extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream) {
     DYD_API_ENTER();
-    DYD_REQUIRE(mode >= 0 && mode <= 2 && bytes >= 0 && dst, "bad membench arguments");
+    DYD_REQUIRE(mode >= 0 && mode <= 5 && bytes >= 0 && dst, "bad membench arguments");
     const int64_t n16 = bytes / 16;
     if (n16 == 0) return DYD_OK;
     if (blocks <= 0) blocks = ctx().num_cu * 8;
@@ -42,7 +54,10 @@ extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t by
     uint4 *d = static_cast<uint4 *>(dst);
     if (mode == 0) hipLaunchKernelGGL(k0_stream<0>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
     else if (mode == 1) hipLaunchKernelGGL(k0_stream<1>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
-    else hipLaunchKernelGGL(k0_stream<2>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    else if (mode == 2) hipLaunchKernelGGL(k0_stream<2>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    else if (mode == 3) hipLaunchKernelGGL(k0_stream<3>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    else if (mode == 4) hipLaunchKernelGGL(k0_stream<4>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+    else hipLaunchKernelGGL(k0_stream<5>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }

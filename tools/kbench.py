@@ -84,7 +84,8 @@ def main():
         nb_ = k1_bytes // 2 // 16 * 16
         src = torch.empty(nb_ // 8, dtype=torch.float64, device=dev).normal_(); dst = torch.empty_like(src)
         for blocks in (2048, 8192):
-            for mode, nm, tot in ((0, "copy", 2 * nb_), (1, "read", nb_), (2, "write", nb_)):
+            for mode, nm, tot in ((0, "copy", 2 * nb_), (1, "read", nb_), (2, "write", nb_), (3, "copy_nt", 2 * nb_),
+                                  (4, "read_nt", nb_), (5, "write_nt", nb_)):
                 med, mn = timeit(lambda: ck(L.dyd_membench_dev(mode, src.data_ptr(), dst.data_ptr(), nb_, blocks, sp), "mb"))
                 report(f"membench_{nm}_b{blocks}", tot, med, mn)
         med, mn = timeit(lambda: dst.copy_(src))
