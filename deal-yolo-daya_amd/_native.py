@@ -88,6 +88,16 @@ SIGNATURES = {
     "dyd_scan_wh_kind": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_wh_value": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_free": (None, [C.c_void_p]),
+    "dyd_csv_index": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "dyd_csv_rows": (C.c_int64, [C.c_void_p]),
+    "dyd_csv_cols": (C.c_int32, [C.c_void_p]),
+    "dyd_csv_header": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "dyd_csv_extract": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dyd_csv_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "dyd_csv_free": (None, [C.c_void_p]),
+    "dyd_csv_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "dyd_host_free": (None, [C.c_void_p]),
     "dyd_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "dyd_membench_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
 }

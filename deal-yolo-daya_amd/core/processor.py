@@ -28,6 +28,7 @@ import numpy as np
 import pandas as pd
 
 from .. import flatten as _fl
+from .. import fastcsv as _fc
 from .. import native_json as _nj
 from ..backend import resolve as _backend
 from .utils import _parse_data_objects, _split_label_cell, _split_object_labels, safe_filename
@@ -35,6 +36,7 @@ from .utils import _parse_data_objects, _split_label_cell, _split_object_labels,
 ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference processor.py:244
 BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
 _CHUNK_CELLS = 1 << 18                               # cells flattened per device batch (Python path)
+LAST_IO_PATH = {}                                    # step -> "native" | "pandas": which CSV path the last call took
 _NATIVE_CHUNK_CELLS = 1 << 21                        # cells per native scan (2M rows ~ 0.26 G points at 124 pts/row)
 
 
@@ -247,15 +249,98 @@ def replace_ptlist_frame(df: pd.DataFrame, backend=None, stats: Optional[dict] =
     return kept, excluded
 
 
+_LATE_FALLBACK = object()
+
+
+def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, backend):
+    """CSV -> CSV replace step without pandas touching the annotation column (fastcsv + native JSON).
+    Returns NotImplemented whenever the fast path does not apply; nothing has been written then."""
+    try:
+        table = _fc.read_split(str(input_csv_path), [ANNOTATION_COL])
+    except (OSError, ValueError, pd.errors.ParserError, UnicodeDecodeError):
+        return NotImplemented
+    if table is None or ANNOTATION_COL not in table.heavy:
+        return NotImplemented
+    be = _backend(backend)
+    ann = table.heavy[ANNOTATION_COL]
+    print(f"成功读取CSV，共 {table.n_rows} 行数据")
+    kept_rows = np.flatnonzero(ann.na == 0)
+    excluded_rows = np.flatnonzero(ann.na != 0)
+    scan = _nj.scan_polygons_buffers(ann.data, ann.off, ann.na)
+    totals = {"boxes": 0, "points": 0, "host_boxes": 0, "python_cells": 0}
+    irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+    py = (_replace_cells_python(ann.cells(irregular), be, totals) if len(irregular) else ([], [], []))   # may raise, like the reference
+    if scan.n_boxes:
+        _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
+    else:
+        arg4 = np.zeros((0, 4), np.int32)
+    text, off = scan.emit_buffers(arg4)
+    widths, heights = scan.width_height(0), scan.width_height(1)
+    for col, key in ((widths, "width"), (heights, "height")):
+        for i, v in enumerate(col):
+            if v is Ellipsis:
+                col[i] = json.loads(ann.cell(i)).get(key)
+    new_na = (scan.status != _nj.OK).astype(np.uint8)
+    if len(irregular):                                   # splice the Python-path results into the column
+        cells = [None] * table.n_rows
+        ok_rows = np.flatnonzero(scan.status == _nj.OK)
+        raw = bytes(text)
+        for i in ok_rows.tolist():
+            cells[i] = raw[off[i]:off[i + 1]].decode("utf-8")
+        for j, i in enumerate(irregular.tolist()):
+            cells[i], widths[i], heights[i] = py[0][j], py[1][j], py[2][j]
+        spec = _fc._series_column(pd.Series(cells, dtype=object))
+        new_col = _fc.Utf8Column(spec[1], spec[2], spec[3])
+    else:
+        new_col = _fc.Utf8Column(text, off, new_na, scan)
+    kw = pd.Series([widths[i] for i in kept_rows.tolist()])     # dtype inference of `kept["width"] = list` (:295)
+    kh = pd.Series([heights[i] for i in kept_rows.tolist()])
+    full_w = pd.Series(np.full(table.n_rows, np.nan, dtype=object) if kw.dtype == object else np.zeros(table.n_rows, kw.dtype))
+    full_h = pd.Series(np.full(table.n_rows, np.nan, dtype=object) if kh.dtype == object else np.zeros(table.n_rows, kh.dtype))
+    full_w.iloc[kept_rows] = kw.to_numpy()
+    full_h.iloc[kept_rows] = kh.to_numpy()
+    names, columns = [], []
+    if "source" in table.light.columns:
+        names.append("source"); columns.append(table.light["source"])
+    names += [ANNOTATION_COL, BBOX_COL]
+    columns += [ann, new_col]
+    names += ["width", "height"]
+    columns += [full_w, full_h]
+    if not _fc.write_table(str(output_csv_path), names, columns, table.n_rows, rows=kept_rows):
+        scan.close()
+        return _LATE_FALLBACK                              # the row count was already printed
+    scan.close()
+    if excluded_output_file is not None:
+        excluded = table.light.iloc[excluded_rows].copy()
+        excluded.insert(table.names.index(ANNOTATION_COL), ANNOTATION_COL, np.nan)
+        Path(excluded_output_file).parent.mkdir(parents=True, exist_ok=True)
+        excluded[table.names].to_csv(excluded_output_file, index=False, encoding="utf-8-sig")
+    return {
+        "filtered_rows": int(len(kept_rows)),
+        "excluded_rows": int(len(excluded_rows)),
+        "excluded_output": excluded_output_file,
+    }
+
+
 def process_csv_replace_ptlist(
         input_csv_path: str,
         output_csv_path: str = "processed_replaced_ptlist.csv",
         excluded_output_file: Optional[str] = "processed_excluded.csv",
         backend=None,
 ):
+    announced = False
+    if _fc.enabled() and _nj.enabled() and os.path.isfile(str(input_csv_path)):
+        res = _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, backend)
+        if res is _LATE_FALLBACK:
+            announced = True
+        elif res is not NotImplemented:
+            LAST_IO_PATH["replace"] = "native"
+            return res
+    LAST_IO_PATH["replace"] = "pandas"
     try:
         df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
-        print(f"成功读取CSV，共 {len(df)} 行数据")
+        if not announced:
+            print(f"成功读取CSV，共 {len(df)} 行数据")
     except FileNotFoundError:
         print(f"错误：未找到文件 {input_csv_path}")
         return None
@@ -339,6 +424,31 @@ def iou_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold: float 
     return df[mask], df[~mask]
 
 
+def _iou_csv_fast(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold, backend):
+    """CSV -> two CSVs IoU step on flat buffers (see _replace_csv_fast)."""
+    try:
+        table = _fc.read_split(str(input_csv_path), [ANNOTATION_COL, BBOX_COL])
+    except (OSError, ValueError, pd.errors.ParserError, UnicodeDecodeError):
+        return NotImplemented
+    if table is None or BBOX_COL not in table.heavy:
+        return NotImplemented
+    be = _backend(backend)
+    col = table.heavy[BBOX_COL]
+    scan = _nj.scan_boxes_buffers(col.data, col.off, col.na)
+    totals = {"boxes": 0, "host_rows": 0, "python_cells": 0}
+    irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+    py = (_iou_mask_python(col.cells(irregular), min_boxes, iou_threshold, be, totals) if len(irregular)
+          else np.zeros(0, bool))                          # may raise, like the reference
+    mask = be.iou_any_ge(scan.box4, scan.row_off, min_boxes, iou_threshold).astype(bool)
+    mask[irregular] = py
+    scan.close()
+    columns = [table.heavy[nm] if nm in table.heavy else table.light[nm] for nm in table.names]
+    # sample-check both files before writing either, so a fallback never leaves half the output behind
+    ok = (_fc.write_table(str(high_iou_csv), table.names, columns, table.n_rows, rows=np.flatnonzero(mask))
+          and _fc.write_table(str(other_csv), table.names, columns, table.n_rows, rows=np.flatnonzero(~mask)))
+    return None if ok else NotImplemented
+
+
 def filter_by_box_count_and_iou(
         input_csv_path,
         high_iou_csv="high_iou_0.98.csv",
@@ -347,6 +457,11 @@ def filter_by_box_count_and_iou(
         iou_threshold: float = 0.98,
         backend=None,
 ):
+    if _fc.enabled() and _nj.enabled() and os.path.isfile(str(input_csv_path)):
+        if _iou_csv_fast(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold, backend) is None:
+            LAST_IO_PATH["iou"] = "native"
+            return
+    LAST_IO_PATH["iou"] = "pandas"
     try:
         df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
     except Exception as e:

@@ -1,0 +1,337 @@
+// host_csv.cpp — native CSV hand-off for the step functions (host code, no HIP).  SURVEY §8f #2.
+//
+// Between steps the reference hands tables over as CSV files (read_csv at processor.py:125, :181-182,
+// :235, :379, :678; to_csv at :158, :213, :309, :313, :404, :407); once the JSON work is native, pandas'
+// CSV reader / writer are > 85 % of a step.  Two things make those files heavy: the annotation column
+// and the bbox column (~4-5 KB per row each).  This file
+//   * indexes a CSV buffer (quote-aware tokeniser with pandas' C-parser conventions),
+//   * extracts a HEAVY column straight into the flat utf-8 + offsets form the native JSON scanner
+//     consumes (no Python str objects), with pandas' default NA strings recognised,
+//   * re-assembles the remaining LIGHT columns as a small CSV text that pandas itself parses (so dtype
+//     inference, NA handling and float parsing of those columns stay pandas' own), and
+//   * writes a table whose columns are typed buffers (utf-8 / int64 / float64 / bool) with csv.QUOTE_MINIMAL
+//     quoting and float repr, i.e. DataFrame.to_csv(index=False) byte for byte (the Python wrapper
+//     cross-checks a sample of rows against pandas before trusting it).
+// Anything unusual (ragged rows, stray quotes, bare CR line ends ...) makes the index call fail and the
+// caller falls back to pandas for that file.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dyd.h"
+
+// shared with host_json.cpp
+namespace dyd_host {
+void append_py_float_public(std::string &out, double v);
+}
+
+namespace {
+
+struct Field {
+    int64_t b, e;   // byte range inside the buffer (without the surrounding quotes)
+    uint8_t quoted; // 1: was quoted (doubled quotes inside still doubled)
+};
+
+// pandas' default NA strings (pandas/_libs/parsers.pyx STR_NA_VALUES)
+const char *const kNa[] = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN",
+                           "<NA>", "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+
+bool is_na(const char *p, size_t n) {
+    if (n > 8) return false;
+    for (const char *s : kNa)
+        if (strlen(s) == n && !memcmp(s, p, n)) return true;
+    return false;
+}
+
+}  // namespace
+
+struct dyd_csv {
+    const char *text = nullptr;
+    int64_t len = 0;
+    int64_t n_rows = 0;   // data rows (header excluded)
+    int32_t n_cols = 0;
+    std::vector<Field> header;
+    std::vector<Field> fields;  // n_rows * n_cols, row-major
+    // outputs owned by the handle
+    std::unique_ptr<uint8_t[]> col_bytes;  // not value-initialised: filled by extract
+    std::vector<int64_t> col_off;
+    std::vector<uint8_t> col_na;
+    std::string projected;
+};
+
+extern "C" {
+
+// Index a CSV buffer (utf-8, BOM already stripped by the caller).  Fails (DYD_ERR_INVALID) on anything the
+// fast path does not reproduce exactly; the caller then uses pandas.
+int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out) {
+    if (!out || (!text && len)) return DYD_ERR_INVALID;
+    dyd_csv *h = new (std::nothrow) dyd_csv();
+    if (!h) return DYD_ERR_OOM;
+    h->text = reinterpret_cast<const char *>(text);
+    h->len = len;
+    const char *p = h->text, *end = h->text + len;
+    std::vector<Field> row;
+    bool have_header = false;
+    try {
+        while (p < end) {
+            // ---- one record ---------------------------------------------------------------------
+            row.clear();
+            if (*p == '\n') { ++p; continue; }                      // blank line: skipped (skip_blank_lines)
+            if (*p == '\r') { delete h; return DYD_ERR_INVALID; }   // CR line ends: leave to pandas
+            while (true) {
+                Field f{};
+                if (p < end && *p == '"') {
+                    f.quoted = 1;
+                    f.b = ++p - h->text;
+                    while (true) {
+                        const char *q = static_cast<const char *>(memchr(p, '"', (size_t)(end - p)));
+                        if (!q) { delete h; return DYD_ERR_INVALID; }   // unterminated quote
+                        if (q + 1 < end && q[1] == '"') { p = q + 2; continue; }
+                        f.e = q - h->text;
+                        p = q + 1;
+                        break;
+                    }
+                    if (p < end && *p != ',' && *p != '\n') { delete h; return DYD_ERR_INVALID; }  // text after closing quote / CR
+                } else {
+                    f.b = p - h->text;
+                    while (p < end && *p != ',' && *p != '\n') {
+                        if (*p == '"' || *p == '\r') { delete h; return DYD_ERR_INVALID; }  // stray quote / CR
+                        ++p;
+                    }
+                    f.e = p - h->text;
+                }
+                row.push_back(f);
+                if (p < end && *p == ',') { ++p; if (p == end) { row.push_back(Field{p - h->text, p - h->text, 0}); break; } continue; }
+                if (p < end) ++p;  // '\n'
+                break;
+            }
+            if (!have_header) {
+                h->header = row;
+                h->n_cols = (int32_t)row.size();
+                have_header = true;
+            } else {
+                if ((int32_t)row.size() != h->n_cols) { delete h; return DYD_ERR_INVALID; }  // ragged
+                h->fields.insert(h->fields.end(), row.begin(), row.end());
+                ++h->n_rows;
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    if (!have_header) { delete h; return DYD_ERR_INVALID; }
+    *out = h;
+    return DYD_OK;
+}
+
+int64_t dyd_csv_rows(const dyd_csv *h) { return h->n_rows; }
+int32_t dyd_csv_cols(const dyd_csv *h) { return h->n_cols; }
+
+// header name of column c, unescaped, into buf (returns its length or -1 if it does not fit)
+int64_t dyd_csv_header(const dyd_csv *h, int32_t c, uint8_t *buf, int64_t cap) {
+    if (c < 0 || c >= h->n_cols) return -1;
+    const Field &f = h->header[(size_t)c];
+    int64_t n = 0;
+    for (int64_t i = f.b; i < f.e; ++i) {
+        if (n >= cap) return -1;
+        buf[n++] = (uint8_t)h->text[i];
+        if (f.quoted && h->text[i] == '"') ++i;  // doubled quote
+    }
+    return n;
+}
+
+// Extract column c as flat utf-8 (quotes undoubled) + offsets + NA mask (pandas default NA strings;
+// quoted cells are NA-checked too, like the C parser does).  Arrays stay owned by the handle until the
+// next extract call.
+int dyd_csv_extract(dyd_csv *h, int32_t c, const uint8_t **bytes, const int64_t **off, const uint8_t **na) {
+    if (!h || c < 0 || c >= h->n_cols) return DYD_ERR_INVALID;
+    try {
+        size_t total = 0;
+        for (int64_t r = 0; r < h->n_rows; ++r) {
+            const Field &f = h->fields[(size_t)(r * h->n_cols + c)];
+            total += (size_t)(f.e - f.b);
+        }
+        h->col_bytes.reset(new uint8_t[total + 1]);
+        h->col_off.resize((size_t)h->n_rows + 1);
+        h->col_na.resize((size_t)h->n_rows);
+        uint8_t *w = h->col_bytes.get();
+        int64_t pos = 0;
+        for (int64_t r = 0; r < h->n_rows; ++r) {
+            const Field &f = h->fields[(size_t)(r * h->n_cols + c)];
+            h->col_off[(size_t)r] = pos;
+            const char *s = h->text + f.b;
+            const int64_t n = f.e - f.b;
+            if (!f.quoted || !memchr(s, '"', (size_t)n)) {
+                memcpy(w + pos, s, (size_t)n);
+                pos += n;
+            } else {  // copy the runs between doubled quotes; every '"' inside a quoted field is half of a pair
+                const char *q = s, *e = s + n;
+                while (q < e) {
+                    const char *hit = static_cast<const char *>(memchr(q, '"', (size_t)(e - q)));
+                    if (!hit) { memcpy(w + pos, q, (size_t)(e - q)); pos += e - q; break; }
+                    memcpy(w + pos, q, (size_t)(hit - q + 1));
+                    pos += hit - q + 1;
+                    q = hit + 2;
+                }
+            }
+            const int64_t clen = pos - h->col_off[(size_t)r];
+            h->col_na[(size_t)r] = is_na(reinterpret_cast<const char *>(w) + h->col_off[(size_t)r], (size_t)clen) ? 1 : 0;
+        }
+        h->col_off[(size_t)h->n_rows] = pos;
+    } catch (const std::bad_alloc &) {
+        return DYD_ERR_OOM;
+    }
+    *bytes = h->col_bytes.get();
+    *off = h->col_off.data();
+    *na = h->col_na.data();
+    return DYD_OK;
+}
+
+// CSV text of the columns keep[0..n_keep) only (raw field text, original quoting), header included, for
+// pandas to parse.
+int dyd_csv_project(dyd_csv *h, const int32_t *keep, int32_t n_keep, const uint8_t **text, int64_t *len) {
+    if (!h || n_keep < 0 || (n_keep && !keep)) return DYD_ERR_INVALID;
+    try {
+        std::string &o = h->projected;
+        o.clear();
+        auto put = [&](const Field &f) {
+            if (f.quoted) o += '"';
+            o.append(h->text + f.b, (size_t)(f.e - f.b));
+            if (f.quoted) o += '"';
+        };
+        for (int32_t k = 0; k < n_keep; ++k) {
+            if (keep[k] < 0 || keep[k] >= h->n_cols) return DYD_ERR_INVALID;
+            if (k) o += ',';
+            put(h->header[(size_t)keep[k]]);
+        }
+        o += '\n';
+        for (int64_t r = 0; r < h->n_rows; ++r) {
+            const Field *row = &h->fields[(size_t)(r * h->n_cols)];
+            if (n_keep == 1 && row[keep[0]].b == row[keep[0]].e && !row[keep[0]].quoted) {
+                o += "\"\"\n";  // a lone empty field would read as a blank line
+                continue;
+            }
+            for (int32_t k = 0; k < n_keep; ++k) {
+                if (k) o += ',';
+                put(row[keep[k]]);
+            }
+            o += '\n';
+        }
+    } catch (const std::bad_alloc &) {
+        return DYD_ERR_OOM;
+    }
+    *text = reinterpret_cast<const uint8_t *>(h->projected.data());
+    *len = (int64_t)h->projected.size();
+    return DYD_OK;
+}
+
+void dyd_csv_free(dyd_csv *h) { delete h; }
+
+// ---- writer ---------------------------------------------------------------------------------------
+// kind 0: utf-8 strings (data = bytes, off = [n+1] offsets, na = optional mask: NA -> empty field)
+// kind 1: int64; kind 2: float64 (NaN -> empty, else repr); kind 3: bool (u8) -> True / False
+// (struct dyd_csv_col is declared in include/dyd.h)
+
+static void put_text(std::string &o, const char *s, size_t n, bool quote_cr) {
+    bool need = false;
+    for (size_t i = 0; i < n; ++i) {
+        const char c = s[i];
+        if (c == ',' || c == '"' || c == '\n' || (quote_cr && c == '\r')) { need = true; break; }
+    }
+    if (!need) { o.append(s, n); return; }
+    o += '"';
+    const char *p = s, *end = s + n;
+    while (p < end) {
+        const char *q = static_cast<const char *>(memchr(p, '"', (size_t)(end - p)));
+        if (!q) { o.append(p, (size_t)(end - p)); break; }
+        o.append(p, (size_t)(q - p + 1));
+        o += '"';
+        p = q + 1;
+    }
+    o += '"';
+}
+
+// Writes header + rows (rows[i] = source row index, or all n_rows in order when rows == NULL) to path.
+int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, const dyd_csv_col *cols, int32_t n_cols,
+                  int64_t n_rows, const int64_t *rows, int64_t n_sel, int quote_cr, int n_threads, int append_to_memory,
+                  uint8_t **mem_out, int64_t *mem_len) {
+    if (n_cols <= 0 || !cols || n_sel < 0) return DYD_ERR_INVALID;
+    const int64_t n_out = rows ? n_sel : n_rows;
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n_out / 512));
+    std::vector<std::string> parts((size_t)n_threads);
+    auto work = [&](int t) {
+        std::string &o = parts[(size_t)t];
+        const int64_t lo = n_out * t / n_threads, hi = n_out * (t + 1) / n_threads;
+        char nb[32];
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t r = rows ? rows[k] : k;
+            const size_t mark = o.size();
+            for (int32_t c = 0; c < n_cols; ++c) {
+                if (c) o += ',';
+                const dyd_csv_col &col = cols[c];
+                switch (col.kind) {
+                    case 0: {
+                        if (col.na && col.na[r]) break;
+                        const char *s = static_cast<const char *>(col.data) + col.off[r];
+                        put_text(o, s, (size_t)(col.off[r + 1] - col.off[r]), quote_cr != 0);
+                        break;
+                    }
+                    case 1:
+                        o.append(nb, (size_t)snprintf(nb, sizeof(nb), "%lld", (long long)static_cast<const int64_t *>(col.data)[r]));
+                        break;
+                    case 2: {
+                        const double v = static_cast<const double *>(col.data)[r];
+                        if (v == v) dyd_host::append_py_float_public(o, v);
+                        break;
+                    }
+                    case 3:
+                        o += static_cast<const uint8_t *>(col.data)[r] ? "True" : "False";
+                        break;
+                    default: break;
+                }
+            }
+            if (n_cols == 1 && o.size() == mark) o += "\"\"";  // csv.writer: a lone empty field is written as ""
+            o += '\n';
+        }
+    };
+    try {
+        if (n_threads <= 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+    } catch (const std::bad_alloc &) {
+        return DYD_ERR_OOM;
+    }
+    if (append_to_memory) {  // used by the Python wrapper's self-check
+        size_t total = (size_t)header_len;
+        for (auto &s : parts) total += s.size();
+        uint8_t *m = static_cast<uint8_t *>(malloc(total ? total : 1));
+        if (!m) return DYD_ERR_OOM;
+        size_t pos = 0;
+        memcpy(m, header, (size_t)header_len); pos += (size_t)header_len;
+        for (auto &s : parts) { memcpy(m + pos, s.data(), s.size()); pos += s.size(); }
+        *mem_out = m;
+        *mem_len = (int64_t)total;
+        return DYD_OK;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return DYD_ERR_INVALID;
+    bool ok = fwrite(header, 1, (size_t)header_len, f) == (size_t)header_len;
+    for (auto &s : parts) ok = ok && fwrite(s.data(), 1, s.size(), f) == s.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? DYD_OK : DYD_ERR_INVALID;
+}
+
+void dyd_host_free(void *p) { free(p); }
+
+}  // extern "C"

@@ -91,6 +91,12 @@ void append_py_float(std::string &out, double v) {
     }
 }
 
+}  // namespace
+namespace dyd_host {
+void append_py_float_public(std::string &out, double v) { append_py_float(out, v); }
+}  // namespace dyd_host
+namespace {
+
 struct Num {
     bool is_int;
     double v;       // value as double (exact for ints within 2^53)

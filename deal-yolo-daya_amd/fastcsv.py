@@ -1,0 +1,228 @@
+"""Native CSV hand-off (csrc/host_csv.cpp).
+
+``read_split`` reads a step's input CSV so that the HEAVY columns (the two annotation JSON columns)
+never become Python objects: they are returned as flat utf-8 buffers for the native JSON scanner and
+for ``write_table``; every other (light) column is parsed by pandas itself from a reduced CSV text, so
+dtype inference, NA handling and float parsing stay exactly pandas'.
+
+``write_table`` writes typed column buffers the way ``DataFrame.to_csv(index=False)`` does
+(csv.QUOTE_MINIMAL, float repr, NaN -> empty) and checks a sample of rows against pandas before it
+trusts the native writer for the whole file.
+
+Both return ``None`` / ``False`` whenever the file or the table is outside what the fast path
+reproduces exactly; the callers then take the plain pandas path.
+"""
+from __future__ import annotations
+
+import csv
+import ctypes as C
+import io
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import pandas as pd
+
+from . import _native
+
+_BOM = b"\xef\xbb\xbf"
+
+
+def enabled() -> bool:
+    return os.environ.get("DYD_NATIVE_CSV", "1") != "0"
+
+
+def _quote_cr() -> bool:
+    """does this interpreter's csv module quote a field that holds a bare CR?  (changed across versions)"""
+    s = io.StringIO()
+    csv.writer(s, lineterminator="\n").writerow(["a\rb", "c"])
+    return s.getvalue().startswith('"')
+
+
+_QUOTE_CR = _quote_cr()
+
+
+@dataclass
+class Utf8Column:
+    """one string column as flat bytes: cell i = data[off[i]:off[i+1]], na[i] != 0 -> missing"""
+    data: np.ndarray
+    off: np.ndarray
+    na: np.ndarray
+    keep: object = None        # keeps foreign memory alive
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def cell(self, i: int):
+        if self.na[i]:
+            return np.nan
+        return bytes(self.data[self.off[i]:self.off[i + 1]]).decode("utf-8")
+
+    def cells(self, rows) -> list:
+        return [self.cell(int(i)) for i in rows]
+
+
+def _view(ptr, dtype, count):
+    if count == 0 or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
+
+
+@dataclass
+class SplitTable:
+    names: list                 # all column names in file order
+    n_rows: int
+    light: pd.DataFrame         # the non-heavy columns, parsed by pandas (RangeIndex)
+    heavy: dict                 # name -> Utf8Column
+
+
+def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
+    """-> SplitTable, or None when the fast path must not be used for this file."""
+    if not enabled() or encoding.lower().replace("_", "-") not in ("utf-8-sig", "utf-8", "utf8"):
+        return None
+    L = _native.load_library()
+    with open(path, "rb") as f:
+        raw = f.read()
+    start = len(_BOM) if raw.startswith(_BOM) and "sig" in encoding.lower() else 0
+    buf = np.frombuffer(raw, dtype=np.uint8)[start:]
+    if buf.size == 0:
+        return None
+    h = C.c_void_p()
+    if L.dyd_csv_index(buf.ctypes.data, buf.size, C.byref(h)) != 0:
+        return None
+    try:
+        n_rows, n_cols = int(L.dyd_csv_rows(h)), int(L.dyd_csv_cols(h))
+        names = []
+        tmp = np.empty(4096, np.uint8)
+        for c in range(n_cols):
+            n = L.dyd_csv_header(h, c, tmp.ctypes.data, tmp.size)
+            if n < 0:
+                return None
+            names.append(bytes(tmp[:n]).decode("utf-8"))
+        if len(set(names)) != len(names) or any(nm == "" or nm.startswith("Unnamed") for nm in names):
+            return None                                  # pandas renames such columns: leave it to pandas
+        heavy = {}
+        for nm in heavy_names:
+            if nm not in names:
+                continue
+            pb, po, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            if L.dyd_csv_extract(h, names.index(nm), C.byref(pb), C.byref(po), C.byref(pn)) != 0:
+                return None
+            off = _view(po.value, np.int64, n_rows + 1).copy()
+            data = _view(pb.value, np.uint8, int(off[-1]) + 1).copy()
+            na = _view(pn.value, np.uint8, n_rows).copy()
+            # pandas would infer a non-object dtype if every present cell looked numeric / boolean: only a
+            # column with at least one JSON-looking cell is certainly an object column of str
+            starts = off[:-1][na == 0]
+            if len(starts) == 0 or not np.isin(data[starts], np.frombuffer(b'{["', np.uint8)).any():
+                return None
+            heavy[nm] = Utf8Column(data, off, na)
+        light_idx = [i for i, nm in enumerate(names) if nm not in heavy]
+        if light_idx:
+            keep = np.asarray(light_idx, np.int32)
+            pt, ln = C.c_void_p(), C.c_int64()
+            if L.dyd_csv_project(h, keep.ctypes.data, len(keep), C.byref(pt), C.byref(ln)) != 0:
+                return None
+            text = bytes(_view(pt.value, np.uint8, ln.value))
+            light = pd.read_csv(io.BytesIO(text), encoding="utf-8")
+            if len(light) != n_rows or list(light.columns) != [names[i] for i in light_idx]:
+                return None
+        else:
+            light = pd.DataFrame(index=pd.RangeIndex(n_rows))
+        return SplitTable(names, n_rows, light, heavy)
+    finally:
+        L.dyd_csv_free(h)
+
+
+# ------------------------------------------------------------------------------------------------- writer
+def _series_column(s: pd.Series):
+    """pandas column -> (kind, arrays...) or None if the dtype is not covered"""
+    kind = s.dtype.kind
+    if s.dtype == np.int64:
+        return (1, np.ascontiguousarray(s.to_numpy()), None, None)
+    if s.dtype == np.float64:
+        return (2, np.ascontiguousarray(s.to_numpy()), None, None)
+    if s.dtype == np.bool_:
+        return (3, np.ascontiguousarray(s.to_numpy().astype(np.uint8)), None, None)
+    if kind == "O":
+        vals = s.tolist()
+        na = np.fromiter((v is None or (type(v) is float and v != v) for v in vals), dtype=np.uint8, count=len(vals))
+        # csv.writer prints str(value) for the scalars an object column can hold after JSON / CSV parsing
+        ok = (str, int, float, bool, np.integer, np.floating, np.bool_)
+        if not all(n or isinstance(v, ok) for v, n in zip(vals, na.tolist())):
+            return None
+        texts = [("" if n else (v if type(v) is str else str(v))) for v, n in zip(vals, na.tolist())]
+        blob = "".join(texts)
+        data = blob.encode("utf-8")
+        lens = np.fromiter(map(len, texts), dtype=np.int64, count=len(texts))
+        if len(data) != len(blob):
+            for i, v in enumerate(texts):
+                if not v.isascii():
+                    lens[i] = len(v.encode("utf-8"))
+        off = np.zeros(len(texts) + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        return (0, np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8), off, na)
+    return None
+
+
+class _Cols(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("data", C.c_void_p), ("off", C.c_void_p), ("na", C.c_void_p)]
+
+
+def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, encoding: str = "utf-8-sig",
+                check_rows: int = 40) -> bool:
+    """Write the table like ``DataFrame(...)[names].to_csv(path, index=False, encoding=encoding)``.
+
+    columns[i] is a pandas Series (light column, length n_rows) or a Utf8Column.  ``rows`` selects and
+    orders source rows (default: all).  Returns False — without touching ``path`` — when a column type is
+    not covered or when the sample check against pandas disagrees."""
+    if not enabled() or encoding.lower().replace("_", "-") not in ("utf-8-sig", "utf-8", "utf8"):
+        return False
+    L = _native.load_library()
+    specs, keep = [], []
+    for col in columns:
+        if isinstance(col, Utf8Column):
+            specs.append((0, col.data, col.off, col.na))
+        else:
+            sp = _series_column(col)
+            if sp is None:
+                return False
+            specs.append(sp)
+    arr = (_Cols * len(specs))()
+    for i, (kind, data, off, na) in enumerate(specs):
+        data = np.ascontiguousarray(data)
+        keep.append(data)
+        arr[i].kind = kind
+        arr[i].data = data.ctypes.data
+        if off is not None:
+            off = np.ascontiguousarray(off, dtype=np.int64); keep.append(off); arr[i].off = off.ctypes.data
+        if na is not None:
+            na = np.ascontiguousarray(na, dtype=np.uint8); keep.append(na); arr[i].na = na.ctypes.data
+    header = pd.DataFrame(columns=names).to_csv(index=False).encode("utf-8")
+    bom = _BOM if "sig" in encoding.lower() else b""
+    rows_arr = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+    n_out = n_rows if rows_arr is None else len(rows_arr)
+
+    # ---- cross-check a sample of rows against pandas itself ---------------------------------------
+    if n_out:
+        pick = np.unique(np.concatenate([np.arange(min(check_rows, n_out)), np.arange(max(0, n_out - 8), n_out)]))
+        src = pick if rows_arr is None else rows_arr[pick]
+        sample = {}
+        for nm, col in zip(names, columns):
+            sample[nm] = col.cells(src) if isinstance(col, Utf8Column) else col.iloc[src].reset_index(drop=True)
+        want = pd.DataFrame(sample, columns=names).to_csv(index=False).encode("utf-8")
+        mem, ln = C.c_void_p(), C.c_int64()
+        srcc = np.ascontiguousarray(src, dtype=np.int64)
+        rc = L.dyd_csv_write(None, header, len(header), arr, len(specs), n_rows, srcc.ctypes.data, len(srcc), int(_QUOTE_CR), 1,
+                             1, C.byref(mem), C.byref(ln))
+        if rc != 0:
+            return False
+        got = bytes(_view(mem.value, np.uint8, ln.value))
+        L.dyd_host_free(mem)
+        if got != want:
+            return False
+    full_header = bom + header
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    rc = L.dyd_csv_write(os.fsencode(path), full_header, len(full_header), arr, len(specs), n_rows,
+                         rows_arr.ctypes.data if rows_arr is not None else None, n_out, int(_QUOTE_CR), 0, 0, None, None)
+    return rc == 0

@@ -88,6 +88,20 @@ class PolygonScan(_Scan):
         self.w_val = _view(L.dyd_scan_wh_value(handle, 0), np.float64, n_cells).copy()
         self.h_val = _view(L.dyd_scan_wh_value(handle, 1), np.float64, n_cells).copy()
 
+    def emit_buffers(self, arg4: np.ndarray, n_threads: int = 0) -> tuple:
+        """Rewritten JSON text of every cell as flat utf-8 + offsets (views into the handle, valid until
+        close()); cells that are not regular have empty text."""
+        L = _native.load_library()
+        arg4 = np.ascontiguousarray(arg4, dtype=np.int32).reshape(-1)
+        if arg4.size != 4 * self.n_boxes:
+            raise ValueError("arg4 does not match the scan")
+        out_text, out_off = C.c_void_p(), C.c_void_p()
+        _native.check(L.dyd_json_emit_polygons(self._h, self._data.ctypes.data, self._off.ctypes.data,
+                                               arg4.ctypes.data if arg4.size else None, n_threads,
+                                               C.byref(out_text), C.byref(out_off)), "dyd_json_emit_polygons")
+        off = _view(out_off.value, np.int64, self.n_cells + 1)
+        return _view(out_text.value, np.uint8, int(off[-1])), off
+
     def emit(self, arg4: np.ndarray, n_threads: int = 0) -> list:
         """Rewritten JSON text per cell: str for regular cells, None for undecodable / missing cells and
         for irregular ones (the caller fills those in)."""
@@ -130,6 +144,29 @@ class BoxScan(_Scan):
         nb = int(self.cell_box_off[-1]) if n_cells else 0
         self.box4 = _view(L.dyd_scan_xy(handle), np.float64, 4 * nb).reshape(-1, 4)
         self.row_off = self.cell_box_off
+
+
+def scan_polygons_buffers(data, off, missing, n_threads: int = 0, keep=None) -> PolygonScan:
+    """scan cells that already are flat utf-8 (fastcsv.Utf8Column): no Python str objects involved"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    missing = np.ascontiguousarray(missing, dtype=np.uint8)
+    L = _native.load_library()
+    h = C.c_void_p()
+    _native.check(L.dyd_json_scan_polygons(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1,
+                                           n_threads, C.byref(h)), "dyd_json_scan_polygons")
+    return PolygonScan(h, len(off) - 1, keep, data, off)
+
+
+def scan_boxes_buffers(data, off, missing, n_threads: int = 0, keep=None) -> BoxScan:
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    missing = np.ascontiguousarray(missing, dtype=np.uint8)
+    L = _native.load_library()
+    h = C.c_void_p()
+    _native.check(L.dyd_json_scan_boxes(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1,
+                                        n_threads, C.byref(h)), "dyd_json_scan_boxes")
+    return BoxScan(h, len(off) - 1, (keep, data, off, missing))
 
 
 def scan_polygons(cells, n_threads: int = 0) -> PolygonScan:

@@ -189,6 +189,32 @@ const uint8_t *dyd_scan_wh_kind(const dyd_scan *scan, int which);   /* which: 0 
 const double *dyd_scan_wh_value(const dyd_scan *scan, int which);
 void dyd_scan_free(dyd_scan *scan);
 
+/* ---- native CSV hand-off (HOST code) ------------------------------------------------
+ * Replaces pandas read_csv / to_csv around the two heavy JSON columns (processor.py:235, :309, :379,
+ * :404, :407).  dyd_csv_index tokenises a utf-8 buffer with pandas' C-parser conventions and FAILS on
+ * anything it does not reproduce exactly (the caller then uses pandas); dyd_csv_extract returns one
+ * column as flat utf-8 + offsets + NA mask (pandas' default NA strings); dyd_csv_project returns the CSV
+ * text of the remaining columns for pandas itself to parse; dyd_csv_write writes typed column buffers
+ * (kind 0 utf-8, 1 int64, 2 float64, 3 bool) like DataFrame.to_csv(index=False). */
+typedef struct dyd_csv dyd_csv;
+typedef struct dyd_csv_col {
+    int32_t kind;
+    const void *data;
+    const int64_t *off;
+    const uint8_t *na;
+} dyd_csv_col;
+int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out);
+int64_t dyd_csv_rows(const dyd_csv *csv);
+int32_t dyd_csv_cols(const dyd_csv *csv);
+int64_t dyd_csv_header(const dyd_csv *csv, int32_t col, uint8_t *buf, int64_t cap);
+int dyd_csv_extract(dyd_csv *csv, int32_t col, const uint8_t **bytes, const int64_t **off, const uint8_t **na);
+int dyd_csv_project(dyd_csv *csv, const int32_t *keep, int32_t n_keep, const uint8_t **text, int64_t *len);
+void dyd_csv_free(dyd_csv *csv);
+int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, const dyd_csv_col *cols,
+                  int32_t n_cols, int64_t n_rows, const int64_t *rows, int64_t n_sel, int quote_cr,
+                  int n_threads, int to_memory, uint8_t **mem_out, int64_t *mem_len);
+void dyd_host_free(void *p);
+
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging. */
 int dyd_set_option(const char *key, int64_t value);

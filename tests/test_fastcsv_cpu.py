@@ -1,0 +1,130 @@
+"""Native CSV hand-off (csrc/host_csv.cpp, fastcsv.py) against pandas itself: the split reader must hand
+pandas-identical light columns and heavy cells, the writer must produce to_csv's bytes, and the step
+functions must write the same files whether they take the native or the pandas CSV path."""
+import io
+import os
+import random
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import golden_csv_text, load_golden
+from helpers import read_text, write_csv_text
+from deal_yolo_daya_amd import fastcsv, synth
+from deal_yolo_daya_amd.core import processor as P
+
+ANN, BBOX = P.ANNOTATION_COL, P.BBOX_COL
+
+
+def _messy_frame(seed, n=400):
+    r = random.Random(seed)
+    t = synth.generate(n, seed=seed, max_boxes=5)
+    df = synth.to_frame(t)
+    texts = ['plain', 'with,comma', 'with "quotes"', 'multi\nline', ' lead', 'trail ', '', 'NA', 'null', 'nan', 'None', '中文, "引号"',
+             '1.50', '007', 'True', "it's", 'tab\there', '"', '""', ',']
+    df["txt"] = [r.choice(texts) for _ in range(n)]
+    df["i"] = [r.randint(-10**12, 10**12) for _ in range(n)]
+    df["f"] = [r.choice([np.nan, 0.1, -0.0, 1e16, 1e-7, 1920.0, 3.14159, float(r.randint(0, 9)), r.random() * 1e5]) for _ in range(n)]
+    df["b"] = [r.random() < 0.5 for _ in range(n)]
+    df["mixed"] = [r.choice(["a", "1", "2.5", None]) for _ in range(n)]
+    df["allna"] = np.nan
+    for k in r.sample(range(n), 12):
+        df.loc[k, ANN] = r.choice([np.nan, "null", "NA", '{"objects": [', "[1, 2]", '{"objects": null}'])
+    cols = list(df.columns)
+    r.shuffle(cols)
+    return df[cols]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_read_split_equals_pandas(tmp_path, seed):
+    df = _messy_frame(seed)
+    path = str(tmp_path / "t.csv")
+    df.to_csv(path, index=False, encoding="utf-8-sig")
+    want = pd.read_csv(path, encoding="utf-8-sig")
+    t = fastcsv.read_split(path, [ANN, BBOX])
+    assert t is not None and t.names == list(want.columns) and t.n_rows == len(want)
+    pd.testing.assert_frame_equal(t.light, want[[c for c in want.columns if c != ANN]])
+    got = t.heavy[ANN].cells(range(t.n_rows))
+    exp = want[ANN].tolist()
+    assert all((isinstance(a, float) and isinstance(b, float)) or a == b for a, b in zip(got, exp))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_write_table_equals_to_csv(tmp_path, seed):
+    df = _messy_frame(100 + seed)
+    path = str(tmp_path / "t.csv")
+    df.to_csv(path, index=False, encoding="utf-8-sig")
+    back = pd.read_csv(path, encoding="utf-8-sig")
+    t = fastcsv.read_split(path, [ANN])
+    cols = [t.heavy[c] if c in t.heavy else t.light[c] for c in t.names]
+    out, ref = str(tmp_path / "o.csv"), str(tmp_path / "r.csv")
+    assert fastcsv.write_table(out, t.names, cols, t.n_rows)
+    back.to_csv(ref, index=False, encoding="utf-8-sig")
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    rows = np.flatnonzero(np.arange(t.n_rows) % 3 == 1)[::-1].copy()
+    assert fastcsv.write_table(out, t.names, cols, t.n_rows, rows=rows)
+    back.iloc[rows].to_csv(ref, index=False, encoding="utf-8-sig")
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    assert fastcsv.write_table(out, t.names, cols, t.n_rows, rows=np.zeros(0, np.int64))
+    back.iloc[:0].to_csv(ref, index=False, encoding="utf-8-sig")
+    assert open(out, "rb").read() == open(ref, "rb").read()
+
+
+def test_reader_refuses_what_it_does_not_reproduce(tmp_path):
+    cases = {"crlf": "source,%s\r\na,{}\r\n" % ANN, "ragged": "source,%s\na\n" % ANN, "stray_quote": 'source,%s\na"b,{}\n' % ANN,
+             "dup_names": "a,a,%s\n1,2,{}\n" % ANN, "numeric_heavy": "source,%s\na,5\nb,7\n" % ANN, "empty": ""}
+    for name, text in cases.items():
+        p = str(tmp_path / f"{name}.csv")
+        with open(p, "w", encoding="utf-8-sig", newline="") as f:
+            f.write(text)
+        assert fastcsv.read_split(p, [ANN]) is None, name
+
+
+def test_writer_refuses_unknown_dtypes(tmp_path):
+    df = pd.DataFrame({"a": pd.to_datetime(["2020-01-01"]), "b": [1]})
+    assert not fastcsv.write_table(str(tmp_path / "x.csv"), ["a", "b"], [df["a"], df["b"]], 1)
+    df = pd.DataFrame({"a": pd.Series([[1], "x"], dtype=object)})
+    assert not fastcsv.write_table(str(tmp_path / "x.csv"), ["a"], [df["a"]], 2)
+    assert not os.path.exists(tmp_path / "x.csv")
+    df = pd.DataFrame({"a": pd.Series([1, "x,y", 2.5, True, None, np.float64(3.0), np.int64(7)], dtype=object)})   # scalars are fine
+    assert fastcsv.write_table(str(tmp_path / "y.csv"), ["a"], [df["a"]], len(df))
+    df.to_csv(tmp_path / "z.csv", index=False, encoding="utf-8-sig")
+    assert open(tmp_path / "y.csv", "rb").read() == open(tmp_path / "z.csv", "rb").read()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_steps_write_identical_files_on_both_csv_paths(oracle_backend, tmp_path, monkeypatch, seed):
+    df = _messy_frame(200 + seed)
+    src = str(tmp_path / "in.csv")
+    df.to_csv(src, index=False, encoding="utf-8-sig")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DYD_NATIVE_CSV", mode)
+        Q = lambda n: str(tmp_path / f"{n}_{mode}.csv")  # noqa: E731
+        try:
+            res = P.process_csv_replace_ptlist(src, Q("p"), Q("e"), backend=oracle_backend)
+        except Exception as e:  # noqa: BLE001   (irregular cells may raise: both paths must agree on that too)
+            outs[mode] = ("raise", type(e).__name__)
+            continue
+        assert P.LAST_IO_PATH["replace"] == ("native" if mode == "1" else "pandas")
+        P.filter_by_box_count_and_iou(Q("p"), Q("h"), Q("o"), 2, 0.5, backend=oracle_backend)
+        assert P.LAST_IO_PATH["iou"] == ("native" if mode == "1" else "pandas")
+        outs[mode] = (res["filtered_rows"], res["excluded_rows"]) + tuple(open(Q(n), "rb").read() for n in "peho")
+    assert outs["1"] == outs["0"]
+
+
+def test_golden_files_take_the_native_csv_path(oracle_backend, tmp_path):
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    write_csv_text(Q("filtered.csv"), golden_csv_text("e2e_filtered.csv.gz"))
+    P.process_csv_replace_ptlist(Q("filtered.csv"), Q("processed.csv"), Q("excluded.csv"), backend=oracle_backend)
+    assert P.LAST_IO_PATH["replace"] == "native"
+    P.filter_by_box_count_and_iou(Q("processed.csv"), Q("high.csv"), Q("other.csv"), 2, 0.98, backend=oracle_backend)
+    assert P.LAST_IO_PATH["iou"] == "native"
+    for n in ("processed", "excluded", "high", "other"):
+        assert read_text(Q(n + ".csv")) == golden_csv_text(f"e2e_{n}.csv.gz"), n
+    g = load_golden("replace_cases.json")
+    write_csv_text(Q("cases.csv"), g["input_csv"])
+    P.process_csv_replace_ptlist(Q("cases.csv"), Q("cases_out.csv"), Q("cases_exc.csv"), backend=oracle_backend)
+    assert P.LAST_IO_PATH["replace"] == "native"          # irregular cells are spliced in, the CSV path stays native
+    assert read_text(Q("cases_out.csv")) == g["output_csv"] and read_text(Q("cases_exc.csv")) == g["excluded_csv"]
