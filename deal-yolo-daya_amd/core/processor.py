@@ -73,17 +73,27 @@ def deduplicate_csv_by_source(
         raise FileNotFoundError(f"CSV文件不存在：{csv_path}")
     if not csv_path.endswith(".csv"):
         raise ValueError(f"文件不是CSV格式：{csv_path}（请传入.csv后缀的文件）")
+    table = None
     try:
-        df = pd.read_csv(csv_path, encoding=encoding, parse_dates=False)
+        table = _fc.read_split(csv_path, [ANNOTATION_COL, BBOX_COL], encoding) if _fc.enabled() else None
+        if table is not None and not table.heavy:
+            table = None                                   # nothing heavy in this file: plain pandas is as good
+        df = table.light if table is not None else pd.read_csv(csv_path, encoding=encoding, parse_dates=False)
     except Exception as e:
         raise Exception(f"读取CSV文件失败：{str(e)}") from e
+    LAST_IO_PATH["dedup"] = "native" if table is not None else "pandas"
     if verbose:
         print(f"成功读取CSV文件：{os.path.basename(csv_path)}")
         print(f"读取后原始数据行数：{len(df)}")
     if "source" not in df.columns:
-        raise KeyError(f"CSV文件中未找到'source'列，请检查列名是否正确（当前列名：{list(df.columns)}）")
+        names = table.names if table is not None else list(df.columns)
+        raise KeyError(f"CSV文件中未找到'source'列，请检查列名是否正确（当前列名：{names}）")
 
-    result = dedup_frame(df, keep, backend)
+    if table is not None:                                  # heavy columns stay flat buffers until the result frame
+        rows = np.flatnonzero(dedup_keep_mask(df["source"], keep, backend))
+        result = _fc.frame_from_split(table, rows)
+    else:
+        result = dedup_frame(df, keep, backend)
     if verbose:
         print(f"去重策略：按'source'列保留{keep}条数据")
         print(f"去除重复数据行数：{len(df) - len(result)}")
@@ -94,7 +104,11 @@ def deduplicate_csv_by_source(
             parent = os.path.dirname(output_file)
             if parent:
                 os.makedirs(parent, exist_ok=True)
-            result.to_csv(output_file, index=False, encoding=encoding)
+            columns = ([table.heavy[nm] if nm in table.heavy else table.light[nm] for nm in table.names]
+                       if table is not None else None)
+            if columns is None or not _fc.write_table(output_file, table.names, columns, table.n_rows, rows=rows,
+                                                       encoding=encoding):
+                result.to_csv(output_file, index=False, encoding=encoding)
         except Exception as e:
             raise Exception(f"保存去重文件失败：{str(e)}") from e
         if verbose:
@@ -135,11 +149,16 @@ def remove_duplicates_between_csv(
             raise FileNotFoundError(f"文件不存在：{path}")
         if not path.endswith(".csv"):
             raise ValueError(f"文件不是CSV格式：{path}（请传入.csv后缀文件）")
+    table = None
     try:
-        df_main = pd.read_csv(main_csv, encoding=encoding, parse_dates=False)
+        table = _fc.read_split(main_csv, [ANNOTATION_COL, BBOX_COL], encoding) if _fc.enabled() else None
+        if table is not None and (not table.heavy or compare_col in table.heavy):
+            table = None
+        df_main = table.light if table is not None else pd.read_csv(main_csv, encoding=encoding, parse_dates=False)
         df_ref = pd.read_csv(ref_csv, encoding=encoding, parse_dates=False)
     except Exception as e:
         raise Exception(f"读取CSV失败：{str(e)}") from e
+    LAST_IO_PATH["ref_filter"] = "native" if table is not None else "pandas"
     if verbose:
         print(f"读取主文件：{len(df_main)}行")
         print(f"读取参考文件：{len(df_ref)}行")
@@ -148,7 +167,12 @@ def remove_duplicates_between_csv(
     if compare_col not in df_ref.columns:
         raise KeyError(f"参考文件中未找到列 '{compare_col}'")
 
-    kept = ref_filter_frame(df_main, df_ref, compare_col, backend)
+    if table is not None:
+        keep_rows = np.flatnonzero(~ref_hit_mask(df_main[compare_col], df_ref[compare_col], backend))
+        kept = _fc.frame_from_split(table, keep_rows)
+        kept.index = pd.Index(keep_rows)                   # df_main[~is_dup].copy() keeps the original labels (:199)
+    else:
+        kept = ref_filter_frame(df_main, df_ref, compare_col, backend)
     if verbose:
         print(f"去重依据列：{compare_col}")
         print(f"参考文件中唯一值数量：{df_ref[compare_col].dropna().astype(str).nunique()}")
@@ -158,7 +182,11 @@ def remove_duplicates_between_csv(
         parent = os.path.dirname(output_csv)
         if parent:
             os.makedirs(parent, exist_ok=True)
-        kept.to_csv(output_csv, index=False, encoding=encoding)
+        columns = ([table.heavy[nm] if nm in table.heavy else table.light[nm] for nm in table.names]
+                   if table is not None else None)
+        if columns is None or not _fc.write_table(output_csv, table.names, columns, table.n_rows, rows=keep_rows,
+                                                   encoding=encoding):
+            kept.to_csv(output_csv, index=False, encoding=encoding)
     except Exception as e:
         raise Exception(f"保存结果失败：{str(e)}") from e
     if verbose:

@@ -134,6 +134,29 @@ def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
         L.dyd_csv_free(h)
 
 
+def frame_from_split(table: "SplitTable", rows=None) -> pd.DataFrame:
+    """The DataFrame pandas.read_csv would have produced (for `rows`, index reset when rows is given):
+    heavy columns are materialised as Python str / NaN only here, for callers that must return a frame."""
+    import pyarrow as pa
+
+    idx = np.arange(table.n_rows) if rows is None else np.asarray(rows, np.int64)
+    out = {}
+    for nm in table.names:
+        if nm in table.heavy:
+            col = table.heavy[nm]
+            arr = pa.LargeStringArray.from_buffers(table.n_rows, pa.py_buffer(col.off), pa.py_buffer(col.data))
+            vals = arr.take(pa.array(idx)).to_numpy(zero_copy_only=False).astype(object)
+            vals[col.na[idx] != 0] = np.nan
+            out[nm] = vals
+        else:
+            out[nm] = table.light[nm].to_numpy()[idx] if rows is not None else table.light[nm].to_numpy()
+    df = pd.DataFrame(out, columns=table.names)
+    for nm in table.light.columns:                      # keep pandas' dtypes (object columns stay object)
+        if df[nm].dtype != table.light[nm].dtype:
+            df[nm] = df[nm].astype(table.light[nm].dtype)
+    return df
+
+
 # ------------------------------------------------------------------------------------------------- writer
 def _series_column(s: pd.Series):
     """pandas column -> (kind, arrays...) or None if the dtype is not covered"""

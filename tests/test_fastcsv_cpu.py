@@ -128,3 +128,30 @@ def test_golden_files_take_the_native_csv_path(oracle_backend, tmp_path):
     P.process_csv_replace_ptlist(Q("cases.csv"), Q("cases_out.csv"), Q("cases_exc.csv"), backend=oracle_backend)
     assert P.LAST_IO_PATH["replace"] == "native"          # irregular cells are spliced in, the CSV path stays native
     assert read_text(Q("cases_out.csv")) == g["output_csv"] and read_text(Q("cases_exc.csv")) == g["excluded_csv"]
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_dedup_and_ref_filter_frames_on_both_csv_paths(oracle_backend, tmp_path, monkeypatch, seed):
+    """the two steps that RETURN a DataFrame must return pandas-identical frames on the native CSV path"""
+    df = _messy_frame(300 + seed)
+    df["source"] = [f"u{k % 150}" if k % 41 else np.nan for k in range(len(df))]
+    ref = pd.DataFrame({"source": [f"u{k}" for k in range(0, 150, 7)] + [np.nan, "nan"], "other": 1})
+    src, refp = str(tmp_path / "in.csv"), str(tmp_path / "ref.csv")
+    df.to_csv(src, index=False, encoding="utf-8-sig")
+    ref.to_csv(refp, index=False, encoding="utf-8-sig")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DYD_NATIVE_CSV", mode)
+        Q = lambda n: str(tmp_path / f"{n}_{mode}.csv")  # noqa: E731
+        frames = []
+        for keep in ("first", "last", False):
+            frames.append(P.deduplicate_csv_by_source(src, Q(f"d{keep}"), keep=keep, verbose=False, backend=oracle_backend))
+            assert P.LAST_IO_PATH["dedup"] == ("native" if mode == "1" else "pandas")
+        frames.append(P.remove_duplicates_between_csv(src, refp, Q("r"), verbose=False, backend=oracle_backend))
+        assert P.LAST_IO_PATH["ref_filter"] == ("native" if mode == "1" else "pandas")
+        res[mode] = (frames, [open(Q(n), "rb").read() for n in ("dfirst", "dlast", "dFalse", "r")])
+    for a, b in zip(res["1"][0], res["0"][0]):
+        pd.testing.assert_frame_equal(a, b)
+    assert res["1"][1] == res["0"][1]
+    want = pd.read_csv(src, encoding="utf-8-sig").drop_duplicates(subset=["source"], keep="first", ignore_index=True)
+    pd.testing.assert_frame_equal(res["1"][0][0], want)
