@@ -70,6 +70,28 @@ def main():
         c, texts = clock(lambda: scan.emit(arg4))
         out["replace_breakdown_s"] = {"native_scan(incl. join+encode)": round(a, 3), "K1 host-pointer call (H2D+kernel+D2H)": round(b, 3),
                                       "K1 kernel_ms": round(_native.last_kernel_ms(), 3), "native_emit(incl. str objects)": round(c, 3)}
+        # ---- the four CSV->CSV steps in pipeline order (dedup, ref filter, replace, IoU) --------------------
+        ref_df = pd.DataFrame({"source": synth.reference_urls(args.rows)})
+        ref_df.to_csv(Q("ref.csv"), index=False, encoding="utf-8-sig")
+
+        def chain(mod, tag, names):
+            t0 = time.perf_counter()
+            getattr(mod, names[0])(Q("in.csv"), Q(f"c1_{tag}.csv"), **({"verbose": False} if mod is P else {}))
+            t1 = time.perf_counter()
+            getattr(mod, names[1])(Q(f"c1_{tag}.csv"), Q("ref.csv"), Q(f"c2_{tag}.csv"), **({"verbose": False} if mod is P else {}))
+            t2 = time.perf_counter()
+            getattr(mod, names[2])(Q(f"c2_{tag}.csv"), Q(f"c3_{tag}.csv"), Q(f"c3e_{tag}.csv"))
+            t3 = time.perf_counter()
+            getattr(mod, names[3])(Q(f"c3_{tag}.csv"), Q(f"c4h_{tag}.csv"), Q(f"c4o_{tag}.csv"), 2, 0.98)
+            t4 = time.perf_counter()
+            return {"dedup_s": round(t1 - t0, 3), "ref_filter_s": round(t2 - t1, 3), "replace_s": round(t3 - t2, 3),
+                    "iou_s": round(t4 - t3, 3), "total_s": round(t4 - t0, 3), "input_rows_per_s": round(args.rows / (t4 - t0))}
+
+        prod_names = ("deduplicate_csv_by_source", "remove_duplicates_between_csv", "process_csv_replace_ptlist",
+                      "filter_by_box_count_and_iou")
+        chain(P, "warm", prod_names)
+        out["product_chain_csv_to_csv"] = chain(P, "prod", prod_names)
+        out["product_chain_io_paths"] = dict(P.LAST_IO_PATH)
         # ---- CPU port of the reference, path level ------------------------------------------------------
         if not args.skip_cpu:
             s1, _ = clock(lambda: osteps.replace_csv(Q("in.csv"), Q("rp.csv"), Q("re.csv")))
@@ -79,6 +101,9 @@ def main():
                        for a, b in (("rp.csv", "p_native_json.csv"), ("rh.csv", "h_native_json.csv"), ("ro.csv", "o_native_json.csv"),
                                     ("rp.csv", "p_cpython_json.csv")))
             out["outputs_byte_identical_to_cpu_port"] = same
+            out["cpu_port_chain_csv_to_csv"] = chain(osteps, "cpu", ("dedup_csv", "ref_filter_csv", "replace_csv", "iou_filter_csv"))
+            out["chain_outputs_byte_identical"] = all(
+                open(Q(f"{n}_prod.csv"), "rb").read() == open(Q(f"{n}_cpu.csv"), "rb").read() for n in ("c1", "c2", "c3", "c3e", "c4h", "c4o"))
     print(json.dumps(out, ensure_ascii=False))
 
 
