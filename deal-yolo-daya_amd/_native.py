@@ -75,6 +75,10 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_split_ids_sharded_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_yolo_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "dyd_yolo_lines_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     "dyd_json_scan_polygons": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "dyd_json_emit_polygons": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -275,3 +279,35 @@ def split_ids(cat, perm_concat, cat_off, n_train, n_val):
     check(lib().dyd_split_ids(_ptr(cat), len(cat), _ptr(perm_concat), _ptr(cat_off), _ptr(n_train), _ptr(n_val),
                               n_cat, _ptr(split), _ptr(pos)), "dyd_split_ids")
     return split, pos
+
+
+def yolo_lines(box4, row_off, sel, width, height, class_id):
+    """K7 over host arrays -> (text_off int64 [n+1], flag u8 [n], text bytes).  flag 2 rows carry no text:
+    the caller prints them (zero image size, values of 2^43 and more)."""
+    box4 = np.ascontiguousarray(box4, dtype=np.float64).reshape(-1)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int32)
+    n = len(row_off) - 1
+    width = np.ascontiguousarray(width, dtype=np.float64)
+    height = np.ascontiguousarray(height, dtype=np.float64)
+    class_id = np.ascontiguousarray(class_id, dtype=np.int32)
+    if n < 0 or len(width) != n or len(height) != n or len(class_id) != n:
+        raise ValueError("row_off / width / height / class_id sizes disagree")
+    if n and (int(row_off[-1]) * 4 != len(box4)):
+        raise ValueError("row_off[-1] != number of boxes")
+    sel_p = None
+    if sel is not None:
+        sel = np.ascontiguousarray(sel, dtype=np.uint8)
+        if len(sel) * 4 != len(box4):
+            raise ValueError("sel size != number of boxes")
+        sel_p = _ptr(sel)
+    off = np.zeros(n + 1, np.int64)
+    flag = np.zeros(n, np.uint8)
+    text, total = C.c_void_p(), C.c_int64()
+    L = lib()
+    check(L.dyd_yolo_lines(_ptr(box4), _ptr(row_off), sel_p, _ptr(width), _ptr(height), _ptr(class_id), n, _ptr(off),
+                           _ptr(flag), C.byref(text), C.byref(total)), "dyd_yolo_lines")
+    try:
+        data = C.string_at(text.value, total.value) if total.value else b""
+    finally:
+        L.dyd_host_free(text)
+    return off, flag, data

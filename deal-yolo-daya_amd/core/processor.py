@@ -11,6 +11,9 @@ positionally through ``run_step`` (:548, :566, :584, :598, :630):
     filter_by_box_count_and_iou      reference processor.py:321-407   -> K2
     split_dataset_by_rules           reference processor.py:654-831   -> K6 (+ host MT19937)
 
+and, next to them, the label-line arithmetic of generate_yolo_datasets_from_excels
+(reference processor.py:1001-1060) as ``yolo_label_texts`` -> K7.
+
 Each step is  flatten (cells -> SoA numpy buffers)  ->  device stage (HIP kernels behind
 include/dyd.h)  ->  emit (masks / indices back into pandas).  Every step also has a
 DataFrame-level twin (``*_frame``) that skips the CSV hand-off.  The device stage is
@@ -31,7 +34,8 @@ from .. import flatten as _fl
 from .. import fastcsv as _fc
 from .. import native_json as _nj
 from ..backend import resolve as _backend
-from .utils import _parse_data_objects, _split_label_cell, _split_object_labels, safe_filename
+from .utils import (_extract_boxes_with_labels, _parse_data_objects, _split_label_cell, _split_object_labels,
+                    safe_filename)
 
 ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference processor.py:244
 BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
@@ -711,3 +715,93 @@ def split_dataset_by_rules(
             "category_counts": res["category_counts"],
         },
     }
+
+
+# =============================================================================== f4  YOLO label lines
+REASON_NO_MATCHING_BOX = "无匹配标签框"          # reference processor.py:1009
+REASON_NO_IMAGE_SIZE = "缺少图像尺寸"            # :1024
+REASON_NO_VALID_BOX = "标注框无效"               # :1058
+_EXACT_INT = 1 << 52                             # |x1 + x2| stays exact in f64 below 2^53
+
+
+def _label_lines_python(boxes, class_id, width, height) -> list:
+    """The reference's own arithmetic on Python numbers (processor.py:1046-1052) for the rows the device does
+    not print: big integers (exact int / int division), bools, values of 2^43 and more."""
+    out = []
+    for _, xa, ya, xb, yb in boxes:
+        left, right = min(xa, xb), max(xa, xb)
+        top, bottom = min(ya, yb), max(ya, yb)
+        box_w = max(right - left, 0.0)
+        box_h = max(bottom - top, 0.0)
+        if box_w <= 0 or box_h <= 0:
+            continue
+        out.append(f"{class_id} {(left + right) / 2 / width:.6f} {(top + bottom) / 2 / height:.6f} "
+                   f"{box_w / width:.6f} {box_h / height:.6f}")
+    return out
+
+
+def _plain_number(v, limit=_EXACT_INT) -> bool:
+    t = type(v)
+    if t is float or t is np.float64:
+        return True
+    if t is int or (isinstance(v, np.integer)):
+        return -limit <= int(v) <= limit
+    return False
+
+
+def yolo_label_texts(cells, label_values, class_ids, widths, heights, backend=None, stats: Optional[dict] = None):
+    """Label-file text per row of a split sheet: the part of generate_yolo_datasets_from_excels between the
+    box extraction and ``label_path.write_text`` (reference processor.py:1004-1060), batched.
+
+    cells[i] is the row's annotation JSON, label_values[i] = str(row[label_col]) (:992), class_ids[i] =
+    class_to_id[label_value] (:1049), widths / heights the row's image size (:1013-1014).
+    -> (texts, reasons): texts[i] is "\n".join(label_lines) or None; reasons[i] is the reference's skip
+    reason for a None (无匹配标签框 / 缺少图像尺寸 / 标注框无效) in the order the reference tests them.
+    Host: box extraction + label match; device: K7 (arithmetic, exact "%.6f", joining)."""
+    be = _backend(backend)
+    n = len(cells)
+    texts, reasons = [None] * n, [None] * n
+    dev_rows, dev_boxes, row_off, dev_w, dev_h, dev_cid = [], [], [0], [], [], []
+    py_rows = {}
+    for i in range(n):
+        boxes = [b for b in _extract_boxes_with_labels(cells[i]) if b[0] == label_values[i]]
+        if not boxes:
+            reasons[i] = REASON_NO_MATCHING_BOX
+            continue
+        w, h = widths[i], heights[i]
+        if not w or not h:
+            reasons[i] = REASON_NO_IMAGE_SIZE
+            continue
+        cid = class_ids[i]
+        if (_plain_number(w, 1 << 53) and _plain_number(h, 1 << 53) and isinstance(cid, (int, np.integer)) and 0 <= cid < (1 << 31)
+                and all(_plain_number(v) for b in boxes for v in b[1:])):
+            dev_rows.append(i)
+            for b in boxes:
+                dev_boxes.extend(b[1:])
+            row_off.append(len(dev_boxes) // 4)
+            dev_w.append(w)
+            dev_h.append(h)
+            dev_cid.append(cid)
+        else:
+            py_rows[i] = boxes
+    if dev_rows:
+        off, flag, data = be.yolo_lines(np.asarray(dev_boxes, np.float64), np.asarray(row_off, np.int32), None,
+                                        np.asarray(dev_w, np.float64), np.asarray(dev_h, np.float64),
+                                        np.asarray(dev_cid, np.int32))
+        for k, i in enumerate(dev_rows):
+            if flag[k] == 0:
+                texts[i] = data[off[k]:off[k + 1]].decode("ascii")
+            elif flag[k] == 1:
+                reasons[i] = REASON_NO_VALID_BOX
+            else:                                            # the device leaves huge values to the host
+                b0, b1 = row_off[k], row_off[k + 1]
+                py_rows[i] = [(label_values[i], *dev_boxes[4 * b:4 * b + 4]) for b in range(b0, b1)]
+    for i, boxes in py_rows.items():
+        lines = _label_lines_python(boxes, class_ids[i], widths[i], heights[i])
+        if lines:
+            texts[i] = "\n".join(lines)
+        else:
+            reasons[i] = REASON_NO_VALID_BOX
+    if stats is not None:
+        stats.update(rows=n, device_rows=len(dev_rows), python_rows=len(py_rows))
+    return texts, reasons

@@ -5,11 +5,14 @@ reference's ``core/utils.py`` that sit on the hot path (same names, same results
     _parse_data_objects   reference utils.py:645-657
     _split_object_labels  reference utils.py:659-662
     safe_filename         reference utils.py:525-529 (names the per-category workbook)
+    _extract_boxes_with_labels  reference utils.py:681-710 (labelled boxes of a cell, YOLO step)
+    _safe_image_stem      reference utils.py:712-724 (label / image file stem)
 """
 from __future__ import annotations
 
 import json
 import re
+from pathlib import Path
 
 import pandas as pd
 
@@ -55,3 +58,44 @@ def safe_filename(value: str) -> str:
         return "train"
     cleaned = re.sub(r"[^A-Za-z0-9._-]+", "_", value).strip("_")
     return cleaned or "train"
+
+
+def _extract_boxes_with_labels(json_str) -> list:
+    """[(name, min x, min y, max x, max y)] of the named objects with a non-empty ptList.
+
+    As in the reference the x and the y values are collected independently (a point may carry only one
+    of them), min / max are CPython's first-wins builtins over the decoded values, and the first exception
+    of any kind ends the scan, keeping what was collected before it."""
+    collected = []
+    if not isinstance(json_str, str):          # NaN / None / numbers: nothing to read
+        return collected
+    try:
+        for obj in json.loads(json_str).get("objects", []):
+            if not isinstance(obj, dict):
+                continue
+            name = obj.get("name")
+            if not name:
+                continue
+            points = obj.get("polygon", {}).get("ptList", [])
+            if not points:
+                continue
+            dict_points = [pt for pt in points if isinstance(pt, dict)]
+            xs = [pt.get("x") for pt in dict_points if "x" in pt]
+            ys = [pt.get("y") for pt in dict_points if "y" in pt]
+            if xs and ys:
+                collected.append((name, min(xs), min(ys), max(xs), max(ys)))
+    except Exception:  # noqa: BLE001 - the reference swallows everything here
+        pass
+    return collected
+
+
+def _safe_image_stem(source_url, idx) -> str:
+    """'<sanitised file stem>_<row index>' (query string dropped), 'img_<idx>' when there is no source"""
+    if not source_url:
+        return f"img_{idx}"
+    try:
+        stem = Path(Path(str(source_url)).name).stem
+        stem = stem.split("?")[0] if "?" in stem else stem
+        return f"{safe_filename(stem)}_{idx}"
+    except Exception:  # noqa: BLE001
+        return f"img_{idx}"

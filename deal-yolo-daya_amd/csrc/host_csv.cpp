@@ -49,6 +49,28 @@ bool is_na(const char *p, size_t n) {
     return false;
 }
 
+// could the C parser's dtype inference read this cell as a number or a boolean?  (a liberal superset: a
+// column with no such cell is an object column of str in every piece of the file, whatever the piece size)
+bool maybe_scalar(const char *p, size_t n) {
+    if (n == 0) return false;
+    bool numeric_bytes = true, digit = false;
+    for (size_t i = 0; i < n && numeric_bytes; ++i) {
+        const char c = p[i];
+        digit |= (c >= '0' && c <= '9');
+        numeric_bytes = (c >= '0' && c <= '9') || c == '.' || c == 'e' || c == 'E' || c == '+' || c == '-' || c == ' ' || c == '\t';
+    }
+    if (numeric_bytes) return digit;  // every number spelling holds a digit
+    while (n && (*p == ' ' || *p == '\t')) { ++p; --n; }
+    while (n && (p[n - 1] == ' ' || p[n - 1] == '\t')) --n;
+    if (n == 0 || n > 9) return false;
+    char low[10];
+    for (size_t i = 0; i < n; ++i) low[i] = (char)((p[i] >= 'A' && p[i] <= 'Z') ? p[i] + 32 : p[i]);
+    low[n] = 0;
+    const char *w = low;
+    if (*w == '+' || *w == '-') ++w;
+    return !strcmp(w, "true") || !strcmp(w, "false") || !strcmp(w, "inf") || !strcmp(w, "infinity") || !strcmp(w, "nan");
+}
+
 }  // namespace
 
 struct dyd_csv {
@@ -147,8 +169,9 @@ int64_t dyd_csv_header(const dyd_csv *h, int32_t c, uint8_t *buf, int64_t cap) {
 }
 
 // Extract column c as flat utf-8 (quotes undoubled) + offsets + NA mask (pandas default NA strings;
-// quoted cells are NA-checked too, like the C parser does).  Arrays stay owned by the handle until the
-// next extract call.
+// quoted cells are NA-checked too, like the C parser does).  na[i]: 0 text, 1 missing, 2 text that dtype
+// inference could read as a number / boolean (the caller leaves such a column to pandas).  Arrays stay owned
+// by the handle until the next extract call.
 int dyd_csv_extract(dyd_csv *h, int32_t c, const uint8_t **bytes, const int64_t **off, const uint8_t **na) {
     if (!h || c < 0 || c >= h->n_cols) return DYD_ERR_INVALID;
     try {
@@ -181,7 +204,8 @@ int dyd_csv_extract(dyd_csv *h, int32_t c, const uint8_t **bytes, const int64_t 
                 }
             }
             const int64_t clen = pos - h->col_off[(size_t)r];
-            h->col_na[(size_t)r] = is_na(reinterpret_cast<const char *>(w) + h->col_off[(size_t)r], (size_t)clen) ? 1 : 0;
+            const char *cell = reinterpret_cast<const char *>(w) + h->col_off[(size_t)r];
+            h->col_na[(size_t)r] = is_na(cell, (size_t)clen) ? 1 : (maybe_scalar(cell, (size_t)clen) ? 2 : 0);
         }
         h->col_off[(size_t)h->n_rows] = pos;
     } catch (const std::bad_alloc &) {
@@ -193,11 +217,18 @@ int dyd_csv_extract(dyd_csv *h, int32_t c, const uint8_t **bytes, const int64_t 
     return DYD_OK;
 }
 
-// CSV text of the columns keep[0..n_keep) only (raw field text, original quoting), header included, for
-// pandas to parse.
+// CSV text for pandas to parse: every column of the file is present (so the C parser's low-memory piece
+// size, which is a function of the table WIDTH, and with it per-piece dtype inference, stay what they are
+// for the original file), but only the columns keep[0..n_keep) carry their cells (raw field text, original
+// quoting); the others are empty fields.  The caller reads it with usecols = the kept names.
 int dyd_csv_project(dyd_csv *h, const int32_t *keep, int32_t n_keep, const uint8_t **text, int64_t *len) {
-    if (!h || n_keep < 0 || (n_keep && !keep)) return DYD_ERR_INVALID;
+    if (!h || n_keep <= 0 || !keep) return DYD_ERR_INVALID;
     try {
+        std::vector<uint8_t> kept((size_t)h->n_cols, 0);
+        for (int32_t k = 0; k < n_keep; ++k) {
+            if (keep[k] < 0 || keep[k] >= h->n_cols) return DYD_ERR_INVALID;
+            kept[(size_t)keep[k]] = 1;
+        }
         std::string &o = h->projected;
         o.clear();
         auto put = [&](const Field &f) {
@@ -205,21 +236,20 @@ int dyd_csv_project(dyd_csv *h, const int32_t *keep, int32_t n_keep, const uint8
             o.append(h->text + f.b, (size_t)(f.e - f.b));
             if (f.quoted) o += '"';
         };
-        for (int32_t k = 0; k < n_keep; ++k) {
-            if (keep[k] < 0 || keep[k] >= h->n_cols) return DYD_ERR_INVALID;
-            if (k) o += ',';
-            put(h->header[(size_t)keep[k]]);
+        for (int32_t c = 0; c < h->n_cols; ++c) {
+            if (c) o += ',';
+            put(h->header[(size_t)c]);
         }
         o += '\n';
         for (int64_t r = 0; r < h->n_rows; ++r) {
             const Field *row = &h->fields[(size_t)(r * h->n_cols)];
-            if (n_keep == 1 && row[keep[0]].b == row[keep[0]].e && !row[keep[0]].quoted) {
+            if (h->n_cols == 1 && row[0].b == row[0].e && !row[0].quoted) {
                 o += "\"\"\n";  // a lone empty field would read as a blank line
                 continue;
             }
-            for (int32_t k = 0; k < n_keep; ++k) {
-                if (k) o += ',';
-                put(row[keep[k]]);
+            for (int32_t c = 0; c < h->n_cols; ++c) {
+                if (c) o += ',';
+                if (kept[(size_t)c]) put(row[c]);
             }
             o += '\n';
         }

@@ -111,10 +111,10 @@ def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
             off = _view(po.value, np.int64, n_rows + 1).copy()
             data = _view(pb.value, np.uint8, int(off[-1]) + 1).copy()
             na = _view(pn.value, np.uint8, n_rows).copy()
-            # pandas would infer a non-object dtype if every present cell looked numeric / boolean: only a
-            # column with at least one JSON-looking cell is certainly an object column of str
-            starts = off[:-1][na == 0]
-            if len(starts) == 0 or not np.isin(data[starts], np.frombuffer(b'{["', np.uint8)).any():
+            # pandas infers dtypes per low-memory piece of the file, and a piece whose present cells all look
+            # numeric / boolean becomes numbers ("1.50" -> 1.5).  The column is taken natively only when NO
+            # present cell could be read as a number / boolean (na == 2): then every piece is object / str.
+            if (na == 2).any() or (na != 0).all():
                 return None
             heavy[nm] = Utf8Column(data, off, na)
         light_idx = [i for i, nm in enumerate(names) if nm not in heavy]
@@ -124,8 +124,9 @@ def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
             if L.dyd_csv_project(h, keep.ctypes.data, len(keep), C.byref(pt), C.byref(ln)) != 0:
                 return None
             text = bytes(_view(pt.value, np.uint8, ln.value))
-            light = pd.read_csv(io.BytesIO(text), encoding="utf-8")
-            if len(light) != n_rows or list(light.columns) != [names[i] for i in light_idx]:
+            light_names = [names[i] for i in light_idx]
+            light = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names)[light_names]
+            if len(light) != n_rows or list(light.columns) != light_names:
                 return None
         else:
             light = pd.DataFrame(index=pd.RangeIndex(n_rows))

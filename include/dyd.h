@@ -164,6 +164,32 @@ int dyd_split_ids_sharded_dev(const int32_t *cat, int64_t n, const int64_t *cat_
                               int32_t n_cat, const int64_t *cat_rank_base, uint8_t *out_split,
                               int64_t *out_pos, void *stream);
 
+/* ---- K7: YOLO label lines ----------------------------------------------
+ * Replaces the per-box arithmetic and "%.6f" formatting of generate_yolo_datasets_from_excels
+ * (processor.py:1046-1052) and the "\n".join of a row's lines (:1054):
+ *   x1,x2 = min,max; y1,y2 = min,max; bw = max(x2-x1, 0.0); bh = max(y2-y1, 0.0); skip if bw<=0 or bh<=0;
+ *   "{cid} {(x1+x2)/2/width:.6f} {(y1+y2)/2/height:.6f} {bw/width:.6f} {bh/height:.6f}"
+ * box4         : boxes as (x1, y1, x2, y2) f64, any corner order              [4*n_boxes]
+ * row_off      : boxes of row i are [row_off[i], row_off[i+1])               [n_rows+1]
+ * sel_or_null  : 1 = the box carries the row's label (b[0] == label_value, :1006), NULL = all  [n_boxes]
+ * width/height : the row's image size (:1013-1014)                            [n_rows]
+ * class_id     : class_to_id[label_value] (:1049)                             [n_rows]
+ * out_text_off : byte range of row i in the text = [off[i], off[i+1])         [n_rows+1]
+ * out_flag     : 0 text written, 1 no line (the reference skips the row: 标注框无效 / 无匹配标签框),
+ *                2 left to the host: zero width/height (the reference tests `not width` first, :1016),
+ *                negative class id, or a value >= 2^43 whose "%.6f" has up to 316 characters  [n_rows]
+ * dyd_yolo_lines     : host pointers; *out_text is allocated by the library (release with dyd_host_free).
+ * dyd_yolo_lines_dev : device pointers; out_text_or_null == NULL only measures (offsets, flags, total);
+ *                      otherwise text_cap bytes are available and DYD_ERR_RANGE is returned, with the needed
+ *                      size in *out_total, when that is too little.  *out_total is a HOST int64. */
+int dyd_yolo_lines(const double *box4, const int32_t *row_off, const uint8_t *sel_or_null,
+                   const double *width, const double *height, const int32_t *class_id, int64_t n_rows,
+                   int64_t *out_text_off, uint8_t *out_flag, uint8_t **out_text, int64_t *out_text_len);
+int dyd_yolo_lines_dev(const double *box4, const int32_t *row_off, const uint8_t *sel_or_null,
+                       const double *width, const double *height, const int32_t *class_id, int64_t n_rows,
+                       int64_t *out_text_off, uint8_t *out_flag, uint8_t *out_text_or_null, int64_t text_cap,
+                       int64_t *out_total, void *stream);
+
 /* ---- native flatten / emit (HOST code, multithreaded) ------------------------------
  * Schema-specialised JSON scanner + canonical re-emitter that replaces json.loads / json.dumps inside
  * parse_and_replace_ptlist (processor.py:262-281), extract_width_height (:285-292) and extract_boxes
@@ -193,8 +219,11 @@ void dyd_scan_free(dyd_scan *scan);
  * Replaces pandas read_csv / to_csv around the two heavy JSON columns (processor.py:235, :309, :379,
  * :404, :407).  dyd_csv_index tokenises a utf-8 buffer with pandas' C-parser conventions and FAILS on
  * anything it does not reproduce exactly (the caller then uses pandas); dyd_csv_extract returns one
- * column as flat utf-8 + offsets + NA mask (pandas' default NA strings); dyd_csv_project returns the CSV
- * text of the remaining columns for pandas itself to parse; dyd_csv_write writes typed column buffers
+ * column as flat utf-8 + offsets + a per-cell class (0 text, 1 missing = one of pandas' default NA strings,
+ * 2 text that dtype inference could read as a number / boolean); dyd_csv_project returns CSV text
+ * of the same width in which only the `keep` columns carry their cells, for pandas itself to parse with
+ * usecols (same width => same low-memory piece boundaries => same per-piece dtype inference as on the
+ * original file); dyd_csv_write writes typed column buffers
  * (kind 0 utf-8, 1 int64, 2 float64, 3 bool) like DataFrame.to_csv(index=False). */
 typedef struct dyd_csv dyd_csv;
 typedef struct dyd_csv_col {

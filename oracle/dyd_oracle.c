@@ -247,3 +247,44 @@ void orc_split_ids(const int32_t *cat, int64_t n, const int64_t *perm, const int
     free(inv);
     free(seen);
 }
+
+/* ---- K7: YOLO label lines -- restates processor.py:1046-1052 (per-box arithmetic, "%.6f") and :1054
+ * ("\n".join).  glibc's printf rounds the exact binary value half-to-even like CPython's float format.
+ * Two-call protocol: out_text == NULL measures; flags: 0 text, 1 no line, 2 zero width / height or a
+ * negative class id (the reference decides those before the arithmetic, :1016). */
+#include <stdio.h>
+int64_t orc_yolo_lines(const double *box4, const int32_t *row_off, const uint8_t *sel, const double *width,
+                       const double *height, const int32_t *class_id, int64_t n_rows, int64_t *out_off,
+                       uint8_t *out_flag, uint8_t *out_text) {
+    int64_t pos = 0;
+    char line[4 * 330 + 32];
+    for (int64_t r = 0; r < n_rows; ++r) {
+        out_off[r] = pos;
+        const double w = width[r], h = height[r];
+        if (w == 0.0 || h == 0.0 || class_id[r] < 0) {
+            out_flag[r] = 2;
+            continue;
+        }
+        int lines = 0;
+        for (int32_t b = row_off[r]; b < row_off[r + 1]; ++b) {
+            if (sel && !sel[b]) continue;
+            const double *p = box4 + 4 * (int64_t)b;
+            const double x1 = py_min2(p[0], p[2]), x2 = py_max2(p[0], p[2]);
+            const double y1 = py_min2(p[1], p[3]), y2 = py_max2(p[1], p[3]);
+            const double bw = py_max2(x2 - x1, 0.0), bh = py_max2(y2 - y1, 0.0);
+            if (bw <= 0.0 || bh <= 0.0) continue;
+            double v[4] = {(x1 + x2) / 2.0 / w, (y1 + y2) / 2.0 / h, bw / w, bh / h};
+            int n = snprintf(line, sizeof line, "%s%d", lines ? "\n" : "", class_id[r]);
+            for (int k = 0; k < 4; ++k) {
+                if (v[k] != v[k]) n += snprintf(line + n, sizeof line - (size_t)n, " nan");   /* never "-nan" */
+                else n += snprintf(line + n, sizeof line - (size_t)n, " %.6f", v[k]);
+            }
+            if (out_text) memcpy(out_text + pos, line, (size_t)n);
+            pos += n;
+            ++lines;
+        }
+        out_flag[r] = lines ? 0 : 1;
+    }
+    out_off[n_rows] = pos;
+    return pos;
+}

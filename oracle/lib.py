@@ -101,3 +101,28 @@ def split_ids(cat, perm_concat, cat_off, n_train, n_val):
                           _p(cat_off, C.c_int64), _p(n_train, C.c_int64), _p(n_val, C.c_int64),
                           C.c_int32(len(n_train)), _p(split, C.c_uint8), _p(pos, C.c_int64))
     return split, pos
+
+
+def yolo_lines(box4, row_off, sel, width, height, class_id):
+    """-> (text_off int64 [n+1], flag u8 [n], text bytes)"""
+    lib = _load()
+    box4 = np.ascontiguousarray(box4, dtype=np.float64).reshape(-1)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int32)
+    n = len(row_off) - 1
+    width = np.ascontiguousarray(width, dtype=np.float64)
+    height = np.ascontiguousarray(height, dtype=np.float64)
+    class_id = np.ascontiguousarray(class_id, dtype=np.int32)
+    sel_p = None
+    if sel is not None:
+        sel = np.ascontiguousarray(sel, dtype=np.uint8)
+        sel_p = _p(sel, C.c_uint8)
+    off = np.zeros(n + 1, np.int64)
+    flag = np.zeros(n, np.uint8)
+    fn = lib.orc_yolo_lines
+    fn.restype = C.c_int64
+    args = (_p(box4, C.c_double), _p(row_off, C.c_int32), sel_p, _p(width, C.c_double), _p(height, C.c_double),
+            _p(class_id, C.c_int32), C.c_int64(n), _p(off, C.c_int64), _p(flag, C.c_uint8))
+    total = fn(*args, None)
+    text = np.zeros(max(int(total), 1), np.uint8)
+    fn(*args, _p(text, C.c_uint8))
+    return off, flag, text[:total].tobytes()

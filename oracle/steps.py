@@ -361,3 +361,58 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns=None, t
         out[cat] = (f.iloc[:a], f.iloc[a:a + b], f.iloc[a + b:])
     return {"categories": out, "unclassified": pd.DataFrame(unclassified),
             "split_counts": pd.DataFrame(counts), "category_counts": cat_counts}
+
+
+# ------------------------------------------------- f4  YOLO label lines  utils.py:681-710, processor.py:1046-1052
+def extract_boxes_with_labels(json_str):
+    """utils.py:681-710: (label, min x, min y, max x, max y) per named object with a non-empty ptList; x and
+    y lists are gathered independently; ANY exception ends the scan and keeps the boxes found so far."""
+    found = []
+    try:
+        if pd.isna(json_str) or not isinstance(json_str, str):
+            return found
+        for obj in json.loads(json_str).get("objects", []):
+            if not isinstance(obj, dict):
+                continue
+            label = obj.get("name")
+            if not label:
+                continue
+            pts = obj.get("polygon", {}).get("ptList", [])
+            if not pts:
+                continue
+            xs = [p.get("x") for p in pts if isinstance(p, dict) and "x" in p]
+            ys = [p.get("y") for p in pts if isinstance(p, dict) and "y" in p]
+            if not xs or not ys:
+                continue
+            found.append((label, min(xs), min(ys), max(xs), max(ys)))
+    except Exception:  # noqa: BLE001  (the reference uses a bare except)
+        pass
+    return found
+
+
+def yolo_label_lines(boxes, class_id, width, height):
+    """processor.py:1046-1052: 'cid cx cy w h' (normalised, %.6f) for every box with positive width and height"""
+    lines = []
+    for _, x1, y1, x2, y2 in boxes:
+        x1, x2 = min(x1, x2), max(x1, x2)
+        y1, y2 = min(y1, y2), max(y1, y2)
+        bw = max(x2 - x1, 0.0)
+        bh = max(y2 - y1, 0.0)
+        if bw <= 0 or bh <= 0:
+            continue
+        lines.append(f"{class_id} {(x1 + x2) / 2 / width:.6f} {(y1 + y2) / 2 / height:.6f} {bw / width:.6f} {bh / height:.6f}")
+    return lines
+
+
+def yolo_row_text(json_str, label_value, class_id, width, height):
+    """One row of a split sheet -> (label-file text or None, skip reason or None), in the reference's order of
+    checks (processor.py:1001-1060) for a row whose source and image are present."""
+    boxes = [b for b in extract_boxes_with_labels(json_str) if b[0] == label_value]
+    if not boxes:
+        return None, "无匹配标签框"
+    if not width or not height:
+        return None, "缺少图像尺寸"
+    lines = yolo_label_lines(boxes, class_id, width, height)
+    if not lines:
+        return None, "标注框无效"
+    return "\n".join(lines), None

@@ -12,6 +12,7 @@ tests or vectors of its own, so these outputs are what pins oracle/ and the HIP 
     perm_cases.json      a5 DataFrame.sample(frac=1, random_state=seed) orders + int(n*ratio) cuts
     split_case.json      a5 split_dataset_by_rules with Excel I/O captured in memory
     e2e_*.csv.gz         one seeded table through all five steps (inputs and every output)
+    yolo_cases.json      f4 _extract_boxes_with_labels + the label files generate_yolo_datasets_from_excels writes
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -371,6 +372,141 @@ def make_e2e(n_rows=240):
     print("wrote e2e_*.csv.gz")
 
 
+
+# ------------------------------------------------------------------------------- f4  YOLO label lines
+def _obj(name, *pts, raw=None):
+    if raw is not None:
+        return raw
+    pl = ", ".join("{" + ", ".join(f'"{k}": {v}' for k, v in p.items()) + "}" if isinstance(p, dict) else str(p) for p in pts)
+    head = f'"name": {json.dumps(name, ensure_ascii=False)}, ' if name is not None else ""
+    return "{" + head + '"polygon": {"ptList": [' + pl + "]}}"
+
+
+def _cell(*objs):
+    return '{"objects": [' + ", ".join(objs) + "]}"
+
+
+def P2(x1, y1, x2, y2):
+    return ({"x": x1, "y": y1}, {"x": x2, "y": y2})
+
+
+# (json cell, label value, width, height)
+YOLO_CASES = {
+    "int_box": (_cell(_obj("a", *P2(10, 20, 110, 220))), "a", 1920, 1080),
+    "float_box": (_cell(_obj("a", *P2(10.25, 20.5, 110.75, 220.13))), "a", 1920, 1080),
+    "float_size": (_cell(_obj("b", *P2(3, 4, 1000, 700))), "b", 1920.0, 1080.5),
+    "polygon_many_points": (_cell(_obj("a", {"x": 5, "y": 9}, {"x": 1, "y": 12}, {"x": 7, "y": 3}, {"x": 6.5, "y": 30})), "a", 64, 48),
+    "three_objects_two_match": (_cell(_obj("a", *P2(0, 0, 10, 10)), _obj("b", *P2(1, 1, 5, 5)), _obj("a", *P2(20, 30, 25.5, 31))), "a", 100, 50),
+    "zero_width_only": (_cell(_obj("a", *P2(5, 0, 5, 10))), "a", 100, 100),
+    "zero_height_mixed": (_cell(_obj("a", *P2(5, 7, 9, 7)), _obj("a", *P2(1, 2, 3, 4))), "a", 100, 100),
+    "single_point_polygon": (_cell(_obj("a", {"x": 3, "y": 4})), "a", 100, 100),
+    "nan_first_x": (_cell(_obj("a", {"x": "NaN", "y": 1}, {"x": 2, "y": 5})), "a", 100, 100),
+    "nan_later_ignored": (_cell(_obj("a", {"x": 2, "y": 1}, {"x": "NaN", "y": "NaN"}, {"x": 4, "y": 5})), "a", 100, 100),
+    "infinite_corner": (_cell(_obj("a", {"x": 1, "y": 1}, {"x": "Infinity", "y": 5})), "a", 100, 100),
+    "both_infinite": (_cell(_obj("a", {"x": "-Infinity", "y": 1}, {"x": "Infinity", "y": 5})), "a", 100, 100),
+    "negative_coords": (_cell(_obj("a", *P2(-50, -20.5, -10, 30))), "a", 640, 480),
+    "negative_rounds_to_minus_zero": (_cell(_obj("a", *P2(-1e-9, -3e-10, 1e-10, 1e-10))), "a", 1920, 1080),
+    "neg_zero_corners": (_cell(_obj("a", *P2(-0.0, -0.0, 0.0, 0.0))), "a", 10, 10),
+    "tie_half_even_down": (_cell(_obj("a", *P2(0, 0, 2, 6))), "a", 128, 128),
+    "tie_half_even_up": (_cell(_obj("a", *P2(0, 0, 6, 10))), "a", 128, 256),
+    "just_above_tie": (_cell(_obj("a", *P2(0, 0, 2.0000000000000004, 6.000000000000001))), "a", 128, 128),
+    "rounds_up_to_ten": (_cell(_obj("a", *P2(0, 0, 19.9999999, 39.99999999))), "a", 1, 2),
+    "carry_into_integer_digits": (_cell(_obj("a", *P2(0, 0, 1.9999996, 1999.9999996))), "a", 1, 1),
+    "large_normalised": (_cell(_obj("a", *P2(0, 0, 123456789012.25, 8796093022207.5))), "a", 1, 1),
+    "at_2_pow_43": (_cell(_obj("a", *P2(0, 0, 17592186044416, 17592186044418))), "a", 1, 2),
+    "huge_values": (_cell(_obj("a", *P2(0, 0, 1e300, 2.5e15))), "a", 1e-5, 3),
+    "tiny_size_divisor": (_cell(_obj("a", *P2(1, 2, 3, 4))), "a", 1e-300, 5e-324),
+    "denormal_results": (_cell(_obj("a", *P2(0, 0, 1e-310, 3e-320))), "a", 7, 1e5),
+    "nan_width": (_cell(_obj("a", *P2(1, 2, 3, 4))), "a", float("nan"), 100),
+    "inf_height": (_cell(_obj("a", *P2(1, 2, 3, 4))), "a", 100, float("inf")),
+    "negative_width": (_cell(_obj("a", *P2(1, 2, 3, 4))), "a", -100, 100),
+    "zero_width_image": (_cell(_obj("a", *P2(1, 2, 3, 4))), "a", 0, 100),
+    "zero_float_height_image": (_cell(_obj("a", *P2(1, 2, 3, 4))), "a", 100, 0.0),
+    "label_mismatch": (_cell(_obj("b", *P2(1, 2, 3, 4))), "a", 100, 100),
+    "multi_label_name_never_equal": (_cell(_obj("a,b", *P2(1, 2, 3, 4))), "a", 100, 100),
+    "escaped_name_equal": (_cell(_obj(None, raw='{"name": "\\u4e2d\\u6587", "polygon": {"ptList": [{"x": 1, "y": 2}, {"x": 3, "y": 4}]}}')), "中文", 100, 100),
+    "x_and_y_lists_independent": (_cell(_obj("a", {"x": 1}, {"y": 2}, {"x": 5, "y": 7}, {"y": 9, "k": 0})), "a", 10, 10),
+    "only_x_keys": (_cell(_obj("a", {"x": 1}, {"x": 2})), "a", 10, 10),
+    "exception_keeps_earlier_boxes": (_cell(_obj("a", *P2(1, 2, 3, 4)), _obj("a", {"x": '"s"', "y": 1}, {"x": 2, "y": 2}), _obj("a", *P2(5, 6, 7, 8))), "a", 10, 10),
+    "null_x_raises": (_cell(_obj("a", *P2(1, 2, 3, 4)), _obj("a", {"x": "null", "y": 1}, {"x": 2, "y": 2})), "a", 10, 10),
+    "non_dict_points_and_objects": (_cell("7", '"s"', _obj("a", 5, '"t"', "null", {"x": 1, "y": 2}, {"x": 3, "y": 4})), "a", 10, 10),
+    "ptlist_not_a_list": (_cell(_obj("a", *P2(1, 2, 3, 4)), '{"name": "a", "polygon": {"ptList": 5}}', _obj("a", *P2(5, 6, 7, 8))), "a", 10, 10),
+    "polygon_not_a_dict": (_cell(_obj("a", *P2(1, 2, 3, 4)), '{"name": "a", "polygon": [1]}', _obj("a", *P2(5, 6, 7, 8))), "a", 10, 10),
+    "bool_coordinates": (_cell(_obj("a", {"x": "true", "y": "false"}, {"x": 5, "y": 3})), "a", 10, 10),
+    "big_int_coordinates": (_cell(_obj("a", *P2(9007199254740993, 1, 9007199254740997, 3))), "a", 4, 4),
+    "int_beyond_2_pow_52": (_cell(_obj("a", *P2(4503599627370497, 1, 4503599627370499, 3))), "a", 3, 4),
+    "numeric_name": (_cell(_obj(7, *P2(1, 2, 3, 4))), "7", 10, 10),
+    "name_missing_or_empty": (_cell(_obj(None, *P2(1, 2, 3, 4)), _obj("", *P2(1, 2, 3, 4))), "a", 10, 10),
+    "objects_not_a_list": ('{"objects": {"name": "a"}}', "a", 10, 10),
+    "top_level_list": ('[1, 2]', "a", 10, 10),
+    "undecodable": ('{"objects": [', "a", 10, 10),
+    "duplicate_keys_last_wins": (_cell('{"name": "b", "name": "a", "polygon": {"ptList": [{"x": 1, "y": 2, "x": 4}, {"x": 3, "y": 4}]}}'), "a", 10, 10),
+    "two_digit_class": (_cell(_obj("zz", *P2(1, 2, 3, 4))), "zz", 10, 10),
+}
+
+
+def run_reference_yolo(frames, seed=42):
+    """generate_yolo_datasets_from_excels on in-memory sheets ({split: frame}), Excel layer stubbed, images
+    local files -> {split: {source: label text}}, skipped records, class list"""
+    import yaml
+    orig = (ref.pd.ExcelFile, ref.pd.read_excel, pd.DataFrame.to_excel)
+    skipped_frames = []
+
+    class XF:
+        def __init__(self, path):
+            self.sheet_names = list(frames)
+
+    def to_excel(self, target, *a, **k):
+        skipped_frames.append(self.copy())
+
+    ref.pd.ExcelFile = XF
+    ref.pd.read_excel = lambda path, sheet_name=None, **k: frames[sheet_name].copy()
+    pd.DataFrame.to_excel = to_excel
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            book = os.path.join(d, "catA.xlsx")
+            open(book, "wb").close()
+            res = ref.generate_yolo_datasets_from_excels([book], os.path.join(d, "out"), download_images=False, random_seed=seed)
+            ds = res["datasets"][0]
+            labels = {}
+            for split in frames:
+                labels[split] = {}
+                for fn in sorted(os.listdir(os.path.join(ds, "labels", split))):
+                    with open(os.path.join(ds, "labels", split, fn), "rb") as f:
+                        labels[split][fn] = f.read().decode("utf-8")
+            names = yaml.safe_load(open(os.path.join(ds, "data.yaml"), encoding="utf-8"))["names"]
+            stats = res["stats"]
+    finally:
+        ref.pd.ExcelFile, ref.pd.read_excel, pd.DataFrame.to_excel = orig
+    return labels, skipped_frames[-1], names, stats
+
+
+def make_yolo():
+    import src.deal_yolo_data.core.utils as ref_utils
+    with tempfile.TemporaryDirectory() as imgdir:
+        rows = []
+        for k, (name, (cell, label, w, h)) in enumerate(YOLO_CASES.items()):
+            img = os.path.join(imgdir, f"case{k:03d}.jpg")
+            open(img, "wb").write(b"x")
+            rows.append({"source": img, "分类标签": label, NEW: cell, "width": w, "height": h})
+        for k in range(12):                              # filler labels so that class ids reach two digits
+            rows.append({"source": os.path.join(imgdir, "none.jpg"), "分类标签": f"k{k:02d}", NEW: _cell(), "width": 1, "height": 1})
+        df = pd.DataFrame(rows)
+        labels, skipped, names, stats = run_reference_yolo({"train": df})
+    cls = {n: i for i, n in enumerate(names)}
+    by_case = {}
+    for fn, text in labels["train"].items():
+        by_case[int(fn[4:7])] = text
+    out = {"classes": names, "cases": {}}
+    for k, (name, (cell, label, w, h)) in enumerate(YOLO_CASES.items()):
+        boxes = ref_utils._extract_boxes_with_labels(cell)
+        out["cases"][name] = {"json": cell, "label": label, "class_id": cls[label], "width": w, "height": h,
+                              "boxes": [list(b) for b in boxes], "text": by_case.get(k)}
+    out["skipped_reasons"] = skipped["reason"].value_counts().to_dict()
+    out["stats"] = stats
+    _dump("yolo_cases.json", out)
+
+
 if __name__ == "__main__":
     make_replace()
     make_iou()
@@ -379,3 +515,4 @@ if __name__ == "__main__":
     make_perm()
     make_split()
     make_e2e()
+    make_yolo()

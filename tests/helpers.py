@@ -36,6 +36,9 @@ class OracleBackend:
     def split_ids(self, cat, perm, cat_off, n_train, n_val):
         return olib.split_ids(cat, perm, cat_off, n_train, n_val)
 
+    def yolo_lines(self, box4, row_off, sel, width, height, class_id):
+        return olib.yolo_lines(box4, row_off, sel, width, height, class_id)
+
 
 def write_csv_text(path, text):
     with open(path, "w", encoding="utf-8-sig", newline="") as f:

@@ -155,3 +155,38 @@ def test_dedup_and_ref_filter_frames_on_both_csv_paths(oracle_backend, tmp_path,
     assert res["1"][1] == res["0"][1]
     want = pd.read_csv(src, encoding="utf-8-sig").drop_duplicates(subset=["source"], keep="first", ignore_index=True)
     pd.testing.assert_frame_equal(res["1"][0][0], want)
+
+
+def test_low_memory_piece_boundaries_are_those_of_the_full_width_file(tmp_path):
+    """pandas infers dtypes per low-memory piece, and the piece size depends on the table width: the light
+    columns must be typed as in the original 5-column file (131072-row pieces), not as a 3-column file."""
+    n, flip = 140000, 135000
+    path = str(tmp_path / "wide.csv")
+    with open(path, "w", encoding="utf-8-sig", newline="") as f:
+        f.write(f"source,{ANN},code,{BBOX},k\n")
+        for r in range(n):
+            code = "007" if r < flip else "abc"
+            f.write(f'u{r},"{{""objects"": []}}",{code},[],{r}\n')
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = pd.read_csv(path, encoding="utf-8-sig")
+        t = fastcsv.read_split(path, [ANN, BBOX])
+    assert t is not None and set(t.heavy) == {ANN, BBOX}
+    assert [type(v) for v in want["code"].iloc[[0, 131071, 131072, flip]]] == [int, int, str, str]      # the premise
+    got = t.light["code"]
+    assert got.dtype == want["code"].dtype
+    assert [type(v) for v in got.iloc[[0, 131071, 131072, flip]]] == [int, int, str, str]
+    assert got.tolist() == want["code"].tolist()
+    pd.testing.assert_frame_equal(fastcsv.frame_from_split(t), want)
+
+
+def test_heavy_column_with_a_number_like_cell_is_left_to_pandas(tmp_path):
+    for cell in ("12", " 1.5 ", "1e3", "True", "-inf", "+7"):
+        path = str(tmp_path / "n.csv")
+        with open(path, "w", encoding="utf-8-sig", newline="") as f:
+            f.write(f"source,{ANN}\na,{{}}\nb,{cell}\nc,not json\n")
+        assert fastcsv.read_split(path, [ANN]) is None, cell
+    with open(path, "w", encoding="utf-8-sig", newline="") as f:
+        f.write(f"source,{ANN}\na,{{}}\nb,truely\nc,not json\nd,1 2 x\n")
+    assert fastcsv.read_split(path, [ANN]) is not None

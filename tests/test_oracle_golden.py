@@ -191,3 +191,32 @@ def test_e2e_chain(tmp_path):
         for name, frame in (("train", tr), ("val", va), ("test", te)):
             want = g["sheets"][f"{cat}.xlsx"][name]
             _frames_equal(frame[want["columns"]], want, (cat, name))
+
+
+# ------------------------------------------------------------------ f4  YOLO label lines
+def _same_value(a, b):
+    if isinstance(a, float) and isinstance(b, float):
+        return (a != a and b != b) or (a == b and np.signbit(a) == np.signbit(b))
+    return type(a) is type(b) and a == b
+
+
+def test_yolo_extract_matches_reference():
+    g = load_golden("yolo_cases.json")
+    for name, c in g["cases"].items():
+        got = osteps.extract_boxes_with_labels(c["json"])
+        assert len(got) == len(c["boxes"]), name
+        for a, b in zip(got, c["boxes"]):
+            assert all(_same_value(x, y) for x, y in zip(a, b)), (name, a, b)
+
+
+def test_yolo_label_text_matches_reference():
+    g = load_golden("yolo_cases.json")
+    reasons = {}
+    for name, c in g["cases"].items():
+        text, why = osteps.yolo_row_text(c["json"], c["label"], c["class_id"], c["width"], c["height"])
+        assert text == c["text"], name
+        if why:
+            reasons[why] = reasons.get(why, 0) + 1
+    filler = 12                                             # filler rows of the fixture: no objects -> no matching box
+    reasons["无匹配标签框"] += filler
+    assert reasons == g["skipped_reasons"]
