@@ -18,7 +18,7 @@ import threading
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libdyd_gfx950.so")
+LIB_PATH = os.environ.get("DYD_LIB_PATH") or os.path.join(_PKG, "libdyd_gfx950.so")   # env: A/B builds of the library
 
 KEEP_FIRST, KEEP_LAST, KEEP_NONE = 0, 1, 2
 _KEEP = {"first": KEEP_FIRST, "last": KEEP_LAST, False: KEEP_NONE}

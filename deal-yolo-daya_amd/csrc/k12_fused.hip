@@ -98,6 +98,8 @@ int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_
               uint8_t *out_high, double *out_max, hipStream_t st);
 void set_k1_variant(int v);
 void set_k2_variant(int v);
+void set_k7_variant(int v);
+void set_k7_trace(void *p);
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
 // 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off),
@@ -163,6 +165,14 @@ int dyd_set_option(const char *key, int64_t value) {
     }
     if (!strcmp(key, "k2_variant")) {
         set_k2_variant((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "k7_variant")) {
+        set_k7_variant((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "k7_trace_ptr")) {   // device buffer of 8 x n_tiles u64 (0 = off)
+        set_k7_trace(reinterpret_cast<void *>(static_cast<intptr_t>(value)));
         return DYD_OK;
     }
     if (!strcmp(key, "fused_variant")) {

@@ -18,13 +18,16 @@
 // text_off = N+1 int64, flag = N u8, text = T bytes (rows back to back, no terminator).
 // Algorithmic bytes per launch: 32*B [+ B] + 4*(N+1) + 16*N + 4*N in, 8*(N+1) + N + T out.  Bound: HBM.
 //
-// One pass: a workgroup takes the next tile of 256 rows from a ticket counter, measures its rows (one row
-// per lane), scans the lengths in the workgroup, obtains the byte offset of the tile with a decoupled
+// One pass: a workgroup takes the next tile of 256 x RPT rows from a ticket counter, measures its rows (RPT rows
+// per lane, the converted numbers of each row's first line stay in registers), scans the lengths in the workgroup, obtains the byte offset of the tile with a decoupled
 // look-back over the tiles before it (one 8-byte {flag, bytes} word per tile, written and polled with
 // agent-scope relaxed atomics; a tile publishes its own byte count before it looks back, so no tile waits
 // for more than the measuring of its predecessors), prints the rows into LDS at the same 16-byte phase as
 // their place in the output, and streams the LDS image out with 16-byte stores.
 #include "dyd_common.h"
+#ifndef K7_EXP
+#define K7_EXP 0
+#endif
 
 namespace dyd {
 
@@ -39,28 +42,53 @@ constexpr int K7_SPIN_LIMIT = 1 << 22;          // polls before a tile gives up 
 enum : uint32_t { K7_FINITE = 0, K7_NAN = 1, K7_INF = 2, K7_EXOTIC = 3 };
 
 struct Num6 {
-    uint64_t q;       // round-half-even(|v| * 10^6) for finite values below 2^43
-    uint32_t kind;
-    uint32_t neg;     // sign bit of v (printed also for -0.0 and for values that round to zero)
+    uint64_t ip;      // integer digits of round-half-even(|v| * 10^6) / 10^6, finite values below 2^43
+    uint32_t fp;      // the six decimals, 0..999999
+    uint32_t meta;    // kind | neg << 2 (sign bit of v: printed also for -0.0 and values that round to zero)
+    __device__ __forceinline__ uint32_t kind() const { return meta & 3u; }
+    __device__ __forceinline__ uint32_t neg() const { return meta >> 2; }
 };
 
-// exact |v| * 10^6 rounded half-to-even
+// round-half-even(a * 10^6) for 0 <= a < 4294, exactly: a * 10^6 = t + e with t the rounded product and e the
+// error term an FMA returns exactly; t = n + f (n integer, f exact).  f != 1/2 is at least ulp(t) >= 2|e| away
+// from one half, so it decides alone; at f == 1/2 the sign of e decides and e == 0 is a true tie.
+__device__ __forceinline__ uint32_t round6(double a) {
+    const double t = a * 1.0e6;
+    const double e = fma(a, 1.0e6, -t);
+    const uint32_t n = (uint32_t)t;
+    const double f = t - (double)n;
+    const bool up = (f > 0.5) || (f == 0.5 && (e > 0.0 || (e == 0.0 && (n & 1u))));
+    return n + (up ? 1u : 0u);
+}
+
+// exact |v| * 10^6 rounded half-to-even, split into integer part and six decimals
 __device__ __forceinline__ Num6 classify(double v) {
     const uint64_t bits = (uint64_t)__double_as_longlong(v);
     Num6 r;
-    r.neg = (uint32_t)(bits >> 63);
-    r.q = 0;
+    const uint32_t neg = (uint32_t)(bits >> 63);
+    r.ip = 0;
+    r.fp = 0;
     const uint32_t ex = (uint32_t)(bits >> 52) & 0x7ffu;
     const uint64_t frac = bits & ((1ull << 52) - 1);
     if (ex == 0x7ffu) {
-        r.kind = frac ? K7_NAN : K7_INF;
+        r.meta = (frac ? K7_NAN : K7_INF) | (neg << 2);
         return r;
     }
     if (ex >= 1023u + 43u) {  // |v| >= 2^43: up to 309 integer digits, printed by the host
-        r.kind = K7_EXOTIC;
+        r.meta = K7_EXOTIC;
         return r;
     }
-    r.kind = K7_FINITE;
+    r.meta = K7_FINITE | (neg << 2);
+#if K7_EXP == 2
+    r.ip = 0; r.fp = (uint32_t)bits & 0xfffffu; return r;
+#endif
+    const double a = __longlong_as_double((long long)(bits & ~(1ull << 63)));
+    if (a < 4294.0) {   // |v| * 10^6 < 2^32
+        const uint32_t q32 = round6(a), i32 = q32 / 1000000u;
+        r.ip = i32;
+        r.fp = q32 - i32 * 1000000u;
+        return r;
+    }
     const uint64_t m = ex ? (frac | (1ull << 52)) : frac;
     const uint32_t s = 1075u - (ex ? ex : 1u);  // |v| = m * 2^-s, 10 <= s <= 1074
     // P = m * 10^6 < 2^73 as (hi, lo)
@@ -87,47 +115,72 @@ __device__ __forceinline__ Num6 classify(double v) {
         const uint64_t half = 1ull << (s - 1);
         up = (rem > half) || (rem == half && (q & 1));
     }
-    r.q = q + (up ? 1 : 0);
+    q += up ? 1 : 0;
+    if ((q >> 32) == 0) {     // |v| < 4294.97: one 32-bit division
+        const uint32_t q32 = (uint32_t)q, i32 = q32 / 1000000u;
+        r.ip = i32;
+        r.fp = q32 - i32 * 1000000u;
+    } else {
+        r.ip = q / 1000000ull;
+        r.fp = (uint32_t)(q - r.ip * 1000000ull);
+    }
     return r;
 }
 
-__device__ __forceinline__ int digits_u64(uint64_t v) {  // v < 10^14
+__device__ __forceinline__ int digits_u32(uint32_t w) {  // w < 10^7
     int n = 1;
-    if (v >= 10000000ull) { v /= 10000000ull; n += 7; }  // now v < 10^7
-    uint32_t w = (uint32_t)v;
     if (w >= 10000u) { w /= 10000u; n += 4; }
     if (w >= 100u) { w /= 100u; n += 2; }
     if (w >= 10u) n += 1;
     return n;
 }
 
+__device__ __forceinline__ int digits_ip(uint64_t v) {  // v < 10^14
+    if (v < 10000000ull) return digits_u32((uint32_t)v);
+    return 7 + digits_u32((uint32_t)(v / 10000000ull));
+}
+
 __device__ __forceinline__ int num_len(const Num6 &n) {
-    if (n.kind == K7_NAN) return 3;
-    if (n.kind == K7_INF) return 3 + (int)n.neg;
-    return (int)n.neg + digits_u64(n.q / 1000000ull) + 7;
+    if (n.kind() == K7_NAN) return 3;
+    if (n.kind() == K7_INF) return 3 + (int)n.neg();
+    return (int)n.neg() + digits_ip(n.ip) + 7;
+}
+
+// decimal digits of w, most significant first, exactly nd of them (zero padded)
+template <class Put>
+__device__ __forceinline__ void put_u32(uint32_t w, int nd, int pos, Put put) {
+    for (int k = nd - 1; k >= 0; --k) {
+        const uint32_t t = w / 10u;
+        put(pos + k, (char)('0' + (int)(w - t * 10u)));
+        w = t;
+    }
 }
 
 template <class Put>
 __device__ __forceinline__ int num_put(const Num6 &n, int pos, Put put) {
-    if (n.kind == K7_NAN) {
+    if (n.kind() == K7_NAN) {
         put(pos, 'n'); put(pos + 1, 'a'); put(pos + 2, 'n');
         return pos + 3;
     }
-    if (n.neg) put(pos++, '-');
-    if (n.kind == K7_INF) {
+    if (n.neg()) put(pos++, '-');
+    if (n.kind() == K7_INF) {
         put(pos, 'i'); put(pos + 1, 'n'); put(pos + 2, 'f');
         return pos + 3;
     }
-    uint64_t ip = n.q / 1000000ull;
-    uint32_t fp = (uint32_t)(n.q - ip * 1000000ull);
-    const int nd = digits_u64(ip);
-    for (int k = nd - 1; k >= 0; --k) {
-        const uint64_t t = ip / 10;
-        put(pos + k, (char)('0' + (int)(ip - t * 10)));
-        ip = t;
+    if (n.ip < 10000000ull) {
+        const int nd = digits_u32((uint32_t)n.ip);
+        put_u32((uint32_t)n.ip, nd, pos, put);
+        pos += nd;
+    } else {
+        const uint32_t top = (uint32_t)(n.ip / 10000000ull);
+        const uint32_t low = (uint32_t)(n.ip - (uint64_t)top * 10000000ull);
+        const int nd = digits_u32(top);
+        put_u32(top, nd, pos, put);
+        put_u32(low, 7, pos + nd, put);
+        pos += nd + 7;
     }
-    pos += nd;
     put(pos, '.');
+    uint32_t fp = n.fp;
 #pragma unroll
     for (int k = 6; k >= 1; --k) {
         const uint32_t t = fp / 10u;
@@ -145,7 +198,8 @@ struct Line {
 
 // the reference's arithmetic for one box (processor.py:1046-1052), first-wins min / max as in CPython
 __device__ __forceinline__ Line box_line(const double *__restrict__ b, double w, double h) {
-    const double ax = b[0], ay = b[1], bx = b[2], by = b[3];
+    const double2 lo2 = *reinterpret_cast<const double2 *>(b), hi2 = *reinterpret_cast<const double2 *>(b + 2);
+    const double ax = lo2.x, ay = lo2.y, bx = hi2.x, by = hi2.y;
     const double x1 = (bx < ax) ? bx : ax, x2 = (bx > ax) ? bx : ax;
     const double y1 = (by < ay) ? by : ay, y2 = (by > ay) ? by : ay;
     const double dx = x2 - x1, dy = y2 - y1;
@@ -155,11 +209,19 @@ __device__ __forceinline__ Line box_line(const double *__restrict__ b, double w,
     l.exotic = false;
     l.valid = !(bw <= 0.0 || bh <= 0.0);
     if (!l.valid) return l;
+#if K7_EXP == 1
+    l.v[0] = classify((x1 + x2) * 0.5 * w);
+    l.v[1] = classify((y1 + y2) * 0.5 * h);
+    l.v[2] = classify(bw * w);
+    l.v[3] = classify(bh * h);
+#else
     l.v[0] = classify((x1 + x2) / 2.0 / w);
     l.v[1] = classify((y1 + y2) / 2.0 / h);
     l.v[2] = classify(bw / w);
     l.v[3] = classify(bh / h);
-    l.exotic = l.v[0].kind == K7_EXOTIC || l.v[1].kind == K7_EXOTIC || l.v[2].kind == K7_EXOTIC || l.v[3].kind == K7_EXOTIC;
+#endif
+    l.exotic = l.v[0].kind() == K7_EXOTIC || l.v[1].kind() == K7_EXOTIC || l.v[2].kind() == K7_EXOTIC ||
+               l.v[3].kind() == K7_EXOTIC;
     return l;
 }
 
@@ -172,6 +234,22 @@ __device__ __forceinline__ int cid_digits(uint32_t c) {
     return n;
 }
 
+__device__ __forceinline__ int line_len(const Line &l, int cd) {
+    return cd + 4 + num_len(l.v[0]) + num_len(l.v[1]) + num_len(l.v[2]) + num_len(l.v[3]);
+}
+
+template <class Put>
+__device__ __forceinline__ int line_put(const Line &l, uint32_t cid, int cd, int pos, Put put) {
+    put_u32(cid, cd, pos, put);
+    pos += cd;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        put(pos++, ' ');
+        pos = num_put(l.v[k], pos, put);
+    }
+    return pos;
+}
+
 struct RowIn {
     int32_t b0, b1;
     double w, h;
@@ -179,12 +257,81 @@ struct RowIn {
     bool host;   // zero width / height or negative class id: the host decides
 };
 
-// bytes of the row's text; flag: 0 text, 1 no line, 2 host
-__device__ __forceinline__ uint32_t row_measure(const RowIn &r, const double *__restrict__ box4,
-                                                const uint8_t *__restrict__ sel, uint32_t &flag) {
+struct RowState {   // what the measuring pass keeps for the printing pass
+    uint32_t q[4];  // plain rows: the four values as round(v * 10^6) < 10^7
+    uint32_t len;   // bytes of the row's text
+    uint32_t flag;  // 0 text, 1 no line, 2 host
+};
+
+// A PLAIN row is the everyday one: a single box that gives a line whose four values are finite and print with
+// one integer digit ("d.dddddd" or "-d.dddddd"); its line is cd + 36 bytes plus the minus signs.  Lanes holding a
+// plain row keep the four rounded values (bit 31 = sign) and print them straight; the other lanes go through
+// row_measure / row_print below.
+__device__ __forceinline__ bool plain_row(const RowIn &r, const double *__restrict__ box4,
+                                          const uint8_t *__restrict__ sel, uint32_t q[4]) {
+    q[0] = q[1] = q[2] = q[3] = 0;
+    if (r.host || r.b1 - r.b0 != 1 || (uint32_t)r.cid >= 100u) return false;
+    if (sel && !sel[r.b0]) return false;
+    const double *b = box4 + 4 * (int64_t)r.b0;
+    const double2 lo2 = *reinterpret_cast<const double2 *>(b), hi2 = *reinterpret_cast<const double2 *>(b + 2);
+    const double ax = lo2.x, ay = lo2.y, bx = hi2.x, by = hi2.y;
+    const double x1 = (bx < ax) ? bx : ax, x2 = (bx > ax) ? bx : ax;
+    const double y1 = (by < ay) ? by : ay, y2 = (by > ay) ? by : ay;
+    const double bw = x2 - x1, bh = y2 - y1;            // max(d, 0.0) == d for the d > 0 accepted here
+    bool ok = (bw > 0.0) && (bh > 0.0);
+    const double v[4] = {(x1 + x2) / 2.0 / r.w, (y1 + y2) / 2.0 / r.h, bw / r.w, bh / r.h};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double a = fabs(v[k]);
+        const bool in_range = a < 9.9999994;             // false for NaN
+        ok = ok && in_range;
+        q[k] = round6(in_range ? a : 0.0) | ((uint32_t)((uint64_t)__double_as_longlong(v[k]) >> 63) << 31);
+    }
+    return ok;
+}
+
+// "d.dddddd" for q < 10^7
+template <class Put>
+__device__ __forceinline__ void put_plain(uint32_t q, int pos, Put put) {
+    const uint32_t d0 = q / 1000000u, fp = q - d0 * 1000000u;
+    const uint32_t ab = fp / 10000u, rest = fp - ab * 10000u;
+    const uint32_t cd = rest / 100u, ef = rest - cd * 100u;
+    const uint32_t a = (ab * 103u) >> 10, c = (cd * 103u) >> 10, e = (ef * 103u) >> 10;   // tens digit of a pair < 100
+    put(pos, (char)('0' + d0));
+    put(pos + 1, '.');
+    put(pos + 2, (char)('0' + a));
+    put(pos + 3, (char)('0' + (ab - a * 10u)));
+    put(pos + 4, (char)('0' + c));
+    put(pos + 5, (char)('0' + (cd - c * 10u)));
+    put(pos + 6, (char)('0' + e));
+    put(pos + 7, (char)('0' + (ef - e * 10u)));
+}
+
+__device__ __forceinline__ uint32_t plain_len(const RowIn &r, const uint32_t q[4]) {
+    return ((uint32_t)r.cid >= 10u ? 38u : 37u) + (q[0] >> 31) + (q[1] >> 31) + (q[2] >> 31) + (q[3] >> 31);
+}
+
+template <class Put>
+__device__ __forceinline__ void plain_print(const RowIn &r, const RowState &st, Put put) {
+    const uint32_t cid = (uint32_t)r.cid, tens = (cid * 103u) >> 10;
+    int pos = 0;
+    if (cid >= 10u) put(pos++, (char)('0' + tens));
+    put(pos++, (char)('0' + (cid - tens * 10u)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        put(pos++, ' ');
+        if (st.q[k] >> 31) put(pos++, '-');
+        put_plain(st.q[k] & 0x7fffffffu, pos, put);
+        pos += 8;
+    }
+}
+
+__device__ __forceinline__ void row_measure(const RowIn &r, const double *__restrict__ box4,
+                                            const uint8_t *__restrict__ sel, RowState &st) {
+    st.len = 0;
     if (r.host) {
-        flag = 2;
-        return 0;
+        st.flag = 2;
+        return;
     }
     uint32_t len = 0, lines = 0;
     const int cd = cid_digits((uint32_t)r.cid);
@@ -193,42 +340,32 @@ __device__ __forceinline__ uint32_t row_measure(const RowIn &r, const double *__
         const Line l = box_line(box4 + 4 * (int64_t)b, r.w, r.h);
         if (!l.valid) continue;
         if (l.exotic) {
-            flag = 2;
-            return 0;
+            st.flag = 2;
+            return;
         }
-        len += (uint32_t)(cd + 4 + num_len(l.v[0]) + num_len(l.v[1]) + num_len(l.v[2]) + num_len(l.v[3]));
+        len += (uint32_t)line_len(l, cd);
         ++lines;
     }
-    flag = lines ? 0 : 1;
-    return lines ? len + lines - 1 : 0;
+    st.flag = lines ? 0 : 1;
+    st.len = lines ? len + lines - 1 : 0;
 }
 
 template <class Put>
 __device__ __forceinline__ void row_print(const RowIn &r, const double *__restrict__ box4,
                                           const uint8_t *__restrict__ sel, Put put) {
-    int pos = 0;
     const int cd = cid_digits((uint32_t)r.cid);
-    for (int32_t b = r.b0; b < r.b1; ++b) {
+    int pos = 0;
+    for (int32_t b = r.b0; b < r.b1; ++b) {   // the lines are converted again: this path is the rare one
         if (sel && !sel[b]) continue;
         const Line l = box_line(box4 + 4 * (int64_t)b, r.w, r.h);
         if (!l.valid) continue;
         if (pos) put(pos++, '\n');
-        uint32_t c = (uint32_t)r.cid;
-        for (int k = cd - 1; k >= 0; --k) {
-            const uint32_t t = c / 10u;
-            put(pos + k, (char)('0' + (int)(c - t * 10u)));
-            c = t;
-        }
-        pos += cd;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            put(pos++, ' ');
-            pos = num_put(l.v[k], pos, put);
-        }
+        pos = line_put(l, (uint32_t)r.cid, cd, pos, put);
     }
 }
 
 // state[0] = ticket counter, state[1] = error word, state[2 + t] = look-back word of tile t
+template <int RPT, int GROUP>
 __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restrict__ box4,
                                                            const int32_t *__restrict__ row_off,
                                                            const uint8_t *__restrict__ sel,
@@ -237,53 +374,105 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restr
                                                            const int32_t *__restrict__ class_id, int64_t n_rows,
                                                            int64_t *__restrict__ text_off,
                                                            uint8_t *__restrict__ flag_out, uint8_t *text,
-                                                           int64_t text_cap, unsigned long long *state) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_text[K7_LDS_TEXT + 16];
-    __shared__ uint32_t s_wave[K7_WAVES];
+                                                           int64_t text_cap, unsigned long long *state,
+                                                           unsigned long long *trace) {
+    constexpr int TILE = K7_BLOCK * RPT;
+    __shared__ __attribute__((aligned(16))) unsigned char s_text[K7_LDS_TEXT + 32];
+    __shared__ uint32_t s_wave[RPT][K7_WAVES];
     __shared__ unsigned long long s_bcast[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_bcast[0] = atomicAdd(&state[0], 1ull);
-    __syncthreads();
-    const int64_t tile = (int64_t)s_bcast[0];
+    // one ticket serves GROUP consecutive tiles: a single counter word sustains ~88 tickets per microsecond
+    const int64_t ticket = (int64_t)blockIdx.x;   // EXPERIMENT: dispatch order
     unsigned long long *words = state + 2;
-    const int64_t row = tile * K7_BLOCK + tid;
+    const int64_t n_tiles = (n_rows + TILE - 1) / TILE;
+  for (int g = 0; g < GROUP; ++g) {
+    const int64_t tile = ticket * GROUP + g;
+    if (tile >= n_tiles) break;
+    const int64_t row0 = tile * TILE + tid;   // the thread's rows are row0 + k * K7_BLOCK
+#define K7_STAMP(i) do { if (trace && tid == 0) trace[tile * 8 + (i)] = wall_clock64(); } while (0)
+    K7_STAMP(0);
 
     // ---- measure --------------------------------------------------------------------------------
-    RowIn r;
-    uint32_t len = 0, flag = 0;
-    const bool live = row < n_rows;
-    if (live) {
-        r.b0 = row_off[row];
-        r.b1 = row_off[row + 1];
-        r.w = width[row];
-        r.h = height[row];
-        r.cid = class_id[row];
-        r.host = (r.w == 0.0) || (r.h == 0.0) || (r.cid < 0);
-        len = row_measure(r, box4, sel, flag);
-    }
-    // ---- exclusive scan of len in the workgroup ---------------------------------------------------
-    uint32_t incl = len;
+    RowIn r[RPT];
+    RowState st[RPT];
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = row0 + (int64_t)k * K7_BLOCK;
+        r[k].b0 = r[k].b1 = 0;
+        r[k].w = r[k].h = 1.0;
+        r[k].cid = 0;
+        if (row < n_rows) {
+            r[k].b0 = row_off[row];
+            r[k].b1 = row_off[row + 1];
+            r[k].w = width[row];
+            r[k].h = height[row];
+            r[k].cid = class_id[row];
+        }
+        r[k].host = (r[k].w == 0.0) || (r[k].h == 0.0) || (r[k].cid < 0);
     }
-    if (lane == kWave - 1) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0, tile_bytes = 0;
+    K7_STAMP(1);
+    bool plain[RPT];
 #pragma unroll
-    for (int w = 0; w < K7_WAVES; ++w) {
-        if (w < wave) wave_base += s_wave[w];
-        tile_bytes += s_wave[w];
+    for (int k = 0; k < RPT; ++k) {
+        const bool live = row0 + (int64_t)k * K7_BLOCK < n_rows;
+        plain[k] = live && plain_row(r[k], box4, sel, st[k].q);
+        if (plain[k]) {
+            st[k].len = plain_len(r[k], st[k].q);
+            st[k].flag = 0;
+        } else {
+            row_measure(r[k], box4, sel, st[k]);
+            if (!live) st[k].len = 0;
+        }
     }
-    const uint32_t toff = wave_base + incl - len;
+    if (trace && tid == 0) trace[tile * 8 + 7] = (unsigned long long)plain[0] | ((unsigned long long)plain[RPT - 1] << 1);
+    K7_STAMP(2);
 
+    // ---- exclusive scan of the lengths in row order (k major) ------------------------------------------
+    uint32_t incl[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        incl[k] = st[k].len;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t up = __shfl_up(incl[k], d);
+            if (lane >= d) incl[k] += up;
+        }
+        if (lane == kWave - 1) s_wave[k][wave] = incl[k];
+    }
+    __syncthreads();
+    uint32_t toff[RPT], tile_bytes = 0;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        uint32_t before = tile_bytes;
+#pragma unroll
+        for (int w = 0; w < K7_WAVES; ++w) {
+            if (w < wave) before += s_wave[k][w];
+            tile_bytes += s_wave[k][w];
+        }
+        toff[k] = before + incl[k] - st[k].len;
+    }
+
+    K7_STAMP(3);
+    // the tile's own byte count goes out first: the tiles after this one need only that to move on
+    if (tid == 0) {
+        const unsigned long long mine = (tile == 0 ? K7_FLAG_PFX : K7_FLAG_AGG) | (unsigned long long)tile_bytes;
+        __hip_atomic_store(&words[tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- print into LDS at tile-relative offsets while the words of the earlier tiles arrive ----------
+    const bool staged = text && tile_bytes && tile_bytes <= (uint32_t)K7_LDS_TEXT;
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            unsigned char *mine = s_text + toff[k];
+            if (plain[k])
+                plain_print(r[k], st[k], [&](int p, char c) { mine[p] = (unsigned char)c; });
+            else if (st[k].len)
+                row_print(r[k], box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
+        }
+    }
+    K7_STAMP(4);
     // ---- decoupled look-back (wave 0) -------------------------------------------------------------
     if (wave == 0) {
-        if (lane == 0) {
-            const unsigned long long mine = (tile == 0 ? K7_FLAG_PFX : K7_FLAG_AGG) | (unsigned long long)tile_bytes;
-            __hip_atomic_store(&words[tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         unsigned long long base = 0;
         int64_t look = tile - 1;      // nearest tile not yet accounted for
         bool failed = false;
@@ -327,56 +516,90 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restr
     }
     __syncthreads();
     const int64_t base = (int64_t)s_bcast[1];
+    K7_STAMP(5);
 
-    if (live) {
-        text_off[row] = base + toff;
-        flag_out[row] = (uint8_t)flag;
-        if (row == n_rows - 1) text_off[n_rows] = base + toff + len;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = row0 + (int64_t)k * K7_BLOCK;
+        if (row < n_rows) {
+            text_off[row] = base + toff[k];
+            flag_out[row] = (uint8_t)st[k].flag;
+            if (row == n_rows - 1) text_off[n_rows] = base + toff[k] + st[k].len;
+        }
     }
-    if (!text || tile_bytes == 0) return;
+    if (!text || tile_bytes == 0) continue;
     if (base + (int64_t)tile_bytes > text_cap) {   // the host sees the total in text_off[n_rows] and reports it
         if (tid == 0) atomicExch(&state[1], 2ull);
-        return;
+        continue;
     }
     unsigned char *dst = text + base;
-    if (tile_bytes <= (uint32_t)K7_LDS_TEXT) {
+    if (staged) {
+        // dst[i] = s_text[i].  The 16-byte store k goes to the aligned address dst - phase + 16k and takes the LDS
+        // bytes from 16k - phase on: five aligned dwords funnel-shifted by (-phase) & 3 bytes.
         const uint32_t phase = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
-        if (live && len) {
-            unsigned char *mine = s_text + phase + toff;
-            row_print(r, box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
-        }
-        __syncthreads();
-        // s_text[phase + i] -> dst[i]; 16-byte chunk k of the LDS image maps to the aligned address dst - phase + 16k
         const uint32_t end = phase + tile_bytes;
         const uint32_t n_chunks = (end + 15u) >> 4;
         unsigned char *aligned = dst - phase;
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s_text);
+        const uint32_t sh = (0u - phase) & 3u;
         for (uint32_t k = tid; k < n_chunks; k += K7_BLOCK) {
             const uint32_t lo = k << 4, hi = lo + 16u;
             if (lo >= phase && hi <= end) {
-                *reinterpret_cast<uint4 *>(aligned + lo) = *reinterpret_cast<const uint4 *>(s_text + lo);
+                const uint32_t m = (lo - phase) >> 2;
+                const uint32_t d0 = s32[m], d1 = s32[m + 1], d2 = s32[m + 2], d3 = s32[m + 3], d4 = s32[m + 4];
+                uint4 v;
+                v.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                v.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                v.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                v.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                *reinterpret_cast<uint4 *>(aligned + lo) = v;
             } else {
                 const uint32_t a = lo < phase ? phase : lo, b = hi > end ? end : hi;
-                for (uint32_t i = a; i < b; ++i) aligned[i] = s_text[i];
+                for (uint32_t i = a; i < b; ++i) aligned[i] = s_text[i - phase];
             }
         }
-    } else if (live && len) {   // a tile of very long rows: print straight to memory
-        unsigned char *mine = dst + toff;
-        row_print(r, box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
+        K7_STAMP(6);
+    } else {   // a tile of very long rows: print straight to memory
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            unsigned char *mine = dst + toff[k];
+            if (plain[k])
+                plain_print(r[k], st[k], [&](int p, char c) { mine[p] = (unsigned char)c; });
+            else if (st[k].len)
+                row_print(r[k], box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
+        }
     }
+    if (GROUP > 1) __syncthreads();   // the LDS image is reused by the next tile of the ticket
+  }  // tiles of the ticket
 }
+
+static int g_k7_rpt = 2;
+static unsigned long long *g_k7_trace = nullptr;   // tuning hook: 8 timestamps per tile
+void set_k7_trace(void *p) { g_k7_trace = static_cast<unsigned long long *>(p); }   // rows per lane (dyd_set_option "k7_variant": 1, 2 or 4)
+void set_k7_variant(int v) { g_k7_rpt = (v == 1 || v == 4) ? v : 2; }
 
 static int yolo_launch(const double *box4, const int32_t *row_off, const uint8_t *sel, const double *width,
                        const double *height, const int32_t *class_id, int64_t n_rows, int64_t *text_off,
                        uint8_t *flag, uint8_t *text, int64_t text_cap, int64_t *total_out, hipStream_t st) {
-    const int64_t n_tiles = ceil_div(n_rows, K7_BLOCK);
+    const int rpt = g_k7_rpt;
+    const int64_t n_tiles = ceil_div(n_rows, (int64_t)K7_BLOCK * rpt);
     void *scr = nullptr;
     const size_t state_bytes = (size_t)(n_tiles + 2) * 8;
     int rc = get_scratch(state_bytes, &scr, st);
     if (rc) return rc;
     DYD_HIP(hipMemsetAsync(scr, 0, state_bytes, st));
-    hipLaunchKernelGGL(k7_yolo_kernel, dim3((unsigned)n_tiles), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width,
-                       height, class_id, n_rows, text_off, flag, text, text_cap,
-                       static_cast<unsigned long long *>(scr));
+    unsigned long long *state = static_cast<unsigned long long *>(scr);
+    constexpr int GROUP = 1;
+    const unsigned blocks = (unsigned)ceil_div(n_tiles, GROUP);
+    if (rpt == 1)
+        hipLaunchKernelGGL((k7_yolo_kernel<1, GROUP>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+                           class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
+    else if (rpt == 4)
+        hipLaunchKernelGGL((k7_yolo_kernel<4, GROUP>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+                           class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
+    else
+        hipLaunchKernelGGL((k7_yolo_kernel<2, GROUP>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+                           class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
     DYD_HIP(hipGetLastError());
     unsigned long long err = 0;
     int64_t total = 0;

@@ -164,6 +164,38 @@ def main():
                                                          pos.data_ptr(), sp), "k6"))
         report("k6_split_ids", 21 * E, med, mn, expanded_rows=E, rows_per_s=round(E / med * 1e3))
 
+    if "k7" in only:
+        import ctypes as C
+        # the shape of a split sheet: one labelled box per expanded row; boxes = K1's output for the synthetic polygons
+        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
+        E = B
+        one = torch.arange(E + 1, dtype=torch.int32, device=dev)
+        w = torch.full((E,), 1920.0, dtype=torch.float64, device=dev); h = torch.full((E,), 1080.0, dtype=torch.float64, device=dev)
+        cid = (torch.arange(E, device=dev, dtype=torch.int32) % 20).contiguous()
+        toff = torch.empty(E + 1, dtype=torch.int64, device=dev); flag = torch.empty(E, dtype=torch.uint8, device=dev)
+        total = C.c_int64()
+        ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), E,
+                                toff.data_ptr(), flag.data_ptr(), None, 0, C.byref(total), sp), "k7 measure")
+        T = total.value
+        text = torch.empty(T, dtype=torch.uint8, device=dev)
+        import os
+        modes = os.environ.get("K7MODE", "full,measure").split(",")
+        for variant in [int(v) for v in os.environ.get("K7V", "1,2,4").split(",")]:
+            ck(L.dyd_set_option(b"k7_variant", variant), "opt")
+            if "full" in modes:
+              med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
+                                                              cid.data_ptr(), E, toff.data_ptr(), flag.data_ptr(), text.data_ptr(), T,
+                                                              C.byref(total), sp), "k7"))
+              report(f"k7_yolo_lines_rpt{variant}", 32 * E + 4 * (E + 1) + 20 * E + 8 * (E + 1) + E + T, med, mn, rows=E, text_bytes=T,
+                   rows_per_s=round(E / med * 1e3), no_line_rows=int((flag == 1).sum().item()))
+            if "measure" not in modes:
+                continue
+            med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
+                                                              cid.data_ptr(), E, toff.data_ptr(), flag.data_ptr(), None, 0,
+                                                              C.byref(total), sp), "k7"))
+            report(f"k7_measure_only_rpt{variant}", 32 * E + 4 * (E + 1) + 20 * E + 8 * (E + 1) + E, med, mn, rows=E)
+        ck(L.dyd_set_option(b"k7_variant", 2), "opt")
+
 
 if __name__ == "__main__":
     main()
