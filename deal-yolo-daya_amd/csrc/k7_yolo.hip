@@ -25,9 +25,6 @@
 // for more than the measuring of its predecessors), prints the rows into LDS at the same 16-byte phase as
 // their place in the output, and streams the LDS image out with 16-byte stores.
 #include "dyd_common.h"
-#ifndef K7_EXP
-#define K7_EXP 0
-#endif
 
 namespace dyd {
 
@@ -79,9 +76,6 @@ __device__ __forceinline__ Num6 classify(double v) {
         return r;
     }
     r.meta = K7_FINITE | (neg << 2);
-#if K7_EXP == 2
-    r.ip = 0; r.fp = (uint32_t)bits & 0xfffffu; return r;
-#endif
     const double a = __longlong_as_double((long long)(bits & ~(1ull << 63)));
     if (a < 4294.0) {   // |v| * 10^6 < 2^32
         const uint32_t q32 = round6(a), i32 = q32 / 1000000u;
@@ -209,17 +203,10 @@ __device__ __forceinline__ Line box_line(const double *__restrict__ b, double w,
     l.exotic = false;
     l.valid = !(bw <= 0.0 || bh <= 0.0);
     if (!l.valid) return l;
-#if K7_EXP == 1
-    l.v[0] = classify((x1 + x2) * 0.5 * w);
-    l.v[1] = classify((y1 + y2) * 0.5 * h);
-    l.v[2] = classify(bw * w);
-    l.v[3] = classify(bh * h);
-#else
     l.v[0] = classify((x1 + x2) / 2.0 / w);
     l.v[1] = classify((y1 + y2) / 2.0 / h);
     l.v[2] = classify(bw / w);
     l.v[3] = classify(bh / h);
-#endif
     l.exotic = l.v[0].kind() == K7_EXOTIC || l.v[1].kind() == K7_EXOTIC || l.v[2].kind() == K7_EXOTIC ||
                l.v[3].kind() == K7_EXOTIC;
     return l;
@@ -365,7 +352,7 @@ __device__ __forceinline__ void row_print(const RowIn &r, const double *__restri
 }
 
 // state[0] = ticket counter, state[1] = error word, state[2 + t] = look-back word of tile t
-template <int RPT, int GROUP>
+template <int RPT>
 __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restrict__ box4,
                                                            const int32_t *__restrict__ row_off,
                                                            const uint8_t *__restrict__ sel,
@@ -381,13 +368,15 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restr
     __shared__ uint32_t s_wave[RPT][K7_WAVES];
     __shared__ unsigned long long s_bcast[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // one ticket serves GROUP consecutive tiles: a single counter word sustains ~88 tickets per microsecond
-    const int64_t ticket = (int64_t)blockIdx.x;   // EXPERIMENT: dispatch order
+    // Tiles are taken in ticket order: every tile before this one is then held by a running or finished workgroup
+    // whatever order the hardware dispatches workgroups in, so waiting for their words below cannot deadlock.
+    // (One counter word sustains ~88 tickets per microsecond; 512-row tiles need ~60.)
+    if (tid == 0) s_bcast[0] = atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_bcast[0];
     unsigned long long *words = state + 2;
     const int64_t n_tiles = (n_rows + TILE - 1) / TILE;
-  for (int g = 0; g < GROUP; ++g) {
-    const int64_t tile = ticket * GROUP + g;
-    if (tile >= n_tiles) break;
+    if (tile >= n_tiles) return;
     const int64_t row0 = tile * TILE + tid;   // the thread's rows are row0 + k * K7_BLOCK
 #define K7_STAMP(i) do { if (trace && tid == 0) trace[tile * 8 + (i)] = wall_clock64(); } while (0)
     K7_STAMP(0);
@@ -527,10 +516,10 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restr
             if (row == n_rows - 1) text_off[n_rows] = base + toff[k] + st[k].len;
         }
     }
-    if (!text || tile_bytes == 0) continue;
+    if (!text || tile_bytes == 0) return;
     if (base + (int64_t)tile_bytes > text_cap) {   // the host sees the total in text_off[n_rows] and reports it
         if (tid == 0) atomicExch(&state[1], 2ull);
-        continue;
+        return;
     }
     unsigned char *dst = text + base;
     if (staged) {
@@ -569,8 +558,6 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restr
                 row_print(r[k], box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
         }
     }
-    if (GROUP > 1) __syncthreads();   // the LDS image is reused by the next tile of the ticket
-  }  // tiles of the ticket
 }
 
 static int g_k7_rpt = 2;
@@ -589,16 +576,15 @@ static int yolo_launch(const double *box4, const int32_t *row_off, const uint8_t
     if (rc) return rc;
     DYD_HIP(hipMemsetAsync(scr, 0, state_bytes, st));
     unsigned long long *state = static_cast<unsigned long long *>(scr);
-    constexpr int GROUP = 1;
-    const unsigned blocks = (unsigned)ceil_div(n_tiles, GROUP);
+    const unsigned blocks = (unsigned)n_tiles;
     if (rpt == 1)
-        hipLaunchKernelGGL((k7_yolo_kernel<1, GROUP>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+        hipLaunchKernelGGL((k7_yolo_kernel<1>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
                            class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
     else if (rpt == 4)
-        hipLaunchKernelGGL((k7_yolo_kernel<4, GROUP>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+        hipLaunchKernelGGL((k7_yolo_kernel<4>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
                            class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
     else
-        hipLaunchKernelGGL((k7_yolo_kernel<2, GROUP>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+        hipLaunchKernelGGL((k7_yolo_kernel<2>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
                            class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
     DYD_HIP(hipGetLastError());
     unsigned long long err = 0;

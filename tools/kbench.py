@@ -180,7 +180,7 @@ def main():
         text = torch.empty(T, dtype=torch.uint8, device=dev)
         import os
         modes = os.environ.get("K7MODE", "full,measure").split(",")
-        for variant in [int(v) for v in os.environ.get("K7V", "1,2,4").split(",")]:
+        for variant in [int(v) for v in os.environ.get("K7V", "2,4").split(",")]:
             ck(L.dyd_set_option(b"k7_variant", variant), "opt")
             if "full" in modes:
               med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
