@@ -34,8 +34,8 @@ from .. import flatten as _fl
 from .. import fastcsv as _fc
 from .. import native_json as _nj
 from ..backend import resolve as _backend
-from .utils import (_extract_boxes_with_labels, _parse_data_objects, _split_label_cell, _split_object_labels,
-                    safe_filename)
+from .utils import (_ensure_image_cached, _extract_boxes_with_labels, _parse_data_objects, _safe_image_stem,
+                    _split_label_cell, _split_object_labels, safe_filename)
 
 ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference processor.py:244
 BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
@@ -805,3 +805,168 @@ def yolo_label_texts(cells, label_values, class_ids, widths, heights, backend=No
     if stats is not None:
         stats.update(rows=n, device_rows=len(dev_rows), python_rows=len(py_rows))
     return texts, reasons
+
+
+def generate_yolo_datasets_from_excels(
+        category_excels: list,
+        output_dir: str,
+        image_cache_dir: Optional[str] = None,
+        source_col: str = "source",
+        label_col: str = "分类标签",
+        json_col_primary: str = BBOX_COL,
+        json_col_fallback: str = ANNOTATION_COL,
+        width_col: str = "width",
+        height_col: str = "height",
+        download_images: bool = True,
+        random_seed: int = 42,
+        class_order: Optional[list] = None,
+        resume: bool = True,
+        progress_callback=None,
+        backend=None,
+):
+    """Drop-in for reference processor.py:893-1093: one YOLO dataset directory per category workbook
+    (images/<split>, labels/<split>, data.yaml) plus yolo_skipped.xlsx.
+
+    Per split sheet the rows are shuffled like ``sample(frac=1, random_state=seed)`` (host MT19937), the label
+    texts of all rows are produced in one batch (``yolo_label_texts`` -> K7) and the per-row side effects (resume
+    check, image copy, label file, skip records) are then replayed in the reference's order.  Rows whose image
+    size comes from the image file rather than from the sheet (:1015-1020) are printed on the host."""
+    import yaml
+
+    be = _backend(backend)
+    output_dir = Path(output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    cache_dir = Path(image_cache_dir) if image_cache_dir else (output_dir / "image_cache")
+    cache_dir.mkdir(parents=True, exist_ok=True)
+
+    datasets, dataset_name_map, skipped, dataset_stats = [], {}, [], {}
+    total_rows = processed_rows = downloaded_images = 0
+    used_dir_names = set()
+    splits = ["train", "val", "test"]
+
+    for excel_path in category_excels:                                   # :917-924
+        if not excel_path or not Path(excel_path).exists():
+            continue
+        book = pd.ExcelFile(excel_path)
+        for split in splits:
+            if split in book.sheet_names:
+                total_rows += len(pd.read_excel(excel_path, sheet_name=split))
+
+    last = None                                                          # arguments of the closing progress call
+    for idx_excel, excel_path in enumerate(category_excels):
+        if not excel_path or not Path(excel_path).exists():
+            continue
+        excel_path = Path(excel_path)
+        category_name = excel_path.stem
+        base_dir_name = safe_filename(str(category_name)) if category_name else f"category_{idx_excel:03d}"
+        dir_name, suffix = base_dir_name, 1
+        while dir_name in used_dir_names:                                # :931-936
+            dir_name = f"{base_dir_name}_{suffix}"
+            suffix += 1
+        used_dir_names.add(dir_name)
+        dataset_dir = output_dir / dir_name
+        dataset_name_map[dataset_dir.name] = category_name
+        images_root, labels_root = dataset_dir / "images", dataset_dir / "labels"
+        for split in splits:
+            (images_root / split).mkdir(parents=True, exist_ok=True)
+            (labels_root / split).mkdir(parents=True, exist_ok=True)
+
+        book = pd.ExcelFile(excel_path)
+        split_sheets = [sp for sp in splits if sp in book.sheet_names]
+        all_labels, frames = [], {}
+        for split in split_sheets:
+            frames[split] = pd.read_excel(excel_path, sheet_name=split)
+            if label_col in frames[split].columns:
+                all_labels.extend(str(v) for v in frames[split][label_col].dropna())
+        classes = sorted(dict.fromkeys(all_labels))                      # :958-963
+        if class_order:
+            head = [c for c in class_order if c in classes]
+            classes = head + [c for c in classes if c not in head]
+        class_to_id = {name: i for i, name in enumerate(classes)}
+        dataset_stats[category_name] = {sp: 0 for sp in splits}
+
+        for split in split_sheets:
+            frame = frames[split]
+            order = be.mt19937_permutation(random_seed, len(frame))      # = sample(frac=1, random_state=seed) (:969)
+            frame = frame.iloc[order].reset_index(drop=True)
+            columns = set(frame.columns)
+            get = lambda name, default=None: (frame[name].tolist() if name in columns else [default] * len(frame))  # noqa: E731
+            sources, widths, heights = get(source_col), get(width_col), get(height_col)
+            labels = [str(v) for v in get(label_col, "")]
+            primary, fallback = get(json_col_primary), get(json_col_fallback)
+            cells = [a or b for a, b in zip(primary, fallback)]          # row.get(primary) or row.get(fallback) (:1004)
+            usable = [bool(src) and bool(lab) and lab in class_to_id for src, lab in zip(sources, labels)]
+            batch = [i for i, ok in enumerate(usable) if ok]
+            texts, reasons = yolo_label_texts([cells[i] for i in batch], [labels[i] for i in batch],
+                                              [class_to_id[labels[i]] for i in batch], [widths[i] for i in batch],
+                                              [heights[i] for i in batch], be)
+            text_of = dict(zip(batch, zip(texts, reasons)))
+
+            for idx in range(len(frame)):
+                last = (processed_rows, total_rows, downloaded_images, category_name, split, f"idx_{idx}", "", excel_path.name, idx)
+                if progress_callback and processed_rows % 50 == 0:
+                    progress_callback(*last)
+                processed_rows += 1                                      # every path below counts the row once
+                source, label_value = sources[idx], labels[idx]
+                if not source:
+                    skipped.append({"category": category_name, "reason": "缺少source", "split": split})
+                    continue
+                if not label_value or label_value not in class_to_id:
+                    skipped.append({"category": category_name, "reason": "缺少或无效分类标签", "split": split})
+                    continue
+                label_path = labels_root / split / f"{_safe_image_stem(str(source), idx)}.txt"
+                if resume and label_path.exists() and label_path.stat().st_size > 0:
+                    dataset_stats[category_name][split] += 1
+                    continue
+                text, reason = text_of[idx]
+                if reason == REASON_NO_MATCHING_BOX:
+                    skipped.append({"category": category_name, "reason": reason, "split": split})
+                    continue
+                image_path = None
+                if download_images:
+                    image_path = _ensure_image_cached(str(source), cache_dir)
+                elif Path(str(source)).exists():
+                    image_path = Path(str(source))
+                width, height = widths[idx], heights[idx]
+                if (not width or not height) and image_path:             # size from the image file (:1015-1020)
+                    try:
+                        from PIL import Image
+                        with Image.open(image_path) as img:
+                            width, height = img.size
+                        boxes = [b for b in _extract_boxes_with_labels(cells[idx]) if b[0] == label_value]
+                        lines = _label_lines_python(boxes, class_to_id[label_value], width, height)
+                        text, reason = ("\n".join(lines), None) if lines else (None, REASON_NO_VALID_BOX)
+                    except Exception:  # noqa: BLE001
+                        pass
+                if not width or not height:
+                    skipped.append({"category": category_name, "reason": REASON_NO_IMAGE_SIZE, "split": split})
+                    continue
+                if not image_path:
+                    skipped.append({"category": category_name, "reason": "图片下载失败", "split": split})
+                    continue
+                out_image = images_root / split / f"{label_path.stem}{image_path.suffix}"
+                if not out_image.exists():
+                    try:
+                        out_image.write_bytes(Path(image_path).read_bytes())
+                        downloaded_images += 1
+                    except Exception:  # noqa: BLE001
+                        skipped.append({"category": category_name, "reason": "图片写入失败", "split": split})
+                        continue
+                if text is not None:
+                    label_path.write_text(text, encoding="utf-8")
+                    dataset_stats[category_name][split] += 1
+                else:
+                    skipped.append({"category": category_name, "reason": REASON_NO_VALID_BOX, "split": split})
+
+        (dataset_dir / "data.yaml").write_text(yaml.dump({
+            "path": str(dataset_dir), "train": "images/train", "val": "images/val", "test": "images/test",
+            "nc": len(classes), "names": classes}, sort_keys=False, allow_unicode=True), encoding="utf-8")
+        datasets.append(dataset_dir)
+
+    skipped_path = output_dir / "yolo_skipped.xlsx"
+    pd.DataFrame(skipped if skipped else [{"category": "无", "reason": "无", "split": "无"}]).to_excel(skipped_path, index=False)
+    if progress_callback and last is not None:
+        # the reference's closing call reads names it never defines (:1076-1077, NameError); report the last row instead
+        progress_callback(processed_rows, *last[1:])
+    return {"datasets": datasets, "skipped": skipped_path, "stats": dataset_stats, "total": total_rows,
+            "processed": processed_rows, "downloaded": downloaded_images, "dataset_name_map": dataset_name_map}

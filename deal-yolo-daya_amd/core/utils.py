@@ -7,6 +7,7 @@ reference's ``core/utils.py`` that sit on the hot path (same names, same results
     safe_filename         reference utils.py:525-529 (names the per-category workbook)
     _extract_boxes_with_labels  reference utils.py:681-710 (labelled boxes of a cell, YOLO step)
     _safe_image_stem      reference utils.py:712-724 (label / image file stem)
+    _ensure_image_cached  reference utils.py:726-748, download_image utils.py:44-55 (image side of the YOLO step)
 """
 from __future__ import annotations
 
@@ -99,3 +100,44 @@ def _safe_image_stem(source_url, idx) -> str:
         return f"{safe_filename(stem)}_{idx}"
     except Exception:  # noqa: BLE001
         return f"img_{idx}"
+
+
+def download_image(url: str, save_path: str) -> bool:
+    """Fetch one image over HTTP (reference utils.py:44-55): True when the file is there afterwards."""
+    import os
+    if os.path.exists(save_path):
+        return True
+    try:
+        import requests
+        response = requests.get(url, stream=True, timeout=15)
+        response.raise_for_status()
+        with open(save_path, "wb") as fh:
+            fh.write(response.content)
+        return True
+    except Exception as exc:  # noqa: BLE001
+        print(f"\n❌ 图片下载失败 {url}：{exc}")
+        return False
+
+
+def _ensure_image_cached(source_url, cache_dir: Path):
+    """Local path -> itself; URL -> cached copy under cache_dir (downloaded once); None on any failure
+    (reference utils.py:726-748)."""
+    if not source_url:
+        return None
+    try:
+        if Path(source_url).exists():
+            return Path(source_url)
+        filename = source_url.split("/")[-1]
+        if "?" in filename:
+            filename = filename.split("?")[0]
+        if not filename:
+            filename = f"image_{hash(source_url)}.jpg"
+        cached = cache_dir / filename
+        if cached.exists() and cached.stat().st_size > 0:
+            return cached
+        download_image(source_url, str(cached))
+        if cached.exists():
+            return cached
+    except Exception:  # noqa: BLE001
+        pass
+    return None

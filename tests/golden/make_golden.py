@@ -445,10 +445,9 @@ YOLO_CASES = {
 }
 
 
-def run_reference_yolo(frames, seed=42):
+def run_reference_yolo(frames, seed=42, **kwargs):
     """generate_yolo_datasets_from_excels on in-memory sheets ({split: frame}), Excel layer stubbed, images
-    local files -> {split: {source: label text}}, skipped records, class list"""
-    import yaml
+    local files -> everything the call leaves behind"""
     orig = (ref.pd.ExcelFile, ref.pd.read_excel, pd.DataFrame.to_excel)
     skipped_frames = []
 
@@ -466,22 +465,25 @@ def run_reference_yolo(frames, seed=42):
         with tempfile.TemporaryDirectory() as d:
             book = os.path.join(d, "catA.xlsx")
             open(book, "wb").close()
-            res = ref.generate_yolo_datasets_from_excels([book], os.path.join(d, "out"), download_images=False, random_seed=seed)
-            ds = res["datasets"][0]
-            labels = {}
-            for split in frames:
-                labels[split] = {}
+            res = ref.generate_yolo_datasets_from_excels([book], os.path.join(d, "out"), download_images=False, random_seed=seed, **kwargs)
+            ds = str(res["datasets"][0])
+            labels, images = {}, {}
+            for split in ("train", "val", "test"):
+                labels[split], images[split] = {}, sorted(os.listdir(os.path.join(ds, "images", split)))
                 for fn in sorted(os.listdir(os.path.join(ds, "labels", split))):
                     with open(os.path.join(ds, "labels", split, fn), "rb") as f:
                         labels[split][fn] = f.read().decode("utf-8")
-            names = yaml.safe_load(open(os.path.join(ds, "data.yaml"), encoding="utf-8"))["names"]
-            stats = res["stats"]
+            yaml_text = open(os.path.join(ds, "data.yaml"), encoding="utf-8").read().replace(ds, "<DATASET>")
+            out = {"labels": labels, "images": images, "data_yaml": yaml_text, "stats": res["stats"], "total": res["total"],
+                   "processed": res["processed"], "downloaded": res["downloaded"], "dataset_name_map": res["dataset_name_map"],
+                   "skipped": json.loads(skipped_frames[-1].to_json(orient="records", force_ascii=False))}
     finally:
         ref.pd.ExcelFile, ref.pd.read_excel, pd.DataFrame.to_excel = orig
-    return labels, skipped_frames[-1], names, stats
+    return out
 
 
 def make_yolo():
+    import yaml
     import src.deal_yolo_data.core.utils as ref_utils
     with tempfile.TemporaryDirectory() as imgdir:
         rows = []
@@ -492,18 +494,52 @@ def make_yolo():
         for k in range(12):                              # filler labels so that class ids reach two digits
             rows.append({"source": os.path.join(imgdir, "none.jpg"), "分类标签": f"k{k:02d}", NEW: _cell(), "width": 1, "height": 1})
         df = pd.DataFrame(rows)
-        labels, skipped, names, stats = run_reference_yolo({"train": df})
+        run = run_reference_yolo({"train": df})
+        # a second, three-sheet run: fallback column, missing source / label, image-less rows, resume files
+        t = synth.generate(40, seed=11, max_boxes=3)
+        base = synth.to_frame(t)
+        recs = []
+        for i in range(len(base)):
+            doc = json.loads(base.loc[i, ANN])
+            for j, obj in enumerate(doc["objects"][:2]):
+                pts = obj["polygon"]["ptList"]
+                xs, ys = [p["x"] for p in pts], [p["y"] for p in pts]
+                one = dict(obj, polygon={"ptList": [{"x": min(xs), "y": min(ys)}, {"x": max(xs), "y": max(ys)}]})
+                img = os.path.join(imgdir, f"pic{i:02d}_{j}.png")
+                open(img, "wb").write(b"png")
+                recs.append({"source": img, "分类标签": obj["name"], NEW: json.dumps({"objects": [one]}, ensure_ascii=False),
+                             ANN: base.loc[i, ANN], "width": doc["width"], "height": doc["height"]})
+        sheet = pd.DataFrame(recs)
+        sheet.loc[0, "source"] = None                      # 缺少source
+        sheet.loc[1, "分类标签"] = np.nan                   # "nan" is not a class
+        sheet.loc[2, NEW] = np.nan                         # NaN is truthy: no fallback, no box
+        sheet.loc[3, NEW] = None                           # falls back to the original polygon column
+        sheet.loc[4, "source"] = os.path.join(imgdir, "missing.jpg")     # no image on disk
+        sheet.loc[5, "width"] = 0
+        n = len(sheet)
+        frames3 = {"train": sheet.iloc[: n * 6 // 10].reset_index(drop=True), "val": sheet.iloc[n * 6 // 10: n * 8 // 10].reset_index(drop=True),
+                   "test": sheet.iloc[n * 8 // 10:].reset_index(drop=True)}
+        run3 = run_reference_yolo(frames3, seed=7, class_order=["c5", "c3", "zzz"])
+        nan_mark = lambda f: f.apply(lambda col: col.map(lambda v: "__NaN__" if isinstance(v, float) and v != v else v))  # noqa: E731
+        frames3_json = {k: json.loads(nan_mark(v.assign(source=v["source"].map(lambda p: os.path.basename(p) if isinstance(p, str) else p)))
+                                       .to_json(orient="split", force_ascii=False)) for k, v in frames3.items()}
+    names = yaml.safe_load(run["data_yaml"])["names"]
     cls = {n: i for i, n in enumerate(names)}
     by_case = {}
-    for fn, text in labels["train"].items():
+    for fn, text in run["labels"]["train"].items():
         by_case[int(fn[4:7])] = text
     out = {"classes": names, "cases": {}}
     for k, (name, (cell, label, w, h)) in enumerate(YOLO_CASES.items()):
         boxes = ref_utils._extract_boxes_with_labels(cell)
         out["cases"][name] = {"json": cell, "label": label, "class_id": cls[label], "width": w, "height": h,
                               "boxes": [list(b) for b in boxes], "text": by_case.get(k)}
-    out["skipped_reasons"] = skipped["reason"].value_counts().to_dict()
-    out["stats"] = stats
+    reasons = {}
+    for r in run["skipped"]:
+        reasons[r["reason"]] = reasons.get(r["reason"], 0) + 1
+    out["skipped_reasons"] = reasons
+    out["stats"] = run["stats"]
+    out["run"] = run                                       # the whole single-sheet run (file names, yaml, skipped order)
+    out["run3"] = {"frames": frames3_json, "seed": 7, "class_order": ["c5", "c3", "zzz"], "result": run3}
     _dump("yolo_cases.json", out)
 
 

@@ -242,3 +242,10 @@ def test_k7_full_size_properties(native):
         x1, y1, x2, y2 = hb[i].tolist()
         want = f"{hc[i]} {(x1 + x2) / 2 / 1920.0:.6f} {(y1 + y2) / 2 / 1080.0:.6f} {max(x2 - x1, 0.0) / 1920.0:.6f} {max(y2 - y1, 0.0) / 1080.0:.6f}"
         assert ht[ho[i]:ho[i + 1]].tobytes().decode() == want, i
+
+
+def test_generate_yolo_datasets_on_the_device(native, tmp_path):
+    """the whole step (label files, images, data.yaml, skip records) equals the reference run of the fixture"""
+    import test_yolo_host_cpu as host
+    got = host.check_yolo_step(tmp_path, None)
+    assert sum(got["stats"]["catA"].values()) > 30

@@ -63,3 +63,97 @@ def test_image_stem():
     # values observed from the reference's _safe_image_stem (utils.py:712-724)
     assert U._safe_image_stem("http://h/p/?q=1", 2) == "train_2" and U._safe_image_stem("http://h/x.jpg?a=b.c", 1) == "x.jpg_1"
     assert U._safe_image_stem("/tmp/a/case003.jpg", 9) == "case003_9" and U._safe_image_stem(12.5, 3) == "12_3"
+
+
+# ------------------------------------------------------------------ the whole step, Excel layer stubbed
+class _Sheets:
+    """in-memory stand-in for the Excel layer (openpyxl is not installed), as tests/golden/make_golden.py uses"""
+
+    def __init__(self, frames):
+        self.frames, self.written = frames, []
+
+    def __enter__(self):
+        import pandas as pd
+        self.orig = (P.pd.ExcelFile, P.pd.read_excel, pd.DataFrame.to_excel)
+        frames, written = self.frames, self.written
+
+        class XF:
+            def __init__(self, path):
+                self.sheet_names = list(frames)
+
+        P.pd.ExcelFile = XF
+        P.pd.read_excel = lambda path, sheet_name=None, **k: frames[sheet_name].copy()
+        pd.DataFrame.to_excel = lambda self_df, target, *a, **k: written.append(self_df.copy())
+        return self
+
+    def __exit__(self, *exc):
+        import pandas as pd
+        P.pd.ExcelFile, P.pd.read_excel, pd.DataFrame.to_excel = self.orig
+        return False
+
+
+def run_product_yolo(frames, tmp_path, backend, **kwargs):
+    import os
+    book = tmp_path / "catA.xlsx"
+    book.write_bytes(b"")
+    with _Sheets(frames) as sheets:
+        res = P.generate_yolo_datasets_from_excels([str(book)], str(tmp_path / "out"), download_images=False, backend=backend, **kwargs)
+    ds = str(res["datasets"][0])
+    labels, images = {}, {}
+    for split in ("train", "val", "test"):
+        images[split] = sorted(os.listdir(os.path.join(ds, "images", split)))
+        labels[split] = {fn: open(os.path.join(ds, "labels", split, fn), "rb").read().decode("utf-8")
+                         for fn in sorted(os.listdir(os.path.join(ds, "labels", split)))}
+    return {"labels": labels, "images": images, "data_yaml": open(os.path.join(ds, "data.yaml"), encoding="utf-8").read().replace(ds, "<DATASET>"),
+            "stats": res["stats"], "total": res["total"], "processed": res["processed"], "downloaded": res["downloaded"],
+            "dataset_name_map": res["dataset_name_map"], "skipped": json.loads(sheets.written[-1].to_json(orient="records", force_ascii=False))}
+
+
+def golden_frames(tmp_path):
+    """the two reference runs of the fixture, sources re-rooted under tmp_path (image stand-ins created)"""
+    import pandas as pd
+    g = load_golden("yolo_cases.json")
+    img = tmp_path / "img"
+    img.mkdir()
+    rows = []
+    for k, c in enumerate(g["cases"].values()):
+        (img / f"case{k:03d}.jpg").write_bytes(b"x")
+        rows.append({"source": str(img / f"case{k:03d}.jpg"), "分类标签": c["label"], P.BBOX_COL: c["json"], "width": c["width"], "height": c["height"]})
+    for k in range(12):
+        rows.append({"source": str(img / "none.jpg"), "分类标签": f"k{k:02d}", P.BBOX_COL: '{"objects": []}', "width": 1, "height": 1})
+    single = {"train": pd.DataFrame(rows)}
+    three = {}
+    for split, rec in g["run3"]["frames"].items():
+        f = pd.DataFrame(rec["data"], columns=rec["columns"]).astype(object)
+        f = f.apply(lambda col: col.map(lambda v: float("nan") if v == "__NaN__" else v))       # NaN and None differ for `a or b`
+        for name in f["source"]:
+            if isinstance(name, str) and name != "missing.jpg":
+                (img / name).write_bytes(b"png")
+        f["source"] = f["source"].map(lambda n: str(img / n) if isinstance(n, str) else n)
+        three[split] = f
+    return g, single, three
+
+
+def check_yolo_step(tmp_path, backend):
+    g, single, three = golden_frames(tmp_path)
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    assert run_product_yolo(single, tmp_path / "a", backend) == g["run"]
+    r3 = g["run3"]
+    got = run_product_yolo(three, tmp_path / "b", backend, random_seed=r3["seed"], class_order=r3["class_order"])
+    assert got == r3["result"]
+    return got
+
+
+def test_generate_yolo_datasets_matches_reference(oracle_backend, tmp_path):
+    got = check_yolo_step(tmp_path, oracle_backend)
+    assert sum(got["stats"]["catA"].values()) > 30 and len(got["skipped"]) >= 5
+
+
+def test_generate_yolo_resume_and_progress(oracle_backend, tmp_path):
+    g, single, three = golden_frames(tmp_path)
+    calls = []
+    first = run_product_yolo(three, tmp_path, oracle_backend, random_seed=7, progress_callback=lambda *a: calls.append(a))
+    assert calls and calls[-1][0] == first["processed"] and all(len(c) == 9 for c in calls)
+    again = run_product_yolo(three, tmp_path, oracle_backend, random_seed=7)              # label files exist: rows are only counted
+    assert again["stats"] == first["stats"] and again["labels"] == first["labels"] and again["downloaded"] == 0
