@@ -11,7 +11,8 @@ positionally through ``run_step`` (:548, :566, :584, :598, :630):
     filter_by_box_count_and_iou      reference processor.py:321-407   -> K2
     split_dataset_by_rules           reference processor.py:654-831   -> K6 (+ host MT19937)
 
-and, next to them, the label-line arithmetic of generate_yolo_datasets_from_excels
+and, either side of them, ``merge_all_csv_in_folder`` (reference processor.py:26-109, native
+CSV hand-off) and the label-line arithmetic of generate_yolo_datasets_from_excels
 (reference processor.py:1001-1060) as ``yolo_label_texts`` -> K7.
 
 Each step is  flatten (cells -> SoA numpy buffers)  ->  device stage (HIP kernels behind
@@ -22,6 +23,7 @@ mandatory: without libdyd_gfx950.so and a gfx950 GPU the steps raise (``_native`
 from __future__ import annotations
 
 import copy
+import io
 import json
 import os
 from pathlib import Path
@@ -42,6 +44,163 @@ BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:2
 _CHUNK_CELLS = 1 << 18                               # cells flattened per device batch (Python path)
 LAST_IO_PATH = {}                                    # step -> "native" | "pandas": which CSV path the last call took
 _NATIVE_CHUNK_CELLS = 1 << 21                        # cells per native scan (2M rows ~ 0.26 G points at 124 pts/row)
+
+
+# =============================================================================== f3  merge
+_READ_CHARS = 262144          # characters the C parser takes from the file handle per read (pandas parsers.pyx)
+_HEAVY_BYTES_PER_ROW = 64     # a column averaging more than this per cell is carried natively (never parsed)
+
+
+class _TellEmulator:
+    """What ``f.tell()`` shows after pandas has parsed up to a given row when it reads a text-mode handle in
+    blocks of 262144 characters (reference processor.py:80): the byte offset behind the last block read."""
+
+    def __init__(self, raw: bytes, bom_len: int):
+        self.b = np.frombuffer(raw, np.uint8)
+        self.pos = bom_len
+
+    def _read_block(self):
+        need, pos, n = _READ_CHARS, self.pos, len(self.b)
+        while need > 0 and pos < n:
+            seg = self.b[pos:pos + need]
+            need -= int(np.count_nonzero((seg & 0xC0) != 0x80))        # characters that start inside the segment
+            pos += len(seg)
+        while pos < n and (self.b[pos] & 0xC0) == 0x80:               # the tail bytes of the last character
+            pos += 1
+        self.pos = pos
+
+    def after(self, byte_end: int) -> int:
+        while self.pos < byte_end and self.pos < len(self.b):
+            self._read_block()
+        return self.pos
+
+
+def _merge_file_native(csv_file: Path, output_file: str, encoding: str, chunk_size: int, header_written: bool, on_chunk):
+    """One input file of the merge through the native CSV path.  -> rows written, or None when the file is left to
+    pandas (nothing has been written then).  on_chunk(rows_in_chunk, chunk_idx, file_bytes) reports progress."""
+    if not _fc.enabled() or not _fc._utf8_like(encoding) or chunk_size is None or chunk_size <= 0:
+        return None
+    raw = csv_file.read_bytes()
+    sig = "sig" in encoding.lower()
+    bom = len(_fc._BOM) if raw.startswith(_fc._BOM) else 0
+    if bom and not sig:
+        return None                                      # a BOM read as text becomes part of the first name
+    try:
+        raw.decode("utf-8")                              # errors="ignore" (:70) drops nothing from valid utf-8
+    except UnicodeDecodeError:
+        return None
+    idx = _fc.CsvIndex.open(np.frombuffer(raw, dtype=np.uint8)[bom:])
+    if idx is None:
+        return None
+    with idx:
+        names, n_rows = idx.names, idx.n_rows
+        if n_rows == 0 or "source_file" in names:
+            return None
+        heavy = {}
+        for c, nm in enumerate(names):
+            if idx.col_bytes(c) >= _HEAVY_BYTES_PER_ROW * n_rows:
+                col = idx.extract(c)
+                if col is not None:
+                    heavy[nm] = col
+        if not heavy:
+            return None                                  # nothing to gain: plain pandas
+        light_names = [nm for nm in names if nm not in heavy]
+        bounds = [(r0, min(r0 + chunk_size, n_rows)) for r0 in range(0, n_rows, chunk_size)]
+        if light_names:
+            text = idx.project([names.index(nm) for nm in light_names])
+            if text is None:
+                return None
+            light_iter = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names, parse_dates=False,
+                                     chunksize=chunk_size)
+        else:
+            light_iter = (pd.DataFrame(index=pd.RangeIndex(r1 - r0)) for r0, r1 in bounds)
+        tell = _TellEmulator(raw, bom)
+        out_names = names + ["source_file"]
+        base = os.path.basename(csv_file)
+        written = 0
+        for chunk_idx, ((r0, r1), light) in enumerate(zip(bounds, light_iter), start=1):
+            if len(light) != r1 - r0:
+                raise RuntimeError("native CSV path: chunk sizes disagree")      # cannot happen for an indexed file
+            light = light.reset_index(drop=True)
+            part = {nm: _fc.Utf8Column(col.data, col.off[r0:r1 + 1], col.na[r0:r1]) for nm, col in heavy.items()}
+            columns = [part[nm] if nm in part else light[nm] for nm in names]
+            columns.append(pd.Series([base] * (r1 - r0), dtype=object))
+            first = not header_written and written == 0
+            if not _fc.write_table(output_file, out_names, columns, r1 - r0, encoding=encoding, append=not first, header=first):
+                frame = pd.DataFrame({nm: (part[nm].cells(range(r1 - r0)) if nm in part else light[nm]) for nm in names},
+                                     columns=names)
+                frame["source_file"] = base
+                frame.to_csv(output_file, index=False, encoding=encoding, mode="w" if first else "a", header=first)
+            written += r1 - r0
+            on_chunk(r1 - r0, chunk_idx, tell.after(bom + idx.row_end(r1 - 1)))
+        return written
+
+
+def merge_all_csv_in_folder(
+        folder_path,
+        output_file="merged_csv.csv",
+        encoding="utf-8-sig",
+        chunk_size: int = 100000,
+        progress_callback=None,
+):
+    """Drop-in for reference processor.py:26-109: append every *.csv of the folder (chunk by chunk, a
+    ``source_file`` column added) to one file; -> total rows, or None when there was nothing to merge.
+    Files whose wide columns (the annotation JSON) can be carried as bytes go through the native CSV path —
+    those columns are never parsed, the narrow ones are parsed by pandas itself chunk by chunk — anything else
+    (other encodings, CR line ends, ragged or quoted-oddly files) takes the reference's pandas loop."""
+    if not os.path.exists(folder_path):
+        raise FileNotFoundError(f"文件夹不存在：{folder_path}")
+    csv_files = list(Path(folder_path).glob("*.csv"))
+    if not csv_files:
+        print(f"警告：文件夹 {folder_path} 中未找到CSV文件")
+        return None
+    print(f"找到 {len(csv_files)} 个CSV文件，开始合并...")
+
+    output_file = str(output_file)
+    Path(output_file).parent.mkdir(parents=True, exist_ok=True)
+    header_written = False
+    total_rows = 0
+    total_bytes = sum(f.stat().st_size for f in csv_files)
+    completed_bytes = 0
+    LAST_IO_PATH["merge"] = {}
+
+    for file_idx, csv_file in enumerate(csv_files, start=1):
+        try:
+            file_size = csv_file.stat().st_size
+            if progress_callback:
+                progress_callback(file_idx, len(csv_files), csv_file.name, total_rows, 0, 0, file_size, 0, total_bytes, completed_bytes)
+            state = {"file_rows": 0}
+
+            def on_chunk(rows, chunk_idx, file_bytes):
+                nonlocal total_rows, header_written
+                header_written = True
+                state["file_rows"] += rows
+                total_rows += rows
+                if progress_callback:
+                    progress_callback(file_idx, len(csv_files), csv_file.name, total_rows, state["file_rows"], chunk_idx,
+                                      file_size, file_bytes, total_bytes, completed_bytes + file_bytes)
+
+            native_rows = _merge_file_native(csv_file, output_file, encoding, chunk_size, header_written, on_chunk)
+            LAST_IO_PATH["merge"][csv_file.name] = "native" if native_rows is not None else "pandas"
+            if native_rows is None:
+                with open(csv_file, "r", encoding=encoding, errors="ignore") as f:
+                    for chunk_idx, df in enumerate(pd.read_csv(f, parse_dates=False, chunksize=chunk_size), start=1):
+                        df["source_file"] = os.path.basename(csv_file)
+                        df.to_csv(output_file, index=False, encoding=encoding, mode="w" if not header_written else "a",
+                                  header=not header_written)
+                        on_chunk(len(df), chunk_idx, f.tell())
+            print(f"成功读取：{csv_file.name}（{state['file_rows']}行）")
+            completed_bytes += file_size
+        except Exception as e:  # noqa: BLE001 - the reference reports and moves on to the next file
+            print(f"读取失败 {csv_file.name}：{str(e)}")
+            continue
+
+    if not header_written:
+        print("错误：没有可合并的有效CSV数据")
+        return None
+    print(f"\n合并完成！共 {total_rows} 行数据")
+    print(f"输出文件：{os.path.abspath(output_file)}")
+    return total_rows
 
 
 # =============================================================================== a1  dedup

@@ -261,6 +261,25 @@ int dyd_csv_project(dyd_csv *h, const int32_t *keep, int32_t n_keep, const uint8
     return DYD_OK;
 }
 
+// total bytes of the cells of one column (picks the columns worth extracting)
+int64_t dyd_csv_col_bytes(const dyd_csv *h, int32_t c) {
+    if (!h || c < 0 || c >= h->n_cols) return -1;
+    int64_t total = 0;
+    for (int64_t r = 0; r < h->n_rows; ++r) {
+        const Field &f = h->fields[(size_t)(r * h->n_cols + c)];
+        total += f.e - f.b;
+    }
+    return total;
+}
+
+// byte offset just behind data row `row` (its line end included); row == -1: behind the header line
+int64_t dyd_csv_row_end(const dyd_csv *h, int64_t row) {
+    if (!h || row < -1 || row >= h->n_rows || h->n_cols <= 0) return -1;
+    const Field &f = row < 0 ? h->header[(size_t)h->n_cols - 1] : h->fields[(size_t)(row * h->n_cols + h->n_cols - 1)];
+    const int64_t e = f.e + (f.quoted ? 1 : 0) + 1;
+    return e < h->len ? e : h->len;
+}
+
 void dyd_csv_free(dyd_csv *h) { delete h; }
 
 // ---- writer ---------------------------------------------------------------------------------------
@@ -287,9 +306,10 @@ static void put_text(std::string &o, const char *s, size_t n, bool quote_cr) {
     o += '"';
 }
 
-// Writes header + rows (rows[i] = source row index, or all n_rows in order when rows == NULL) to path.
+// Writes header + rows (rows[i] = source row index, or all n_rows in order when rows == NULL).
+// mode 0: to `path`, replacing it; 1: to memory (*mem_out, release with dyd_host_free); 2: appended to `path`.
 int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, const dyd_csv_col *cols, int32_t n_cols,
-                  int64_t n_rows, const int64_t *rows, int64_t n_sel, int quote_cr, int n_threads, int append_to_memory,
+                  int64_t n_rows, const int64_t *rows, int64_t n_sel, int quote_cr, int n_threads, int mode,
                   uint8_t **mem_out, int64_t *mem_len) {
     if (n_cols <= 0 || !cols || n_sel < 0) return DYD_ERR_INVALID;
     const int64_t n_out = rows ? n_sel : n_rows;
@@ -342,7 +362,7 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
     } catch (const std::bad_alloc &) {
         return DYD_ERR_OOM;
     }
-    if (append_to_memory) {  // used by the Python wrapper's self-check
+    if (mode == 1) {  // used by the Python wrapper's self-check
         size_t total = (size_t)header_len;
         for (auto &s : parts) total += s.size();
         uint8_t *m = static_cast<uint8_t *>(malloc(total ? total : 1));
@@ -354,7 +374,7 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
         *mem_len = (int64_t)total;
         return DYD_OK;
     }
-    FILE *f = fopen(path, "wb");
+    FILE *f = fopen(path, mode == 2 ? "ab" : "wb");
     if (!f) return DYD_ERR_INVALID;
     bool ok = fwrite(header, 1, (size_t)header_len, f) == (size_t)header_len;
     for (auto &s : parts) ok = ok && fwrite(s.data(), 1, s.size(), f) == s.size();

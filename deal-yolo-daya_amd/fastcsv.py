@@ -76,54 +76,108 @@ class SplitTable:
     heavy: dict                 # name -> Utf8Column
 
 
-def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
-    """-> SplitTable, or None when the fast path must not be used for this file."""
-    if not enabled() or encoding.lower().replace("_", "-") not in ("utf-8-sig", "utf-8", "utf8"):
-        return None
-    L = _native.load_library()
-    with open(path, "rb") as f:
-        raw = f.read()
-    start = len(_BOM) if raw.startswith(_BOM) and "sig" in encoding.lower() else 0
-    buf = np.frombuffer(raw, dtype=np.uint8)[start:]
-    if buf.size == 0:
-        return None
-    h = C.c_void_p()
-    if L.dyd_csv_index(buf.ctypes.data, buf.size, C.byref(h)) != 0:
-        return None
-    try:
+def _utf8_like(encoding: str) -> bool:
+    return encoding.lower().replace("_", "-") in ("utf-8-sig", "utf-8", "utf8")
+
+
+class CsvIndex:
+    """A tokenised CSV buffer (dyd_csv handle).  ``open`` returns None when the native tokeniser does not
+    reproduce pandas on this text (CR line ends, ragged rows, stray quotes, duplicate / empty header names)."""
+
+    def __init__(self, handle, buf, names, n_rows):
+        self._h, self._buf, self.names, self.n_rows = handle, buf, names, n_rows
+
+    @classmethod
+    def open(cls, buf: np.ndarray):
+        L = _native.load_library()
+        if buf.size == 0:
+            return None
+        h = C.c_void_p()
+        if L.dyd_csv_index(buf.ctypes.data, buf.size, C.byref(h)) != 0:
+            return None
         n_rows, n_cols = int(L.dyd_csv_rows(h)), int(L.dyd_csv_cols(h))
-        names = []
-        tmp = np.empty(4096, np.uint8)
+        names, tmp = [], np.empty(4096, np.uint8)
         for c in range(n_cols):
             n = L.dyd_csv_header(h, c, tmp.ctypes.data, tmp.size)
             if n < 0:
+                L.dyd_csv_free(h)
                 return None
             names.append(bytes(tmp[:n]).decode("utf-8"))
         if len(set(names)) != len(names) or any(nm == "" or nm.startswith("Unnamed") for nm in names):
-            return None                                  # pandas renames such columns: leave it to pandas
+            L.dyd_csv_free(h)                                # pandas renames such columns: leave it to pandas
+            return None
+        return cls(h, buf, names, n_rows)
+
+    def close(self):
+        if self._h is not None:
+            _native.load_library().dyd_csv_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def col_bytes(self, c: int) -> int:
+        return int(_native.load_library().dyd_csv_col_bytes(self._h, c))
+
+    def row_end(self, row: int) -> int:
+        """byte offset (inside the indexed buffer) just behind data row `row`; -1 = the header line"""
+        return int(_native.load_library().dyd_csv_row_end(self._h, row))
+
+    def extract(self, c: int):
+        """column c as Utf8Column, or None when pandas might not type it as str in every piece of the file"""
+        L = _native.load_library()
+        pb, po, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if L.dyd_csv_extract(self._h, c, C.byref(pb), C.byref(po), C.byref(pn)) != 0:
+            return None
+        off = _view(po.value, np.int64, self.n_rows + 1).copy()
+        data = _view(pb.value, np.uint8, int(off[-1]) + 1).copy()
+        na = _view(pn.value, np.uint8, self.n_rows).copy()
+        # pandas infers dtypes per low-memory piece of the file, and a piece whose present cells all look
+        # numeric / boolean becomes numbers ("1.50" -> 1.5).  The column is taken natively only when NO
+        # present cell could be read as a number / boolean (na == 2): then every piece is object / str.
+        if (na == 2).any() or (na != 0).all():
+            return None
+        return Utf8Column(data, off, na)
+
+    def project(self, keep: list):
+        """CSV text of the file's width in which only the columns `keep` carry their cells (for pandas)"""
+        L = _native.load_library()
+        arr = np.asarray(keep, np.int32)
+        pt, ln = C.c_void_p(), C.c_int64()
+        if L.dyd_csv_project(self._h, arr.ctypes.data, len(arr), C.byref(pt), C.byref(ln)) != 0:
+            return None
+        return bytes(_view(pt.value, np.uint8, ln.value))
+
+
+def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
+    """-> SplitTable, or None when the fast path must not be used for this file."""
+    if not enabled() or not _utf8_like(encoding):
+        return None
+    with open(path, "rb") as f:
+        raw = f.read()
+    start = len(_BOM) if raw.startswith(_BOM) and "sig" in encoding.lower() else 0
+    idx = CsvIndex.open(np.frombuffer(raw, dtype=np.uint8)[start:])
+    if idx is None:
+        return None
+    with idx:
+        names, n_rows = idx.names, idx.n_rows
         heavy = {}
         for nm in heavy_names:
             if nm not in names:
                 continue
-            pb, po, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
-            if L.dyd_csv_extract(h, names.index(nm), C.byref(pb), C.byref(po), C.byref(pn)) != 0:
+            col = idx.extract(names.index(nm))
+            if col is None:
                 return None
-            off = _view(po.value, np.int64, n_rows + 1).copy()
-            data = _view(pb.value, np.uint8, int(off[-1]) + 1).copy()
-            na = _view(pn.value, np.uint8, n_rows).copy()
-            # pandas infers dtypes per low-memory piece of the file, and a piece whose present cells all look
-            # numeric / boolean becomes numbers ("1.50" -> 1.5).  The column is taken natively only when NO
-            # present cell could be read as a number / boolean (na == 2): then every piece is object / str.
-            if (na == 2).any() or (na != 0).all():
-                return None
-            heavy[nm] = Utf8Column(data, off, na)
+            heavy[nm] = col
         light_idx = [i for i, nm in enumerate(names) if nm not in heavy]
         if light_idx:
-            keep = np.asarray(light_idx, np.int32)
-            pt, ln = C.c_void_p(), C.c_int64()
-            if L.dyd_csv_project(h, keep.ctypes.data, len(keep), C.byref(pt), C.byref(ln)) != 0:
+            text = idx.project(light_idx)
+            if text is None:
                 return None
-            text = bytes(_view(pt.value, np.uint8, ln.value))
             light_names = [names[i] for i in light_idx]
             light = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names)[light_names]
             if len(light) != n_rows or list(light.columns) != light_names:
@@ -131,8 +185,6 @@ def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
         else:
             light = pd.DataFrame(index=pd.RangeIndex(n_rows))
         return SplitTable(names, n_rows, light, heavy)
-    finally:
-        L.dyd_csv_free(h)
 
 
 def frame_from_split(table: "SplitTable", rows=None) -> pd.DataFrame:
@@ -194,13 +246,14 @@ class _Cols(C.Structure):
 
 
 def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, encoding: str = "utf-8-sig",
-                check_rows: int = 40) -> bool:
+                check_rows: int = 40, append: bool = False, header: bool = True) -> bool:
     """Write the table like ``DataFrame(...)[names].to_csv(path, index=False, encoding=encoding)``.
 
     columns[i] is a pandas Series (light column, length n_rows) or a Utf8Column.  ``rows`` selects and
     orders source rows (default: all).  Returns False — without touching ``path`` — when a column type is
-    not covered or when the sample check against pandas disagrees."""
-    if not enabled() or encoding.lower().replace("_", "-") not in ("utf-8-sig", "utf-8", "utf8"):
+    not covered or when the sample check against pandas disagrees.  ``append`` / ``header`` = to_csv's
+    mode="a" / header= (an appended part carries no BOM, like a text file opened for append at a non-zero offset)."""
+    if not enabled() or not _utf8_like(encoding):
         return False
     L = _native.load_library()
     specs, keep = [], []
@@ -222,8 +275,8 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
             off = np.ascontiguousarray(off, dtype=np.int64); keep.append(off); arr[i].off = off.ctypes.data
         if na is not None:
             na = np.ascontiguousarray(na, dtype=np.uint8); keep.append(na); arr[i].na = na.ctypes.data
-    header = pd.DataFrame(columns=names).to_csv(index=False).encode("utf-8")
-    bom = _BOM if "sig" in encoding.lower() else b""
+    header_line = pd.DataFrame(columns=names).to_csv(index=False).encode("utf-8")
+    bom = _BOM if "sig" in encoding.lower() and not (append and os.path.exists(path) and os.path.getsize(path) > 0) else b""
     rows_arr = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
     n_out = n_rows if rows_arr is None else len(rows_arr)
 
@@ -237,7 +290,7 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
         want = pd.DataFrame(sample, columns=names).to_csv(index=False).encode("utf-8")
         mem, ln = C.c_void_p(), C.c_int64()
         srcc = np.ascontiguousarray(src, dtype=np.int64)
-        rc = L.dyd_csv_write(None, header, len(header), arr, len(specs), n_rows, srcc.ctypes.data, len(srcc), int(_QUOTE_CR), 1,
+        rc = L.dyd_csv_write(None, header_line, len(header_line), arr, len(specs), n_rows, srcc.ctypes.data, len(srcc), int(_QUOTE_CR), 1,
                              1, C.byref(mem), C.byref(ln))
         if rc != 0:
             return False
@@ -245,8 +298,9 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
         L.dyd_host_free(mem)
         if got != want:
             return False
-    full_header = bom + header
+    full_header = bom + (header_line if header else b"")
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     rc = L.dyd_csv_write(os.fsencode(path), full_header, len(full_header), arr, len(specs), n_rows,
-                         rows_arr.ctypes.data if rows_arr is not None else None, n_out, int(_QUOTE_CR), 0, 0, None, None)
+                         rows_arr.ctypes.data if rows_arr is not None else None, n_out, int(_QUOTE_CR), 0, 2 if append else 0,
+                         None, None)
     return rc == 0

@@ -238,10 +238,13 @@ int32_t dyd_csv_cols(const dyd_csv *csv);
 int64_t dyd_csv_header(const dyd_csv *csv, int32_t col, uint8_t *buf, int64_t cap);
 int dyd_csv_extract(dyd_csv *csv, int32_t col, const uint8_t **bytes, const int64_t **off, const uint8_t **na);
 int dyd_csv_project(dyd_csv *csv, const int32_t *keep, int32_t n_keep, const uint8_t **text, int64_t *len);
+int64_t dyd_csv_col_bytes(const dyd_csv *csv, int32_t col);   /* total cell bytes of a column */
+int64_t dyd_csv_row_end(const dyd_csv *csv, int64_t row);     /* byte offset behind data row `row` (-1: the header) */
 void dyd_csv_free(dyd_csv *csv);
+/* mode 0: write `path` anew, 1: to memory (*mem_out, dyd_host_free), 2: append to `path` (merge step, :73-76) */
 int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, const dyd_csv_col *cols,
                   int32_t n_cols, int64_t n_rows, const int64_t *rows, int64_t n_sel, int quote_cr,
-                  int n_threads, int to_memory, uint8_t **mem_out, int64_t *mem_len);
+                  int n_threads, int mode, uint8_t **mem_out, int64_t *mem_len);
 void dyd_host_free(void *p);
 
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,

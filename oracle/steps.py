@@ -416,3 +416,47 @@ def yolo_row_text(json_str, label_value, class_id, width, height):
     if not lines:
         return None, "标注框无效"
     return "\n".join(lines), None
+
+
+# ------------------------------------------------- f3  merge  processor.py:26-109
+def merge_folder(folder_path, output_file="merged_csv.csv", encoding="utf-8-sig", chunk_size=100000, progress_callback=None):
+    """processor.py:26-109 restated: chunked read_csv of every *.csv (text-mode handle, errors="ignore"), a
+    source_file column, to_csv append; a failing file is reported and skipped; -> total rows or None."""
+    if not os.path.exists(folder_path):
+        raise FileNotFoundError(f"文件夹不存在：{folder_path}")
+    files = list(Path(folder_path).glob("*.csv"))
+    if not files:
+        print(f"警告：文件夹 {folder_path} 中未找到CSV文件")
+        return None
+    print(f"找到 {len(files)} 个CSV文件，开始合并...")
+    output_file = str(output_file)
+    Path(output_file).parent.mkdir(parents=True, exist_ok=True)
+    wrote_header, total, done_bytes = False, 0, 0
+    all_bytes = sum(f.stat().st_size for f in files)
+    for k, path in enumerate(files, start=1):
+        try:
+            size = path.stat().st_size
+            if progress_callback:
+                progress_callback(k, len(files), path.name, total, 0, 0, size, 0, all_bytes, done_bytes)
+            rows_here = 0
+            with open(path, "r", encoding=encoding, errors="ignore") as fh:
+                for j, part in enumerate(pd.read_csv(fh, parse_dates=False, chunksize=chunk_size), start=1):
+                    part["source_file"] = os.path.basename(path)
+                    part.to_csv(output_file, index=False, encoding=encoding, mode="a" if wrote_header else "w", header=not wrote_header)
+                    wrote_header = True
+                    rows_here += len(part)
+                    total += len(part)
+                    here = fh.tell()
+                    if progress_callback:
+                        progress_callback(k, len(files), path.name, total, rows_here, j, size, here, all_bytes, done_bytes + here)
+            print(f"成功读取：{path.name}（{rows_here}行）")
+            done_bytes += size
+        except Exception as exc:  # noqa: BLE001
+            print(f"读取失败 {path.name}：{str(exc)}")
+            continue
+    if not wrote_header:
+        print("错误：没有可合并的有效CSV数据")
+        return None
+    print(f"\n合并完成！共 {total} 行数据")
+    print(f"输出文件：{os.path.abspath(output_file)}")
+    return total

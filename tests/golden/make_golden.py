@@ -13,6 +13,7 @@ tests or vectors of its own, so these outputs are what pins oracle/ and the HIP 
     split_case.json      a5 split_dataset_by_rules with Excel I/O captured in memory
     e2e_*.csv.gz         one seeded table through all five steps (inputs and every output)
     yolo_cases.json      f4 _extract_boxes_with_labels + the label files generate_yolo_datasets_from_excels writes
+    merge_case.json      f3 merge_all_csv_in_folder: input files, merged bytes, progress-callback arguments, printed lines
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -543,6 +544,58 @@ def make_yolo():
     _dump("yolo_cases.json", out)
 
 
+# ------------------------------------------------------------------------------- f3  merge
+def merge_inputs():
+    """file name -> text (written with utf-8-sig unless noted); sorted name order is the merge order"""
+    t = synth.generate(23, seed=5, max_boxes=3)
+    a = synth.to_frame(t)
+    a["备注"] = ["x,1", 'q"q', "多行\n文本", "", "NA", "7"] * 3 + ["1.50", "007", "True", "nan", " pad "]
+    a["n"] = range(len(a))
+    b = synth.to_frame(synth.generate(9, seed=6, max_boxes=2))[[ANN, "source"]]          # other column order, no extras
+    b.loc[3, ANN] = np.nan
+    c = pd.DataFrame({"source": ["u1", "u2"], "k": [1.5, 2.0]})                            # no wide column: pandas path
+    files = {
+        "a_main.csv": a.to_csv(index=False),
+        "b_other_order.csv": b.to_csv(index=False),
+        "c_narrow.csv": c.to_csv(index=False),
+        "d_crlf.csv": a.head(4).to_csv(index=False, lineterminator="\r\n"),
+        "e_header_only.csv": "source," + ANN + "\n",
+        "f_empty.csv": "",
+        "g_ragged.csv": "source," + ANN + "\nonly_one_field\nu,{},extra\n",
+        "h_has_source_file.csv": pd.DataFrame({"source": ["z"], ANN: ['{"objects": []}' + " " * 80], "source_file": ["old"]}).to_csv(index=False),
+    }
+    return files
+
+
+def run_reference_merge(files, chunk_size):
+    import contextlib
+    import pathlib
+    calls = []
+    orig_glob = pathlib.Path.glob
+    pathlib.Path.glob = lambda self, pat: iter(sorted(orig_glob(self, pat)))
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            folder = os.path.join(d, "in")
+            os.makedirs(folder)
+            for name, text in files.items():
+                with open(os.path.join(folder, name), "w", encoding="utf-8-sig", newline="") as f:
+                    f.write(text)
+            out = os.path.join(d, "o", "merged.csv")
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ret = ref.merge_all_csv_in_folder(folder, out, "utf-8-sig", chunk_size, lambda *a: calls.append(list(a)))
+            merged = open(out, "rb").read().decode("utf-8")          # keeps the BOM as \ufeff
+            printed = buf.getvalue().replace(d, "<TMP>")
+    finally:
+        pathlib.Path.glob = orig_glob
+    return {"chunk_size": chunk_size, "return": ret, "merged": merged, "calls": calls, "printed": printed}
+
+
+def make_merge():
+    files = merge_inputs()
+    _dump("merge_case.json", {"files": files, "runs": [run_reference_merge(files, 7), run_reference_merge(files, 100000)]})
+
+
 if __name__ == "__main__":
     make_replace()
     make_iou()
@@ -552,3 +605,4 @@ if __name__ == "__main__":
     make_split()
     make_e2e()
     make_yolo()
+    make_merge()

@@ -220,3 +220,24 @@ def test_yolo_label_text_matches_reference():
     filler = 12                                             # filler rows of the fixture: no objects -> no matching box
     reasons["无匹配标签框"] += filler
     assert reasons == g["skipped_reasons"]
+
+
+# ------------------------------------------------------------------ f3  merge
+@pytest.mark.parametrize("run_idx", [0, 1])
+def test_merge_port_matches_reference(tmp_path, monkeypatch, capsys, run_idx):
+    import pathlib
+    orig = pathlib.Path.glob
+    monkeypatch.setattr(pathlib.Path, "glob", lambda self, pat: iter(sorted(orig(self, pat))))
+    g = load_golden("merge_case.json")
+    folder = tmp_path / "in"
+    folder.mkdir()
+    for name, text in g["files"].items():
+        with open(folder / name, "w", encoding="utf-8-sig", newline="") as f:
+            f.write(text)
+    want = g["runs"][run_idx]
+    calls = []
+    out = tmp_path / "o" / "merged.csv"
+    ret = osteps.merge_folder(str(folder), str(out), "utf-8-sig", want["chunk_size"], lambda *a: calls.append(list(a)))
+    assert ret == want["return"] and calls == want["calls"]
+    assert open(out, "rb").read().decode("utf-8") == want["merged"]
+    assert capsys.readouterr().out.replace(str(tmp_path), "<TMP>") == want["printed"]
