@@ -92,6 +92,18 @@ SIGNATURES = {
     "dyd_scan_wh_kind": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_wh_value": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_free": (None, [C.c_void_p]),
+    "dyd_json_split_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int,
+                                        C.POINTER(C.c_void_p)]),
+    "dyd_split_status": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_n_expanded": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_rows": (C.c_int64, [C.c_void_p]),
+    "dyd_split_row_cell": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_row_label": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_events": (C.c_int64, [C.c_void_p]),
+    "dyd_split_event_cell": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_event_kind": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_strings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dyd_split_free": (None, [C.c_void_p]),
     "dyd_csv_index": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "dyd_csv_rows": (C.c_int64, [C.c_void_p]),
     "dyd_csv_cols": (C.c_int32, [C.c_void_p]),

@@ -697,6 +697,108 @@ def split_cut_sizes(n: int, train_ratio: float, val_ratio: float, test_ratio: fl
     return int(n * train_ratio), int(n * val_ratio)
 
 
+_SPLIT_ERRORS = {1: "空数据", 2: "JSON解析失败", 3: "objects不是列表", 4: "标注字段objects为空"}      # utils.py:645-657, :722
+
+
+def _expand_cell_python(cell, label_to_category):
+    """One row of the split step the way the reference walks it (processor.py:720-792), for the cells the native
+    expansion leaves to CPython.  -> (error or None, combo, [(label, json)], [(kind, label)], joined reasons)"""
+    doc, objs, err = _parse_data_objects(cell)
+    if err or not objs:
+        return err or _SPLIT_ERRORS[4], "", [], [], ""
+    seen = set()
+    for o in objs:
+        if isinstance(o, dict) and o.get("name"):
+            seen.update(_split_object_labels(o.get("name")))
+    combo = "，".join(sorted(seen)) if seen else ""
+    rows, events, reasons = [], [], set()
+    for o in objs:
+        if not isinstance(o, dict):
+            continue
+        labels = _split_object_labels(o.get("name"))
+        if not labels:
+            events.append((_nj.EV_NO_NAME, None))
+            continue
+        for label in labels:
+            if label not in label_to_category:
+                events.append((_nj.EV_UNDEFINED, label))
+                reasons.add(f"标签{label}未在规则中定义")
+                continue
+            single = dict(o)                                 # the reference deep-copies (:764); the JSON text is the same
+            single["name"] = label
+            slim = {k: v for k, v in doc.items() if k != "objects"}
+            slim["objects"] = [single]
+            rows.append((label, json.dumps(slim, ensure_ascii=False)))
+    if not rows:
+        events.append((_nj.EV_NOTHING_CLASSIFIED, None))
+    return None, combo, rows, events, "；".join(sorted(reasons))
+
+
+def _expand_rows(cells, label_to_category: dict) -> dict:
+    """Expansion of all rows: native for the regular cells (csrc/host_json.cpp), ``_expand_cell_python`` for the
+    rest, merged back into row order."""
+    n = len(cells)
+    labels = list(label_to_category)
+    combo = np.full(n, "", object)
+    reasons = np.full(n, "", object)
+    n_out = np.zeros(n, np.int64)
+    error = np.full(n, None, object)
+    row_src, row_label, row_json = [np.zeros(0, np.int64)], [np.empty(0, object)], [np.empty(0, object)]
+    ev_src, ev_kind, ev_label = [np.zeros(0, np.int64)], [np.zeros(0, np.uint8)], [np.empty(0, object)]
+    python_rows = range(n)
+    if n and _nj.enabled():
+        try:
+            ex = _nj.split_expand(cells, labels)
+        except UnicodeEncodeError:                             # a lone surrogate somewhere: CPython handles every cell
+            ex = None
+        if ex is not None:
+            regular = ex.status != _nj.SP_IRREGULAR
+            combo[regular], reasons[regular], n_out[regular] = ex.combo[regular], ex.reasons[regular], ex.n_expanded[regular]
+            for code, text in _SPLIT_ERRORS.items():
+                error[ex.status == code] = text
+            lab_arr = np.asarray(labels, object) if labels else np.empty(0, object)
+            row_src.append(ex.row_cell); row_label.append(lab_arr[ex.row_label] if len(ex.row_label) else np.empty(0, object))
+            row_json.append(ex.row_json)
+            ev_src.append(ex.event_cell); ev_kind.append(ex.event_kind); ev_label.append(ex.event_label)
+            python_rows = np.flatnonzero(~regular).tolist()
+    for ri in python_rows:
+        err, cmb, rows, events, why = _expand_cell_python(cells[ri], label_to_category)
+        error[ri], combo[ri], reasons[ri], n_out[ri] = err, cmb, why, len(rows)
+        if rows:
+            row_src.append(np.full(len(rows), ri, np.int64))
+            row_label.append(np.asarray([r[0] for r in rows], object)); row_json.append(np.asarray([r[1] for r in rows], object))
+        if events:
+            ev_src.append(np.full(len(events), ri, np.int64))
+            ev_kind.append(np.asarray([e[0] for e in events], np.uint8)); ev_label.append(np.asarray([e[1] or "" for e in events], object))
+    src = np.concatenate(row_src)
+    order = np.argsort(src, kind="stable")
+    src, lab, txt = src[order], np.concatenate(row_label)[order], np.concatenate(row_json)[order]
+    # unclassified entries in the reference's append order: per row its events, an error row contributes itself
+    e_src, e_kind, e_label = np.concatenate(ev_src), np.concatenate(ev_kind), np.concatenate(ev_label)
+    err_rows = np.flatnonzero(np.asarray([e is not None for e in error], bool)) if n else np.zeros(0, np.int64)
+    all_src = np.concatenate([e_src, err_rows])
+    all_kind = np.concatenate([e_kind, np.zeros(len(err_rows), np.uint8)])
+    all_label = np.concatenate([e_label, np.full(len(err_rows), "", object)])
+    eorder = np.argsort(all_src, kind="stable")
+    unclassified = []
+    for ri, kind, label in zip(all_src[eorder].tolist(), all_kind[eorder].tolist(), all_label[eorder].tolist()):
+        if kind == 0:
+            unclassified.append((ri, error[ri], None))
+        elif kind == _nj.EV_NO_NAME:
+            unclassified.append((ri, "标注框缺少name字段", None))
+        elif kind == _nj.EV_UNDEFINED:
+            unclassified.append((ri, f"标签{label}未在规则中定义", label))
+        else:
+            unclassified.append((ri, reasons[ri] if reasons[ri] else "标签无法匹配规则", None))
+    failed = np.asarray([e is not None for e in error], bool) if n else np.zeros(0, bool)
+    verdict = np.where(failed | (n_out == 0), "否", np.where(reasons != "", "部分可分类", "是")).astype(object)
+    reasons_of_row = reasons.copy()
+    for ri in np.flatnonzero(failed).tolist():
+        reasons_of_row[ri] = error[ri]                         # split_counts carries the error text there (:726)
+    return {"src_row": src, "label": lab, "json": txt, "combo_of_row": combo, "n_out": n_out, "verdict": verdict,
+            "reasons_of_row": reasons_of_row, "unclassified": unclassified}
+
+
 def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Optional[list] = None,
                  train_ratio: float = 0.8, val_ratio: float = 0.1, test_ratio: float = 0.1,
                  random_seed: int = 42, backend=None) -> dict:
@@ -713,67 +815,32 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
         json_columns = [c for c in (BBOX_COL, ANNOTATION_COL) if c in df.columns]
     present_json = [c for c in json_columns if c in df.columns]
 
-    categories: dict = {}                 # category -> id, in first-appearance order (:773 dict order)
-    src_row, cat_id, new_json, new_label, new_combo = [], [], [], [], []
-    unclassified, counts = [], []         # (row position, reason, label-or-None) ; split_counts records
     cols = list(df.columns)
     col_pos = {c: i for i, c in enumerate(cols)}
     values = df.to_numpy(dtype=object) if len(df) else np.empty((0, len(cols)), object)
     source_pos = col_pos.get("source")
+    n = len(df)
+    cells = [None] * n                    # the first non-empty str among the JSON columns (:713-718)
+    for c in reversed([c for c in json_columns if c in col_pos]):
+        column = values[:, col_pos[c]]
+        for ri in range(n):
+            v = column[ri]
+            if isinstance(v, str) and v:
+                cells[ri] = v
 
-    for ri in range(len(df)):
-        cell = None
-        for c in json_columns:
-            if c in col_pos:
-                v = values[ri, col_pos[c]]
-                if isinstance(v, str) and v:
-                    cell = v
-                    break
-        doc, objs, err = _parse_data_objects(cell)
-        src = values[ri, source_pos] if source_pos is not None else None
-        if err or not objs:
-            reason = err or "标注字段objects为空"
-            unclassified.append((ri, reason, None))
-            counts.append({"source": src, "原始标签组合": "", "拆分条数": 0, "是否可分类": "否", "无法分类原因": reason})
-            continue
-        seen = set()
-        for o in objs:
-            if isinstance(o, dict) and o.get("name"):
-                seen.update(_split_object_labels(o.get("name")))
-        combo = "，".join(sorted(seen)) if seen else ""
-        n_out, reasons = 0, set()
-        for o in objs:
-            if not isinstance(o, dict):
-                continue
-            labels = _split_object_labels(o.get("name"))
-            if not labels:
-                unclassified.append((ri, "标注框缺少name字段", None))
-                continue
-            for label in labels:
-                if label not in label_to_category:
-                    why = f"标签{label}未在规则中定义"
-                    unclassified.append((ri, why, label))
-                    reasons.add(why)
-                    continue
-                category = label_to_category[label]
-                single = copy.deepcopy(o)
-                single["name"] = label
-                slim = {k: v for k, v in doc.items() if k != "objects"}
-                slim["objects"] = [single]
-                src_row.append(ri)
-                cat_id.append(categories.setdefault(category, len(categories)))
-                new_json.append(json.dumps(slim, ensure_ascii=False))
-                new_label.append(label)
-                new_combo.append(combo)
-                n_out += 1
-        if n_out == 0:
-            unclassified.append((ri, "；".join(sorted(reasons)) if reasons else "标签无法匹配规则", None))
-        status = "否" if n_out == 0 else ("部分可分类" if reasons else "是")
-        counts.append({"source": src, "原始标签组合": combo, "拆分条数": n_out, "是否可分类": status,
-                       "无法分类原因": "；".join(sorted(reasons))})
+    ex = _expand_rows(cells, label_to_category)
+    src_arr, new_json, new_label, new_combo = ex["src_row"], ex["json"], ex["label"], ex["combo_of_row"][ex["src_row"]] if n else ex["json"]
+    cat_names = np.asarray([label_to_category[lab] for lab in new_label], dtype=object) if len(new_label) else np.empty(0, object)
+    names_in_order = list(pd.unique(cat_names)) if len(cat_names) else []          # first-appearance order (:773 dict order)
+    categories = {name: i for i, name in enumerate(names_in_order)}
+    cat_id = np.asarray([categories[c] for c in cat_names], np.int32) if len(cat_names) else np.zeros(0, np.int32)
+    unclassified = ex["unclassified"]     # (row position, reason, label-or-None) in the reference's append order
+    sources = values[:, source_pos] if source_pos is not None else np.full(n, None, object)
+    counts = [{"source": sources[ri], "原始标签组合": ex["combo_of_row"][ri], "拆分条数": int(ex["n_out"][ri]),
+               "是否可分类": ex["verdict"][ri], "无法分类原因": ex["reasons_of_row"][ri]} for ri in range(n)]
 
     # ---- device stage: rank in category -> shuffled position -> split id --------------------
-    cat_arr = np.asarray(cat_id, np.int32)
+    cat_arr = cat_id
     n_cat = len(categories)
     sizes = np.bincount(cat_arr, minlength=n_cat).astype(np.int64) if n_cat else np.zeros(0, np.int64)
     cat_off = np.zeros(n_cat + 1, np.int64)
@@ -789,19 +856,18 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
         split, pos = np.zeros(0, np.uint8), np.zeros(0, np.int64)
 
     # ---- emit: per-category frames in shuffled order, cut by split id ------------------------
-    src_arr = np.asarray(src_row, np.int64)
     out_cats, cat_counts = {}, {}
     for category, cid in categories.items():
         members = np.flatnonzero(cat_arr == cid)
         order = np.empty(len(members), np.int64)
         order[pos[members]] = members                        # shuffled position -> expanded record
         frame = df.iloc[src_arr[order]].copy()
-        text = pd.Series([new_json[i] for i in order], index=frame.index, dtype=object)
+        text = pd.Series(new_json[order], index=frame.index, dtype=object)
         for c in present_json:
             frame[c] = text
-        frame["分类标签"] = [new_label[i] for i in order]
+        frame["分类标签"] = new_label[order]
         frame["分类类别"] = category
-        frame["原始标签组合"] = [new_combo[i] for i in order]
+        frame["原始标签组合"] = new_combo[order]
         frame = frame.reset_index(drop=True)
         sp = split[order]
         out_cats[category] = (frame[sp == 0], frame[sp == 1], frame[sp == 2])

@@ -1115,3 +1115,416 @@ int dyd_json_scan_boxes(const uint8_t *text, const int64_t *cell_off, const uint
 }
 
 }  // extern "C"
+
+// ===================================================================================================
+// split step: expansion of every row into one record per (object, label in the rules)
+// (reference core/processor.py:712-792; helpers utils.py:645-662)
+// ===================================================================================================
+#include <string_view>
+#include <unordered_map>
+
+namespace {
+
+enum SplitStatus : uint8_t {
+    SP_OK = 0,            // expanded (possibly into zero records)
+    SP_EMPTY = 1,         // "空数据": NaN / non-str / "" cell (decided by the caller through `missing`)
+    SP_UNDECODABLE = 2,   // "JSON解析失败"
+    SP_NOT_A_LIST = 3,    // "objects不是列表"
+    SP_NO_OBJECTS = 4,    // "标注字段objects为空"
+    SP_IRREGULAR = 5      // the Python path decides (non-dict document, odd "name" values, duplicate keys ...)
+};
+enum SplitEvent : uint8_t { EV_NO_NAME = 1, EV_UNDEFINED = 2, EV_NOTHING_CLASSIFIED = 3 };
+
+// str.isspace() code points: what str.strip() removes
+bool py_space(uint32_t c) {
+    return (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x20) || c == 0x85 || c == 0xa0 || c == 0x1680 ||
+           (c >= 0x2000 && c <= 0x200a) || c == 0x2028 || c == 0x2029 || c == 0x202f || c == 0x205f || c == 0x3000;
+}
+
+// decodes one UTF-8 code point of a VALID sequence (the buffers come from Python's str.encode)
+uint32_t next_cp(const char *&q, const char *e) {
+    const unsigned char c = (unsigned char)*q;
+    if (c < 0x80) { ++q; return c; }
+    int n = (c >= 0xf0) ? 3 : (c >= 0xe0) ? 2 : 1;
+    uint32_t cp = c & (0x3f >> n);
+    ++q;
+    while (n-- > 0 && q < e) cp = (cp << 6) | ((unsigned char)*q++ & 0x3f);
+    return cp;
+}
+
+// the decoded (UTF-8) value of a raw JSON string span
+void decode_string(Parser &ps, Span s, std::string &out) {
+    out.clear();
+    const char *q = s.b;
+    while (q < s.e) {
+        const unsigned char c = (unsigned char)*q;
+        if (c != '\\') { out += (char)c; ++q; continue; }
+        const char esc = q[1];
+        if (esc == 'u') {
+            uint32_t cp = (uint32_t)hex4(q + 2);
+            q += 6;
+            if (cp >= 0xD800 && cp <= 0xDBFF) {   // string_token accepted only completed pairs
+                const int lo = hex4(q + 2);
+                cp = 0x10000 + ((cp - 0xD800) << 10) + ((uint32_t)lo - 0xDC00);
+                q += 6;
+            } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                ps.irregular();
+            }
+            append_utf8(out, cp);
+        } else {
+            switch (esc) {
+                case 'b': out += '\b'; break;
+                case 'f': out += '\f'; break;
+                case 'n': out += '\n'; break;
+                case 'r': out += '\r'; break;
+                case 't': out += '\t'; break;
+                default: out += esc; break;   // " \ /
+            }
+            q += 2;
+        }
+    }
+}
+
+// re.split(r"[,，;；|]", name), every token stripped, empty tokens dropped (utils.py:659-662)
+void split_labels(const std::string &name, std::vector<std::string> &labels) {
+    labels.clear();
+    const char *q = name.data(), *e = q + name.size();
+    const char *tok_b = q;
+    auto flush = [&](const char *tb, const char *te) {
+        const char *a = tb;   // strip from the left
+        while (a < te) {
+            const char *n = a;
+            if (!py_space(next_cp(n, te))) break;
+            a = n;
+        }
+        const char *z = te;   // strip from the right: walk code points, remember the end of the last non-space
+        const char *last = a;
+        for (const char *w = a; w < z;) {
+            const char *n = w;
+            const uint32_t cp = next_cp(n, z);
+            if (!py_space(cp)) last = n;
+            w = n;
+        }
+        if (last > a) labels.emplace_back(a, last);
+    };
+    while (q < e) {
+        const char *n = q;
+        const uint32_t cp = next_cp(n, e);
+        if (cp == ',' || cp == ';' || cp == '|' || cp == 0xFF0C || cp == 0xFF1B) {
+            flush(tok_b, q);
+            tok_b = n;
+        }
+        q = n;
+    }
+    flush(tok_b, e);
+}
+
+// json.dumps(str, ensure_ascii=False) of decoded UTF-8 text
+void quote_utf8(std::string &out, const std::string &s) {
+    out += '"';
+    for (const char ch : s) {
+        const unsigned char c = (unsigned char)ch;
+        if (c == '"' || c == '\\' || c < 0x20) append_escaped_cp(out, c);
+        else out += ch;
+    }
+    out += '"';
+}
+
+struct ObjText {          // canonical text of one dict element of "objects", the value of "name" cut out
+    std::string before, after;
+    bool has_name = false;
+    std::string name;     // decoded, "" when the value is falsy (no labels either way)
+};
+
+struct SplitPart {        // per-thread outputs, concatenated in cell order afterwards
+    int64_t lo = 0, hi = 0;
+    std::string json, ev_text, combo, reasons;
+    std::vector<int64_t> json_end, row_cell, ev_cell, ev_text_end;
+    std::vector<int32_t> row_label;
+    std::vector<uint8_t> ev_kind;
+};
+
+using LabelMap = std::unordered_map<std::string_view, int32_t>;
+
+// one dict element of "objects" (p at '{') -> canonical text around the name value
+void split_object(Parser &ps, ObjText &o) {
+    o.before.clear(); o.after.clear(); o.has_name = false; o.name.clear();
+    std::string *cur = &o.before;
+    ++ps.p;
+    *cur += '{';
+    KeySet ks;
+    bool first = true;
+    if (ps.peek() == '}') { ++ps.p; *cur += '}'; return; }
+    while (true) {
+        ps.ws();
+        const Span k = ps.string_token();
+        ks.add(ps, k);
+        if (!first) *cur += ", ";
+        first = false;
+        ps.emit_string(*cur, k);
+        *cur += ": ";
+        ps.ws();
+        if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+        ++ps.p;
+        if (Parser::span_is(k, "name")) {
+            o.has_name = true;
+            const Kind kd = kind_of(ps.peek());
+            if (kd == K_STRING) {
+                ps.ws();
+                const Span v = ps.string_token();
+                decode_string(ps, v, o.name);
+            } else if (kd == K_NULL || kd == K_FALSE) {
+                ps.value(nullptr);                       // falsy: no labels
+            } else if (kd == K_ARRAY || kd == K_OBJECT) {
+                const char open = *ps.p;
+                ++ps.p;
+                if (ps.peek() != (open == '[' ? ']' : '}')) ps.irregular();   // str(list / dict) as a label: Python path
+                ++ps.p;
+            } else {
+                ps.irregular();                          // numbers (0 is falsy, 7 -> "7") and true: Python path
+            }
+            cur = &o.after;
+        } else {
+            ps.value(cur);
+        }
+        const char d = ps.peek();
+        if (d == ',') { ++ps.p; continue; }
+        if (d == '}') { ++ps.p; break; }
+        ps.bad();
+    }
+    *cur += '}';
+}
+
+// whole cell.  Throws Fail.  Returns the status; fills part with the cell's records / events.
+SplitStatus split_cell(Span cell, int64_t ci, const LabelMap &map, SplitPart &pt, int32_t &n_out) {
+    Parser ps{cell.b, cell.e};
+    n_out = 0;
+    ps.ws();
+    if (ps.p >= ps.end) ps.bad();
+    if (*ps.p != '{') {   // list / scalar document: data.get raises -> str(exception) is the reason: Python path
+        ps.value(nullptr);
+        ps.ws();
+        if (ps.p != ps.end) ps.bad();
+        ps.irregular();
+    }
+    ++ps.p;
+    std::string head;     // canonical "key": value of every member except "objects", ", "-joined
+    std::vector<ObjText> objs;
+    int64_t n_elements = 0;
+    int objects_kind = -1;   // -1 absent, 0 array, 1 something else
+    KeySet ks;
+    if (ps.peek() == '}') {
+        ++ps.p;
+    } else {
+        while (true) {
+            ps.ws();
+            const Span k = ps.string_token();
+            ks.add(ps, k);
+            ps.ws();
+            if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+            ++ps.p;
+            if (Parser::span_is(k, "objects")) {
+                if (kind_of(ps.peek()) != K_ARRAY) {
+                    objects_kind = 1;
+                    ps.value(nullptr);
+                } else {
+                    objects_kind = 0;
+                    ++ps.p;
+                    if (ps.peek() == ']') {
+                        ++ps.p;
+                    } else {
+                        while (true) {
+                            ++n_elements;
+                            if (ps.peek() == '{') {
+                                objs.emplace_back();
+                                split_object(ps, objs.back());
+                            } else {
+                                ps.value(nullptr);   // non-dict elements are skipped (:742)
+                            }
+                            const char d = ps.peek();
+                            if (d == ',') { ++ps.p; continue; }
+                            if (d == ']') { ++ps.p; break; }
+                            ps.bad();
+                        }
+                    }
+                }
+            } else {
+                if (!head.empty()) head += ", ";
+                ps.emit_string(head, k);
+                head += ": ";
+                ps.value(&head);
+            }
+            const char d = ps.peek();
+            if (d == ',') { ++ps.p; continue; }
+            if (d == '}') { ++ps.p; break; }
+            ps.bad();
+        }
+    }
+    ps.ws();
+    if (ps.p != ps.end) ps.bad();
+    if (objects_kind == 1) return SP_NOT_A_LIST;
+    if (n_elements == 0) return SP_NO_OBJECTS;
+
+    std::vector<std::string> labels, all, undefined;
+    std::vector<std::vector<std::string>> per_obj(objs.size());
+    for (size_t i = 0; i < objs.size(); ++i) {
+        if (objs[i].has_name && !objs[i].name.empty()) split_labels(objs[i].name, per_obj[i]);
+        all.insert(all.end(), per_obj[i].begin(), per_obj[i].end());
+    }
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (size_t i = 0; i < all.size(); ++i) {   // "，".join(sorted(raw_label_set)) (:736)
+        if (i) pt.combo += "\xef\xbc\x8c";
+        pt.combo += all[i];
+    }
+    auto event = [&](uint8_t kind, const std::string &text) {
+        pt.ev_cell.push_back(ci);
+        pt.ev_kind.push_back(kind);
+        pt.ev_text += text;
+        pt.ev_text_end.push_back((int64_t)pt.ev_text.size());
+    };
+    for (size_t i = 0; i < objs.size(); ++i) {
+        if (per_obj[i].empty()) { event(EV_NO_NAME, std::string()); continue; }   // "标注框缺少name字段" (:746-749)
+        for (const std::string &label : per_obj[i]) {
+            const auto it = map.find(std::string_view(label));
+            if (it == map.end()) {                                               // :752-758
+                event(EV_UNDEFINED, label);
+                undefined.push_back(label);
+                continue;
+            }
+            std::string &o = pt.json;                                            // :760-767
+            o += '{';
+            o += head;
+            if (!head.empty()) o += ", ";
+            o += "\"objects\": [";
+            o += objs[i].before;
+            quote_utf8(o, label);
+            o += objs[i].after;
+            o += "]}";
+            pt.json_end.push_back((int64_t)o.size());
+            pt.row_cell.push_back(ci);
+            pt.row_label.push_back(it->second);
+            ++n_out;
+        }
+    }
+    std::sort(undefined.begin(), undefined.end());
+    undefined.erase(std::unique(undefined.begin(), undefined.end()), undefined.end());
+    for (size_t i = 0; i < undefined.size(); ++i) {   // "；".join(sorted(row_reason_set)) (:779, :790)
+        if (i) pt.reasons += "\xef\xbc\x9b";
+        pt.reasons += "\xe6\xa0\x87\xe7\xad\xbe";                      // 标签
+        pt.reasons += undefined[i];
+        pt.reasons += "\xe6\x9c\xaa\xe5\x9c\xa8\xe8\xa7\x84\xe5\x88\x99\xe4\xb8\xad\xe5\xae\x9a\xe4\xb9\x89";   // 未在规则中定义
+    }
+    if (n_out == 0) event(EV_NOTHING_CLASSIFIED, std::string());
+    return SP_OK;
+}
+
+}  // namespace
+
+struct dyd_split {
+    int64_t n_cells = 0;
+    std::vector<uint8_t> status;
+    std::vector<int32_t> n_expanded;
+    std::string combo, reasons, json, ev_text;
+    std::vector<int64_t> combo_off, reasons_off, json_off, ev_text_off, row_cell, ev_cell;
+    std::vector<int32_t> row_label;
+    std::vector<uint8_t> ev_kind;
+};
+
+extern "C" {
+
+// labels: the keys of label_to_category, concatenated UTF-8 with offsets.  `missing[i]` != 0 marks a row without
+// a usable JSON cell (status SP_EMPTY).  The handle owns every output.
+int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                          const uint8_t *label_text, const int64_t *label_off, int32_t n_labels, int n_threads,
+                          dyd_split **out) {
+    if (!out || n_cells < 0 || n_labels < 0 || (n_cells > 0 && !cell_off) || (n_labels > 0 && (!label_text || !label_off)))
+        return DYD_ERR_INVALID;
+    dyd_split *h = new (std::nothrow) dyd_split();
+    if (!h) return DYD_ERR_OOM;
+    try {
+        h->n_cells = n_cells;
+        h->status.assign((size_t)n_cells, SP_OK);
+        h->n_expanded.assign((size_t)n_cells, 0);
+        LabelMap map;
+        map.reserve((size_t)n_labels * 2 + 1);
+        for (int32_t i = 0; i < n_labels; ++i)
+            map.emplace(std::string_view((const char *)label_text + label_off[i], (size_t)(label_off[i + 1] - label_off[i])), i);
+        std::vector<SplitPart> parts(64);
+        std::vector<int64_t> combo_len((size_t)n_cells, 0), reasons_len((size_t)n_cells, 0);
+        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            SplitPart &pt = parts[(size_t)t];
+            pt.lo = lo; pt.hi = hi;
+            for (int64_t i = lo; i < hi; ++i) {
+                if (missing && missing[i]) { h->status[(size_t)i] = SP_EMPTY; continue; }
+                const size_t m_json = pt.json.size(), m_je = pt.json_end.size(), m_ev = pt.ev_cell.size(), m_et = pt.ev_text.size(),
+                             m_combo = pt.combo.size(), m_reasons = pt.reasons.size();
+                int32_t n_out = 0;
+                try {
+                    h->status[(size_t)i] = split_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, i,
+                                                      map, pt, n_out);
+                    h->n_expanded[(size_t)i] = n_out;
+                } catch (Fail f) {
+                    pt.json.resize(m_json); pt.json_end.resize(m_je); pt.row_cell.resize(m_je); pt.row_label.resize(m_je);
+                    pt.ev_cell.resize(m_ev); pt.ev_kind.resize(m_ev); pt.ev_text_end.resize(m_ev); pt.ev_text.resize(m_et);
+                    pt.combo.resize(m_combo); pt.reasons.resize(m_reasons);
+                    h->status[(size_t)i] = (f.code == 1) ? SP_UNDECODABLE : SP_IRREGULAR;
+                }
+                combo_len[(size_t)i] = (int64_t)(pt.combo.size() - m_combo);
+                reasons_len[(size_t)i] = (int64_t)(pt.reasons.size() - m_reasons);
+            }
+        });
+        std::sort(parts.begin(), parts.end(), [](const SplitPart &a, const SplitPart &b) { return a.lo < b.lo; });
+        h->json_off.push_back(0);
+        h->ev_text_off.push_back(0);
+        for (auto &pt : parts) {
+            const int64_t jb = (int64_t)h->json.size(), eb = (int64_t)h->ev_text.size();
+            h->json += pt.json;
+            h->ev_text += pt.ev_text;
+            h->combo += pt.combo;
+            h->reasons += pt.reasons;
+            for (int64_t e : pt.json_end) h->json_off.push_back(jb + e);
+            for (int64_t e : pt.ev_text_end) h->ev_text_off.push_back(eb + e);
+            h->row_cell.insert(h->row_cell.end(), pt.row_cell.begin(), pt.row_cell.end());
+            h->row_label.insert(h->row_label.end(), pt.row_label.begin(), pt.row_label.end());
+            h->ev_cell.insert(h->ev_cell.end(), pt.ev_cell.begin(), pt.ev_cell.end());
+            h->ev_kind.insert(h->ev_kind.end(), pt.ev_kind.begin(), pt.ev_kind.end());
+        }
+        h->combo_off.resize((size_t)n_cells + 1);
+        h->reasons_off.resize((size_t)n_cells + 1);
+        h->combo_off[0] = h->reasons_off[0] = 0;
+        for (int64_t i = 0; i < n_cells; ++i) {
+            h->combo_off[(size_t)i + 1] = h->combo_off[(size_t)i] + combo_len[(size_t)i];
+            h->reasons_off[(size_t)i + 1] = h->reasons_off[(size_t)i] + reasons_len[(size_t)i];
+        }
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    *out = h;
+    return DYD_OK;
+}
+
+const uint8_t *dyd_split_status(const dyd_split *h) { return h->status.data(); }
+const int32_t *dyd_split_n_expanded(const dyd_split *h) { return h->n_expanded.data(); }
+int64_t dyd_split_rows(const dyd_split *h) { return (int64_t)h->row_cell.size(); }
+const int64_t *dyd_split_row_cell(const dyd_split *h) { return h->row_cell.data(); }
+const int32_t *dyd_split_row_label(const dyd_split *h) { return h->row_label.data(); }
+int64_t dyd_split_events(const dyd_split *h) { return (int64_t)h->ev_cell.size(); }
+const int64_t *dyd_split_event_cell(const dyd_split *h) { return h->ev_cell.data(); }
+const uint8_t *dyd_split_event_kind(const dyd_split *h) { return h->ev_kind.data(); }
+// which: 0 record JSON [rows], 1 label combination per cell [n_cells], 2 joined reasons per cell [n_cells],
+// 3 label of each event [events]
+int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const int64_t **off) {
+    if (!h || !data || !off) return DYD_ERR_INVALID;
+    switch (which) {
+        case 0: *data = (const uint8_t *)h->json.data(); *off = h->json_off.data(); return DYD_OK;
+        case 1: *data = (const uint8_t *)h->combo.data(); *off = h->combo_off.data(); return DYD_OK;
+        case 2: *data = (const uint8_t *)h->reasons.data(); *off = h->reasons_off.data(); return DYD_OK;
+        case 3: *data = (const uint8_t *)h->ev_text.data(); *off = h->ev_text_off.data(); return DYD_OK;
+        default: return DYD_ERR_INVALID;
+    }
+}
+void dyd_split_free(dyd_split *h) { delete h; }
+
+}  // extern "C"

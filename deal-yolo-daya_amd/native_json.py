@@ -185,3 +185,60 @@ def scan_boxes(cells, n_threads: int = 0) -> BoxScan:
     _native.check(L.dyd_json_scan_boxes(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1,
                                         n_threads, C.byref(h)), "dyd_json_scan_boxes")
     return BoxScan(h, len(off) - 1, keep)
+
+
+# ------------------------------------------------------------------------------------------ split step
+SP_OK, SP_EMPTY, SP_UNDECODABLE, SP_NOT_A_LIST, SP_NO_OBJECTS, SP_IRREGULAR = 0, 1, 2, 3, 4, 5
+EV_NO_NAME, EV_UNDEFINED, EV_NOTHING_CLASSIFIED = 1, 2, 3
+
+
+def _strings(data_ptr, off_ptr, count) -> np.ndarray:
+    """object array of str from a flat utf-8 buffer + offsets (one C pass through pyarrow)"""
+    import pyarrow as pa
+
+    if count == 0:
+        return np.empty(0, object)
+    off = _view(off_ptr, np.int64, count + 1)
+    data = _view(data_ptr, np.uint8, max(int(off[-1]), 1))
+    arr = pa.LargeStringArray.from_buffers(count, pa.py_buffer(off), pa.py_buffer(data))
+    return arr.to_numpy(zero_copy_only=False).astype(object)
+
+
+class SplitExpansion:
+    """Result of split_expand, copied out of the native handle."""
+
+    def __init__(self, handle, n_cells):
+        L = _native.load_library()
+        try:
+            self.status = _view(L.dyd_split_status(handle), np.uint8, n_cells).copy()
+            self.n_expanded = _view(L.dyd_split_n_expanded(handle), np.int32, n_cells).copy()
+            rows, events = int(L.dyd_split_rows(handle)), int(L.dyd_split_events(handle))
+            self.row_cell = _view(L.dyd_split_row_cell(handle), np.int64, rows).copy()
+            self.row_label = _view(L.dyd_split_row_label(handle), np.int32, rows).copy()
+            self.event_cell = _view(L.dyd_split_event_cell(handle), np.int64, events).copy()
+            self.event_kind = _view(L.dyd_split_event_kind(handle), np.uint8, events).copy()
+            d, o = C.c_void_p(), C.c_void_p()
+            out = []
+            for which, count in ((0, rows), (1, n_cells), (2, n_cells), (3, events)):
+                _native.check(L.dyd_split_strings(handle, which, C.byref(d), C.byref(o)), "dyd_split_strings")
+                out.append(_strings(d.value, o.value, count))
+            self.row_json, self.combo, self.reasons, self.event_label = out
+        finally:
+            L.dyd_split_free(handle)
+
+
+def split_expand(cells, labels: list, n_threads: int = 0) -> SplitExpansion:
+    """cells: per row the JSON cell the reference would pick (str) or None; labels: keys of label_to_category"""
+    L = _native.load_library()
+    buf, off, missing, keep = cells_to_buffers(cells)
+    for i, c in enumerate(cells):                       # "" is not a usable cell either (processor.py:716)
+        if c == "":
+            missing[i] = 1
+    lab = [s.encode("utf-8") for s in labels]
+    lab_off = np.zeros(len(lab) + 1, np.int64)
+    np.cumsum([len(b) for b in lab], out=lab_off[1:])
+    lab_buf = np.frombuffer(b"".join(lab) or b"\0", dtype=np.uint8)
+    h = C.c_void_p()
+    _native.check(L.dyd_json_split_expand(buf.ctypes.data, off.ctypes.data, missing.ctypes.data, len(cells), lab_buf.ctypes.data,
+                                          lab_off.ctypes.data, len(lab), n_threads, C.byref(h)), "dyd_json_split_expand")
+    return SplitExpansion(h, len(cells))

@@ -215,6 +215,33 @@ const uint8_t *dyd_scan_wh_kind(const dyd_scan *scan, int which);   /* which: 0 
 const double *dyd_scan_wh_value(const dyd_scan *scan, int which);
 void dyd_scan_free(dyd_scan *scan);
 
+/* ---- native expansion of the split step (HOST code, multithreaded) -----------------------------------
+ * Replaces the per-row Python of split_dataset_by_rules (processor.py:712-792; utils.py:645-662): every row
+ * becomes one record per (object, label of the object's name found in the rules), the record's JSON being the
+ * row's document with "objects" reduced to that object and its "name" set to the label (:760-767).
+ * text/cell_off/missing: the rows' JSON cells (missing = no usable cell: "空数据"); label_text/label_off: the
+ * keys of label_to_category.  Per cell: status (0 expanded, 1 空数据, 2 JSON解析失败, 3 objects不是列表,
+ * 4 标注字段objects为空, 5 irregular: the Python path decides), number of records, the label combination
+ * ("，".join(sorted(labels)), :736) and the joined reasons ("；".join(sorted(标签…未在规则中定义)), :779).
+ * Records in row order: cell index, label index, JSON text.  Events in the order the reference appends to its
+ * unclassified list: cell index, kind (1 标注框缺少name字段, 2 label not in the rules, 3 nothing classified),
+ * the label for kind 2. */
+typedef struct dyd_split dyd_split;
+int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                          const uint8_t *label_text, const int64_t *label_off, int32_t n_labels, int n_threads,
+                          dyd_split **out);
+const uint8_t *dyd_split_status(const dyd_split *h);          /* [n_cells] */
+const int32_t *dyd_split_n_expanded(const dyd_split *h);      /* [n_cells] */
+int64_t dyd_split_rows(const dyd_split *h);
+const int64_t *dyd_split_row_cell(const dyd_split *h);        /* [rows] */
+const int32_t *dyd_split_row_label(const dyd_split *h);       /* [rows] */
+int64_t dyd_split_events(const dyd_split *h);
+const int64_t *dyd_split_event_cell(const dyd_split *h);      /* [events] */
+const uint8_t *dyd_split_event_kind(const dyd_split *h);      /* [events] */
+/* which: 0 record JSON [rows], 1 label combination [n_cells], 2 joined reasons [n_cells], 3 event label [events] */
+int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const int64_t **off);
+void dyd_split_free(dyd_split *h);
+
 /* ---- native CSV hand-off (HOST code) ------------------------------------------------
  * Replaces pandas read_csv / to_csv around the two heavy JSON columns (processor.py:235, :309, :379,
  * :404, :407).  dyd_csv_index tokenises a utf-8 buffer with pandas' C-parser conventions and FAILS on

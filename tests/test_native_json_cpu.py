@@ -257,3 +257,62 @@ def test_float_repr_matches_python():
     out = scan.emit(np.zeros((0, 4), np.int32))
     for cell, got in zip(cells, out):
         assert got == json.dumps(json.loads(cell), ensure_ascii=False)
+
+
+# ------------------------------------------------------------------------------------------ split expansion
+NAMES = ['"c1"', '"c2"', '"c1,c2"', '"c1，c3；zz"', '" c2 | c1 "', '"c1;;c2"', '""', '" "', '","', '"\\u3000c1\\u3000"', '"c1\\u00a0"',
+         '"\\tc2\\n"', '"undefined"', '"中文,c1"', '"中文"', '"a\\"b"', '"c1|c1"', 'null', 'false', 'true', '0', '7', '1.5', '[]', '{}',
+         '["c1"]', '{"a": 1}', '"\\ud83d\\ude00"', '"x\\u001fy"', '"c1\\u001f"']
+LABEL_MAP = {"c1": "catA", "c2": "catA", "c3": "catB", "中文": "catB", 'a"b': "catC", "😀": "catC"}
+
+
+class SplitGen(Gen):
+    STR_NAMES = [n for n in NAMES if n.startswith('"')]
+    OTHER_KEYS = [k for k in KEYS if k != '"name"']
+
+    def annotation_object(self, two=False):
+        items = []
+        if self.r.random() < 0.85:
+            items.append('"name": ' + (self.r.choice(self.STR_NAMES) if self.r.random() < 0.93 else self.r.choice(NAMES)))
+        if self.r.random() < 0.6:
+            items.append(f'"polygon": {{"ptList": {self.ptlist(two)}}}')
+        if self.r.random() < 0.3:
+            items.append(self.r.choice(self.OTHER_KEYS) + ": " + self.value(2))
+        if self.r.random() < 0.02 and items:
+            items.append(items[0])                      # duplicate key
+        self.r.shuffle(items)
+        return "{" + ("," + self.ws()).join(items) + "}"
+
+
+def _norm(ex):
+    return {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in ex.items()}
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_split_expansion_fuzz_matches_cpython(seed, monkeypatch):
+    g = SplitGen(2000 + seed)
+    cells = [g.cell() for _ in range(500)] + [None, "", '{"objects": [{"name": "c1"}], "k": 1e5}']
+    for i in range(0, len(cells), 37):
+        cells[i] = None if i % 2 else ""
+    native = P._expand_rows(cells, LABEL_MAP)
+    from deal_yolo_daya_amd import native_json
+    st = native_json.split_expand(cells, list(LABEL_MAP)).status
+    assert (st == native_json.SP_OK).sum() > 90 and (st == native_json.SP_IRREGULAR).sum() > 5
+    monkeypatch.setenv("DYD_NATIVE_JSON", "0")
+    plain = P._expand_rows(cells, LABEL_MAP)
+    a, b = _norm(native), _norm(plain)
+    for key in b:
+        assert a[key] == b[key], key
+    assert len(b["json"]) > 100 and len(b["unclassified"]) > 100
+
+
+def test_split_expansion_label_rules():
+    """separators, Unicode whitespace stripping, repeated labels, order of records and events"""
+    cells = ['{"a": 1, "objects": [{"name": "\\u3000c1 ,\\u00a0c2；zz|c1", "id": 1}, 5, {"id": 2}, {"name": "c3"}], "b": [1.0, "x"]}']
+    ex = P._expand_rows(cells, LABEL_MAP)
+    assert ex["label"].tolist() == ["c1", "c2", "c1", "c3"]
+    assert ex["json"][0] == '{"a": 1, "b": [1.0, "x"], "objects": [{"name": "c1", "id": 1}]}'
+    assert ex["json"][3] == '{"a": 1, "b": [1.0, "x"], "objects": [{"name": "c3"}]}'
+    assert ex["combo_of_row"].tolist() == ["c1，c2，c3，zz"]
+    assert ex["unclassified"] == [(0, "标签zz未在规则中定义", "zz"), (0, "标注框缺少name字段", None)]
+    assert ex["verdict"].tolist() == ["部分可分类"] and ex["reasons_of_row"].tolist() == ["标签zz未在规则中定义"]

@@ -92,6 +92,30 @@ def main():
         chain(P, "warm", prod_names)
         out["product_chain_csv_to_csv"] = chain(P, "prod", prod_names)
         out["product_chain_io_paths"] = dict(P.LAST_IO_PATH)
+        # ---- merge step (f3): the table cut into 4 files and merged back ------------------------------------
+        os.makedirs(Q("parts"))
+        quarter = (args.rows + 3) // 4
+        for k in range(4):
+            df.iloc[k * quarter:(k + 1) * quarter].to_csv(Q(f"parts/part{k}.csv"), index=False, encoding="utf-8-sig")
+        import contextlib, io as _io
+        with contextlib.redirect_stdout(_io.StringIO()):
+            P.merge_all_csv_in_folder(Q("parts"), Q("merged_warm.csv"))
+            s_m, n_m = clock(lambda: P.merge_all_csv_in_folder(Q("parts"), Q("merged_prod.csv")))
+        out["product_merge"] = {"s": round(s_m, 3), "rows_per_s": round(n_m / s_m), "io_paths": dict(P.LAST_IO_PATH["merge"])}
+        # ---- split + YOLO label texts (a5 in memory, f4) ----------------------------------------------------
+        rules = pd.DataFrame({"catA": [f"c{i}" for i in range(10)], "catB": [f"c{i}" for i in range(10, 18)] + [None, None]})
+        lmap = P.rules_to_label_map(rules)
+        s_sp, sp = clock(lambda: P.split_frames(kept, lmap))
+        sheet = pd.concat([fr for cat in sp["categories"].values() for fr in cat], ignore_index=True)
+        classes = sorted(set(sheet["分类标签"]))
+        cid = {c: i for i, c in enumerate(classes)}
+        ycells, ylabels = sheet[P.BBOX_COL].tolist(), sheet["分类标签"].tolist()
+        ycids, yw, yh = [cid[v] for v in ylabels], sheet["width"].tolist(), sheet["height"].tolist()
+        P.yolo_label_texts(ycells[:100], ylabels[:100], ycids[:100], yw[:100], yh[:100])
+        ystats = {}
+        s_y, (ytexts, _) = clock(lambda: P.yolo_label_texts(ycells, ylabels, ycids, yw, yh, None, ystats))
+        out["product_split_frames"] = {"s": round(s_sp, 3), "expanded_rows": len(sheet), "input_rows_per_s": round(len(kept) / s_sp)}
+        out["product_yolo_label_texts"] = {"s": round(s_y, 3), "rows": len(sheet), "rows_per_s": round(len(sheet) / s_y), **ystats}
         # ---- CPU port of the reference, path level ------------------------------------------------------
         if not args.skip_cpu:
             s1, _ = clock(lambda: osteps.replace_csv(Q("in.csv"), Q("rp.csv"), Q("re.csv")))
@@ -104,6 +128,13 @@ def main():
             out["cpu_port_chain_csv_to_csv"] = chain(osteps, "cpu", ("dedup_csv", "ref_filter_csv", "replace_csv", "iou_filter_csv"))
             out["chain_outputs_byte_identical"] = all(
                 open(Q(f"{n}_prod.csv"), "rb").read() == open(Q(f"{n}_cpu.csv"), "rb").read() for n in ("c1", "c2", "c3", "c3e", "c4h", "c4o"))
+            with contextlib.redirect_stdout(_io.StringIO()):
+                s_m, n_m = clock(lambda: osteps.merge_folder(Q("parts"), Q("merged_cpu.csv")))
+            out["cpu_port_merge"] = {"s": round(s_m, 3), "rows_per_s": round(n_m / s_m)}
+            out["merge_output_byte_identical"] = open(Q("merged_prod.csv"), "rb").read() == open(Q("merged_cpu.csv"), "rb").read()
+            s_y, want = clock(lambda: [osteps.yolo_row_text(c, l, k, w, h)[0] for c, l, k, w, h in zip(ycells, ylabels, ycids, yw, yh)])
+            out["cpu_port_yolo_label_texts"] = {"s": round(s_y, 3), "rows_per_s": round(len(sheet) / s_y)}
+            out["yolo_texts_identical"] = want == ytexts
     print(json.dumps(out, ensure_ascii=False))
 
 
