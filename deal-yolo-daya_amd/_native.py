@@ -92,6 +92,9 @@ SIGNATURES = {
     "dyd_scan_wh_kind": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_wh_value": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_free": (None, [C.c_void_p]),
+    "dyd_json_scan_labelled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_void_p)]),
+    "dyd_scan_sel": (C.c_void_p, [C.c_void_p]),
     "dyd_json_split_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int,
                                         C.POINTER(C.c_void_p)]),
     "dyd_split_status": (C.c_void_p, [C.c_void_p]),

@@ -974,21 +974,11 @@ def _plain_number(v, limit=_EXACT_INT) -> bool:
     return False
 
 
-def yolo_label_texts(cells, label_values, class_ids, widths, heights, backend=None, stats: Optional[dict] = None):
-    """Label-file text per row of a split sheet: the part of generate_yolo_datasets_from_excels between the
-    box extraction and ``label_path.write_text`` (reference processor.py:1004-1060), batched.
-
-    cells[i] is the row's annotation JSON, label_values[i] = str(row[label_col]) (:992), class_ids[i] =
-    class_to_id[label_value] (:1049), widths / heights the row's image size (:1013-1014).
-    -> (texts, reasons): texts[i] is "\n".join(label_lines) or None; reasons[i] is the reference's skip
-    reason for a None (无匹配标签框 / 缺少图像尺寸 / 标注框无效) in the order the reference tests them.
-    Host: box extraction + label match; device: K7 (arithmetic, exact "%.6f", joining)."""
-    be = _backend(backend)
-    n = len(cells)
-    texts, reasons = [None] * n, [None] * n
+def _yolo_rows_python(rows, cells, label_values, class_ids, widths, heights, be, texts, reasons, stats):
+    """rows of the batch through CPython's json (box extraction) + K7; everything irregular on Python numbers"""
     dev_rows, dev_boxes, row_off, dev_w, dev_h, dev_cid = [], [], [0], [], [], []
     py_rows = {}
-    for i in range(n):
+    for i in rows:
         boxes = [b for b in _extract_boxes_with_labels(cells[i]) if b[0] == label_values[i]]
         if not boxes:
             reasons[i] = REASON_NO_MATCHING_BOX
@@ -1027,8 +1017,85 @@ def yolo_label_texts(cells, label_values, class_ids, widths, heights, backend=No
             texts[i] = "\n".join(lines)
         else:
             reasons[i] = REASON_NO_VALID_BOX
+    stats["device_rows"] += len(dev_rows)
+    stats["python_rows"] += len(py_rows)
+
+
+def _numeric_sizes(values):
+    """-> float64 array when every value is a plain int / float below 2^53 (so `not v` is `v == 0`), else None"""
+    if pd.api.types.infer_dtype(values, skipna=False) not in ("integer", "floating", "mixed-integer-float"):
+        return None
+    arr = np.asarray(values, np.float64)
+    return arr if not (np.abs(arr[np.isfinite(arr)]) > float(1 << 53)).any() else None
+
+
+def yolo_label_texts(cells, label_values, class_ids, widths, heights, backend=None, stats: Optional[dict] = None):
+    """Label-file text per row of a split sheet: the part of generate_yolo_datasets_from_excels between the
+    box extraction and ``label_path.write_text`` (reference processor.py:1004-1060), batched.
+
+    cells[i] is the row's annotation JSON, label_values[i] = str(row[label_col]) (:992), class_ids[i] =
+    class_to_id[label_value] (:1049), widths / heights the row's image size (:1013-1014).
+    -> (texts, reasons): texts[i] is "\n".join(label_lines) or None; reasons[i] is the reference's skip
+    reason for a None (无匹配标签框 / 缺少图像尺寸 / 标注框无效) in the order the reference tests them.
+    Host: native labelled-box scan (csrc/host_json.cpp; CPython json for irregular cells) + label match;
+    device: K7 (arithmetic, exact "%.6f", joining)."""
+    be = _backend(backend)
+    n = len(cells)
+    texts, reasons = [None] * n, [None] * n
+    st = {"rows": n, "device_rows": 0, "python_rows": 0, "python_cells": 0}
+    rest = range(n)
+    w_arr, h_arr = _numeric_sizes(widths), _numeric_sizes(heights)
+    cid_ok = n > 0 and pd.api.types.infer_dtype(class_ids, skipna=False) == "integer"
+    if n and _nj.enabled() and w_arr is not None and h_arr is not None and cid_ok and all(type(v) is str for v in label_values):
+        cid_arr = np.asarray(class_ids, np.int64)
+        try:
+            scan = _nj.scan_labelled(cells, label_values) if ((cid_arr >= 0) & (cid_arr < (1 << 31))).all() else None
+        except UnicodeEncodeError:
+            scan = None
+        if scan is not None:
+            regular = scan.status != _nj.IRREGULAR
+            counts = np.diff(scan.cell_box_off)
+            n_sel = np.add.reduceat(np.concatenate([scan.sel, [0]]).astype(np.int64), scan.cell_box_off[:-1].astype(np.int64)) \
+                if scan.n_boxes else np.zeros(n, np.int64)
+            n_sel = np.where(counts > 0, n_sel, 0)
+            no_box = regular & (n_sel == 0)
+            no_size = regular & ~no_box & ((w_arr == 0) | (h_arr == 0))
+            dev = np.flatnonzero(regular & ~no_box & ~no_size)
+            for i in np.flatnonzero(no_box).tolist():
+                reasons[i] = REASON_NO_MATCHING_BOX
+            for i in np.flatnonzero(no_size).tolist():
+                reasons[i] = REASON_NO_IMAGE_SIZE
+            if len(dev):
+                # the batch keeps every scanned box: rows outside `dev` get a zero image size, which K7 flags and skips
+                w_dev, h_dev = np.zeros(n), np.zeros(n)
+                w_dev[dev], h_dev[dev] = w_arr[dev], h_arr[dev]
+                off, flag, data = be.yolo_lines(scan.box4, scan.cell_box_off, scan.sel, w_dev, h_dev, cid_arr.astype(np.int32))
+                import pyarrow as pa
+                strs = pa.LargeStringArray.from_buffers(n, pa.py_buffer(np.ascontiguousarray(off)),
+                                                        pa.py_buffer(data if data else b"\0")).to_numpy(zero_copy_only=False)
+                host_rows = []
+                for i in dev.tolist():
+                    f = flag[i]
+                    if f == 0:
+                        texts[i] = strs[i]
+                    elif f == 1:
+                        reasons[i] = REASON_NO_VALID_BOX
+                    else:
+                        host_rows.append(i)
+                st["device_rows"] += len(dev) - len(host_rows)
+                for i in host_rows:                             # values of 2^43 and more: printed from the scanned f64 boxes
+                    b0, b1 = int(scan.cell_box_off[i]), int(scan.cell_box_off[i + 1])
+                    boxes = [(label_values[i], *scan.box4[b].tolist()) for b in range(b0, b1) if scan.sel[b]]   # ints <= 2^52 print the same as floats
+                    lines = _label_lines_python(boxes, class_ids[i], widths[i], heights[i])
+                    texts[i], reasons[i] = ("\n".join(lines), None) if lines else (None, REASON_NO_VALID_BOX)
+                    st["python_rows"] += 1
+            rest = np.flatnonzero(~regular).tolist()
+            scan.close()
+    st["python_cells"] = len(rest)
+    if len(rest):
+        _yolo_rows_python(rest, cells, label_values, class_ids, widths, heights, be, texts, reasons, st)
     if stats is not None:
-        stats.update(rows=n, device_rows=len(dev_rows), python_rows=len(py_rows))
+        stats.update(st)
     return texts, reasons
 
 

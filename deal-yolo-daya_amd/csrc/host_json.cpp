@@ -938,6 +938,7 @@ struct dyd_scan {
     std::vector<uint8_t> status;        // CellStatus per cell
     std::vector<uint8_t> w_kind, h_kind;
     std::vector<double> w_val, h_val;
+    std::vector<uint8_t> sel;           // labelled scan: box carries the row's label
     // emit output
     std::string text;
     std::vector<int64_t> text_off;
@@ -1528,3 +1529,237 @@ int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const
 void dyd_split_free(dyd_split *h) { delete h; }
 
 }  // extern "C"
+
+// ===================================================================================================
+// YOLO step: labelled boxes of a cell (reference utils.py:681-710) for K7
+// ===================================================================================================
+namespace {
+
+// first-wins min / max over the number tokens of one coordinate list, CPython semantics on doubles
+struct MinMax {
+    bool any = false;
+    double lo = 0, hi = 0;
+    void add(double v) {
+        if (!any) { any = true; lo = hi = v; return; }
+        if (v < lo) lo = v;
+        if (v > hi) hi = v;
+    }
+};
+
+double coord_value(Parser &ps, Span tok) {
+    if (kind_of(*tok.b) != K_NUMBER) ps.irregular();                      // None / str / bool / container: TypeError paths
+    const Num n = classify_number(tok);
+    if (n.is_int && std::fabs(n.v) > 4503599627370496.0) ps.irregular();  // > 2^52: exact int arithmetic in the label lines
+    return n.v;
+}
+
+// regular cells only; anything the reference treats through an exception or a non-list container throws Fail{2}
+void labelled_cell(Span cell, std::string_view label, std::vector<double> &box4, std::vector<uint8_t> &sel, int32_t &count) {
+    count = 0;
+    Parser ps{cell.b, cell.e};
+    ps.ws();
+    if (ps.p >= ps.end) ps.bad();
+    if (*ps.p != '{') { ps.value(nullptr); ps.ws(); if (ps.p != ps.end) ps.bad(); ps.irregular(); }
+    ++ps.p;
+    KeySet ks;
+    std::string name;
+    if (ps.peek() == '}') { ++ps.p; ps.ws(); if (ps.p != ps.end) ps.bad(); return; }
+    while (true) {
+        ps.ws();
+        const Span k = ps.string_token();
+        ks.add(ps, k);
+        ps.ws();
+        if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+        ++ps.p;
+        if (!Parser::span_is(k, "objects")) {
+            ps.value(nullptr);
+        } else {
+            if (kind_of(ps.peek()) != K_ARRAY) ps.irregular();
+            ++ps.p;
+            if (ps.peek() == ']') {
+                ++ps.p;
+            } else {
+                while (true) {
+                    if (ps.peek() != '{') {
+                        ps.value(nullptr);                      // non-dict objects are skipped (:689)
+                    } else {
+                        ++ps.p;
+                        KeySet oks;
+                        bool has_name = false, truthy = false, has_box = false;
+                        MinMax xs, ys;
+                        if (ps.peek() == '}') {
+                            ++ps.p;
+                        } else {
+                            while (true) {
+                                ps.ws();
+                                const Span ok = ps.string_token();
+                                oks.add(ps, ok);
+                                ps.ws();
+                                if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+                                ++ps.p;
+                                if (Parser::span_is(ok, "name")) {
+                                    has_name = true;
+                                    const Kind kd = kind_of(ps.peek());
+                                    if (kd == K_STRING) { ps.ws(); decode_string(ps, ps.string_token(), name); truthy = !name.empty(); }
+                                    else if (kd == K_NULL || kd == K_FALSE) ps.value(nullptr);
+                                    else ps.irregular();        // numbers, true, containers: never equal to a str label, Python decides
+                                } else if (Parser::span_is(ok, "polygon")) {
+                                    if (kind_of(ps.peek()) != K_OBJECT) ps.irregular();
+                                    ++ps.p;
+                                    KeySet pks;
+                                    if (ps.peek() == '}') {
+                                        ++ps.p;
+                                    } else {
+                                        while (true) {
+                                            ps.ws();
+                                            const Span pk = ps.string_token();
+                                            pks.add(ps, pk);
+                                            ps.ws();
+                                            if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+                                            ++ps.p;
+                                            if (!Parser::span_is(pk, "ptList")) {
+                                                ps.value(nullptr);
+                                            } else {
+                                                if (kind_of(ps.peek()) != K_ARRAY) ps.irregular();
+                                                ++ps.p;
+                                                if (ps.peek() == ']') {
+                                                    ++ps.p;
+                                                } else {
+                                                    while (true) {
+                                                        if (ps.peek() != '{') {
+                                                            ps.value(nullptr);      // not a dict: no coordinate (:699-700)
+                                                        } else {
+                                                            ++ps.p;
+                                                            KeySet qks;
+                                                            if (ps.peek() == '}') {
+                                                                ++ps.p;
+                                                            } else {
+                                                                while (true) {
+                                                                    ps.ws();
+                                                                    const Span qk = ps.string_token();
+                                                                    qks.add(ps, qk);
+                                                                    ps.ws();
+                                                                    if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+                                                                    ++ps.p;
+                                                                    ps.ws();
+                                                                    const char *b = ps.p;
+                                                                    ps.value(nullptr);
+                                                                    if (Parser::span_is(qk, "x")) xs.add(coord_value(ps, Span{b, ps.p}));
+                                                                    else if (Parser::span_is(qk, "y")) ys.add(coord_value(ps, Span{b, ps.p}));
+                                                                    const char d = ps.peek();
+                                                                    if (d == ',') { ++ps.p; continue; }
+                                                                    if (d == '}') { ++ps.p; break; }
+                                                                    ps.bad();
+                                                                }
+                                                            }
+                                                        }
+                                                        const char d = ps.peek();
+                                                        if (d == ',') { ++ps.p; continue; }
+                                                        if (d == ']') { ++ps.p; break; }
+                                                        ps.bad();
+                                                    }
+                                                }
+                                                has_box = xs.any && ys.any;
+                                            }
+                                            const char d = ps.peek();
+                                            if (d == ',') { ++ps.p; continue; }
+                                            if (d == '}') { ++ps.p; break; }
+                                            ps.bad();
+                                        }
+                                    }
+                                } else {
+                                    ps.value(nullptr);
+                                }
+                                const char d = ps.peek();
+                                if (d == ',') { ++ps.p; continue; }
+                                if (d == '}') { ++ps.p; break; }
+                                ps.bad();
+                            }
+                        }
+                        if (has_name && truthy && has_box) {
+                            const double v[4] = {xs.lo, ys.lo, xs.hi, ys.hi};
+                            box4.insert(box4.end(), v, v + 4);
+                            sel.push_back(std::string_view(name) == label ? 1 : 0);
+                            ++count;
+                        }
+                    }
+                    const char d = ps.peek();
+                    if (d == ',') { ++ps.p; continue; }
+                    if (d == ']') { ++ps.p; break; }
+                    ps.bad();
+                }
+            }
+        }
+        const char d = ps.peek();
+        if (d == ',') { ++ps.p; continue; }
+        if (d == '}') { ++ps.p; break; }
+        ps.bad();
+    }
+    ps.ws();
+    if (ps.p != ps.end) ps.bad();
+}
+
+}  // namespace
+
+extern "C" {
+
+// Labelled boxes for the YOLO step: per cell the (min x, min y, max x, max y) of every named object with a
+// non-empty ptList (utils.py:681-710) and whether its name equals the row's label value (processor.py:1006).
+// Undecodable cells give no boxes (the reference swallows the error); irregular cells (status 2) are left to
+// the Python path.  Results: dyd_scan_xy = box4, dyd_scan_cell_box_off, dyd_scan_status, dyd_scan_sel.
+int dyd_json_scan_labelled(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                           const uint8_t *label_text, const int64_t *label_off, int n_threads, dyd_scan **out) {
+    if (!out || n_cells < 0 || (n_cells > 0 && (!cell_off || !label_off))) return DYD_ERR_INVALID;
+    dyd_scan *h = new (std::nothrow) dyd_scan();
+    if (!h) return DYD_ERR_OOM;
+    h->n_cells = n_cells;
+    try {
+        h->status.assign((size_t)n_cells, CELL_OK);
+        std::vector<int32_t> counts((size_t)n_cells, 0);
+        struct Part { std::vector<double> b; std::vector<uint8_t> s; int64_t lo = 0, hi = 0; };
+        std::vector<Part> parts(64);
+        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            Part &pt = parts[(size_t)t];
+            pt.lo = lo; pt.hi = hi;
+            for (int64_t i = lo; i < hi; ++i) {
+                if (missing && missing[i]) { h->status[(size_t)i] = CELL_MISSING; continue; }
+                const size_t mb = pt.b.size(), ms = pt.s.size();
+                int32_t c = 0;
+                try {
+                    labelled_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]},
+                                  std::string_view((const char *)label_text + label_off[i], (size_t)(label_off[i + 1] - label_off[i])),
+                                  pt.b, pt.s, c);
+                } catch (Fail f) {
+                    pt.b.resize(mb); pt.s.resize(ms);
+                    c = 0;
+                    h->status[(size_t)i] = (f.code == 1) ? CELL_UNDECODABLE : CELL_IRREGULAR;
+                }
+                counts[(size_t)i] = c;
+            }
+        });
+        std::sort(parts.begin(), parts.end(), [](const Part &a, const Part &b) { return a.lo < b.lo; });
+        size_t tot = 0;
+        for (auto &pt : parts) tot += pt.s.size();
+        if (tot >= (size_t)1 << 31) { delete h; return DYD_ERR_RANGE; }
+        h->xy.reserve(tot * 4);
+        h->sel.reserve(tot);
+        for (auto &pt : parts) {
+            h->xy.insert(h->xy.end(), pt.b.begin(), pt.b.end());
+            h->sel.insert(h->sel.end(), pt.s.begin(), pt.s.end());
+        }
+        h->cell_box_off.resize((size_t)n_cells + 1);
+        h->cell_box_off[0] = 0;
+        for (int64_t i = 0; i < n_cells; ++i) h->cell_box_off[(size_t)i + 1] = h->cell_box_off[(size_t)i] + counts[(size_t)i];
+        h->pt_off.assign(1, 0);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    *out = h;
+    return DYD_OK;
+}
+
+const uint8_t *dyd_scan_sel(const dyd_scan *h) { return h->sel.data(); }
+
+}  // extern "C"
+

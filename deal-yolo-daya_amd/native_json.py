@@ -242,3 +242,30 @@ def split_expand(cells, labels: list, n_threads: int = 0) -> SplitExpansion:
     _native.check(L.dyd_json_split_expand(buf.ctypes.data, off.ctypes.data, missing.ctypes.data, len(cells), lab_buf.ctypes.data,
                                           lab_off.ctypes.data, len(lab), n_threads, C.byref(h)), "dyd_json_split_expand")
     return SplitExpansion(h, len(cells))
+
+
+# ------------------------------------------------------------------------------------------ YOLO step
+class LabelledScan(_Scan):
+    """labelled boxes per cell: box4 (min x, min y, max x, max y), cell_box_off, sel (name == the row's label)"""
+
+    def __init__(self, handle, n_cells, keep):
+        super().__init__(handle, n_cells, keep)
+        L = _native.load_library()
+        nb = int(self.cell_box_off[-1]) if n_cells else 0
+        self.n_boxes = nb
+        self.box4 = _view(L.dyd_scan_xy(handle), np.float64, 4 * nb).reshape(-1, 4)
+        self.sel = _view(L.dyd_scan_sel(handle), np.uint8, nb)
+
+
+def scan_labelled(cells, labels, n_threads: int = 0) -> LabelledScan:
+    """cells: annotation JSON per row; labels: the row's label value (str) per row"""
+    L = _native.load_library()
+    buf, off, missing, keep = cells_to_buffers(cells)
+    lab = [s.encode("utf-8") for s in labels]
+    lab_off = np.zeros(len(lab) + 1, np.int64)
+    np.cumsum(np.fromiter(map(len, lab), dtype=np.int64, count=len(lab)), out=lab_off[1:])
+    lab_buf = np.frombuffer(b"".join(lab) or b"\0", dtype=np.uint8)
+    h = C.c_void_p()
+    _native.check(L.dyd_json_scan_labelled(buf.ctypes.data, off.ctypes.data, missing.ctypes.data, len(cells), lab_buf.ctypes.data,
+                                           lab_off.ctypes.data, n_threads, C.byref(h)), "dyd_json_scan_labelled")
+    return LabelledScan(h, len(cells), (keep, lab_buf, lab_off))

@@ -213,6 +213,13 @@ const int32_t *dyd_scan_cell_box_off(const dyd_scan *scan);   /* [n_cells+1] */
 const uint8_t *dyd_scan_status(const dyd_scan *scan);         /* [n_cells] */
 const uint8_t *dyd_scan_wh_kind(const dyd_scan *scan, int which);   /* which: 0 width, 1 height; 0 none 1 int 2 float 3 other */
 const double *dyd_scan_wh_value(const dyd_scan *scan, int which);
+/* YOLO step (utils.py:681-710, processor.py:1006): per cell the (min x, min y, max x, max y) of every named object
+ * with a non-empty ptList, in dyd_scan_xy as box4, and dyd_scan_sel[b] = 1 when the object's name equals the row's
+ * label value (label_text / label_off: one label per cell).  Undecodable cells give no boxes, like the reference's
+ * blanket except; status 2 cells are left to the Python path. */
+int dyd_json_scan_labelled(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                           const uint8_t *label_text, const int64_t *label_off, int n_threads, dyd_scan **out);
+const uint8_t *dyd_scan_sel(const dyd_scan *scan);             /* [n_boxes] (labelled scan only) */
 void dyd_scan_free(dyd_scan *scan);
 
 /* ---- native expansion of the split step (HOST code, multithreaded) -----------------------------------

@@ -316,3 +316,59 @@ def test_split_expansion_label_rules():
     assert ex["combo_of_row"].tolist() == ["c1，c2，c3，zz"]
     assert ex["unclassified"] == [(0, "标签zz未在规则中定义", "zz"), (0, "标注框缺少name字段", None)]
     assert ex["verdict"].tolist() == ["部分可分类"] and ex["reasons_of_row"].tolist() == ["标签zz未在规则中定义"]
+
+
+# ------------------------------------------------------------------------------------------ YOLO labelled boxes
+class YoloGen(SplitGen):
+    STR_NAMES = ['"c1"', '"c1"', '"c2"', '"\\u0063\\u0031"', '"中文"', '"c1,c2"', '""', '"x"']
+
+    def point(self):
+        if self.r.random() < 0.9:
+            items = [f'"x": {self.number()}', f'"y": {self.number()}']
+            self.r.shuffle(items)
+            return "{" + ", ".join(items[: self.r.choice([2, 2, 2, 2, 1])]) + "}"
+        return super().point()
+
+    def cell(self, two=False):
+        if self.r.random() < 0.8:
+            objs = [self.annotation_object() for _ in range(self.r.randint(0, 4))]
+            return '{"objects": [' + ", ".join(objs) + '], "width": 5}'
+        return super().cell(two)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_yolo_texts_fuzz_matches_cpython(oracle_backend, seed, monkeypatch):
+    g = YoloGen(3000 + seed)
+    r = random.Random(seed)
+    cells = [g.cell() for _ in range(400)] + [None, float("nan"), ""]
+    labels = [r.choice(["c1", "c1", "c1", "c2", "中文", "c1,c2", "undefined", ""]) for _ in cells]
+    cids = [r.randrange(0, 120) for _ in cells]
+    widths = [r.choice([1920, 640.0, 1, 1e-3, 0, 33, float("nan"), -100]) for _ in cells]
+    heights = [r.choice([1080, 480.5, 2, 0, 77, float("inf"), 1e-9]) for _ in cells]
+    # a coordinate CPython cannot do arithmetic on (a str, None) raises out of the reference's loop (:1046-1052 sit
+    # outside its try): such cells are dropped from the batch here, the raising itself is checked below
+    keep = []
+    for i, (c, lab, k, w, h) in enumerate(zip(cells, labels, cids, widths, heights)):
+        try:
+            osteps.yolo_row_text(c, lab, k, w, h)
+            keep.append(i)
+        except TypeError:
+            with pytest.raises(TypeError):
+                P.yolo_label_texts([c], [lab], [k], [w], [h], oracle_backend)
+    cells, labels, cids, widths, heights = ([v[i] for i in keep] for v in (cells, labels, cids, widths, heights))
+    stats = {}
+    native = P.yolo_label_texts(cells, labels, cids, widths, heights, oracle_backend, stats)
+    assert stats["python_cells"] < len(cells) * 3 // 4 and stats["device_rows"] > 5
+    want = [osteps.yolo_row_text(c, lab, k, w, h) for c, lab, k, w, h in zip(cells, labels, cids, widths, heights)]
+    assert native == ([t for t, _ in want], [why for _, why in want])
+    monkeypatch.setenv("DYD_NATIVE_JSON", "0")
+    plain = P.yolo_label_texts(cells, labels, cids, widths, heights, oracle_backend)
+    assert native == plain
+    assert any(t for t in plain[0]) and {"无匹配标签框", "缺少图像尺寸", "标注框无效"} <= set(plain[1])
+
+
+def test_yolo_texts_odd_sizes_take_the_python_path(oracle_backend):
+    cell = '{"objects": [{"name": "a", "polygon": {"ptList": [{"x": 1, "y": 2}, {"x": 3, "y": 4}]}}]}'
+    texts, reasons = P.yolo_label_texts([cell] * 4, ["a"] * 4, [1, 2, 3, 4], [10, None, "", True], [10, 10, 10, 10], oracle_backend)
+    assert texts[0] == "1 0.200000 0.300000 0.200000 0.200000" and texts[3] == "4 2.000000 0.300000 2.000000 0.200000"
+    assert reasons[1] == reasons[2] == "缺少图像尺寸"
