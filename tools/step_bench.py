@@ -132,6 +132,12 @@ def main():
                 s_m, n_m = clock(lambda: osteps.merge_folder(Q("parts"), Q("merged_cpu.csv")))
             out["cpu_port_merge"] = {"s": round(s_m, 3), "rows_per_s": round(n_m / s_m)}
             out["merge_output_byte_identical"] = open(Q("merged_prod.csv"), "rb").read() == open(Q("merged_cpu.csv"), "rb").read()
+            sub = kept.iloc[: max(1, len(kept) // 10)]                       # the port copies a Series per record: a tenth is enough
+            s_sp, osp = clock(lambda: osteps.split_frames(sub, lmap))
+            out["cpu_port_split_frames"] = {"s": round(s_sp, 3), "input_rows": len(sub), "input_rows_per_s": round(len(sub) / s_sp)}
+            psp = P.split_frames(sub, lmap)
+            out["split_frames_identical"] = all(a.equals(b) for c in osp["categories"] for a, b in zip(osp["categories"][c], psp["categories"][c])) \
+                and osp["unclassified"].equals(psp["unclassified"]) and osp["split_counts"].equals(psp["split_counts"])
             s_y, want = clock(lambda: [osteps.yolo_row_text(c, l, k, w, h)[0] for c, l, k, w, h in zip(ycells, ylabels, ycids, yw, yh)])
             out["cpu_port_yolo_label_texts"] = {"s": round(s_y, 3), "rows_per_s": round(len(sheet) / s_y)}
             out["yolo_texts_identical"] = want == ytexts
