@@ -92,48 +92,47 @@ def _merge_file_native(csv_file: Path, output_file: str, encoding: str, chunk_si
     idx = _fc.CsvIndex.open(np.frombuffer(raw, dtype=np.uint8)[bom:])
     if idx is None:
         return None
-    with idx:
-        names, n_rows = idx.names, idx.n_rows
-        if n_rows == 0 or "source_file" in names:
+    names, n_rows = idx.names, idx.n_rows
+    if n_rows == 0 or "source_file" in names:
+        return None
+    heavy = {}
+    for c, nm in enumerate(names):
+        if idx.col_bytes(c) >= _HEAVY_BYTES_PER_ROW * n_rows:
+            col = idx.extract(c)
+            if col is not None:
+                heavy[nm] = col
+    if not heavy:
+        return None                                  # nothing to gain: plain pandas
+    light_names = [nm for nm in names if nm not in heavy]
+    bounds = [(r0, min(r0 + chunk_size, n_rows)) for r0 in range(0, n_rows, chunk_size)]
+    if light_names:
+        text = idx.project([names.index(nm) for nm in light_names])
+        if text is None:
             return None
-        heavy = {}
-        for c, nm in enumerate(names):
-            if idx.col_bytes(c) >= _HEAVY_BYTES_PER_ROW * n_rows:
-                col = idx.extract(c)
-                if col is not None:
-                    heavy[nm] = col
-        if not heavy:
-            return None                                  # nothing to gain: plain pandas
-        light_names = [nm for nm in names if nm not in heavy]
-        bounds = [(r0, min(r0 + chunk_size, n_rows)) for r0 in range(0, n_rows, chunk_size)]
-        if light_names:
-            text = idx.project([names.index(nm) for nm in light_names])
-            if text is None:
-                return None
-            light_iter = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names, parse_dates=False,
-                                     chunksize=chunk_size)
-        else:
-            light_iter = (pd.DataFrame(index=pd.RangeIndex(r1 - r0)) for r0, r1 in bounds)
-        tell = _TellEmulator(raw, bom)
-        out_names = names + ["source_file"]
-        base = os.path.basename(csv_file)
-        written = 0
-        for chunk_idx, ((r0, r1), light) in enumerate(zip(bounds, light_iter), start=1):
-            if len(light) != r1 - r0:
-                raise RuntimeError("native CSV path: chunk sizes disagree")      # cannot happen for an indexed file
-            light = light.reset_index(drop=True)
-            part = {nm: _fc.Utf8Column(col.data, col.off[r0:r1 + 1], col.na[r0:r1]) for nm, col in heavy.items()}
-            columns = [part[nm] if nm in part else light[nm] for nm in names]
-            columns.append(pd.Series([base] * (r1 - r0), dtype=object))
-            first = not header_written and written == 0
-            if not _fc.write_table(output_file, out_names, columns, r1 - r0, encoding=encoding, append=not first, header=first):
-                frame = pd.DataFrame({nm: (part[nm].cells(range(r1 - r0)) if nm in part else light[nm]) for nm in names},
-                                     columns=names)
-                frame["source_file"] = base
-                frame.to_csv(output_file, index=False, encoding=encoding, mode="w" if first else "a", header=first)
-            written += r1 - r0
-            on_chunk(r1 - r0, chunk_idx, tell.after(bom + idx.row_end(r1 - 1)))
-        return written
+        light_iter = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names, parse_dates=False,
+                                 chunksize=chunk_size)
+    else:
+        light_iter = (pd.DataFrame(index=pd.RangeIndex(r1 - r0)) for r0, r1 in bounds)
+    tell = _TellEmulator(raw, bom)
+    out_names = names + ["source_file"]
+    base = os.path.basename(csv_file)
+    written = 0
+    for chunk_idx, ((r0, r1), light) in enumerate(zip(bounds, light_iter), start=1):
+        if len(light) != r1 - r0:
+            raise RuntimeError("native CSV path: chunk sizes disagree")      # cannot happen for an indexed file
+        light = light.reset_index(drop=True)
+        part = {nm: _fc.Utf8Column(col.data, col.off[r0:r1 + 1], col.na[r0:r1]) for nm, col in heavy.items()}
+        columns = [part[nm] if nm in part else light[nm] for nm in names]
+        columns.append(pd.Series([base] * (r1 - r0), dtype=object))
+        first = not header_written and written == 0
+        if not _fc.write_table(output_file, out_names, columns, r1 - r0, encoding=encoding, append=not first, header=first):
+            frame = pd.DataFrame({nm: (part[nm].cells(range(r1 - r0)) if nm in part else light[nm]) for nm in names},
+                                 columns=names)
+            frame["source_file"] = base
+            frame.to_csv(output_file, index=False, encoding=encoding, mode="w" if first else "a", header=first)
+        written += r1 - r0
+        on_chunk(r1 - r0, chunk_idx, tell.after(bom + idx.row_end(r1 - 1)))
+    return written
 
 
 def merge_all_csv_in_folder(

@@ -113,12 +113,8 @@ class CsvIndex:
             _native.load_library().dyd_csv_free(self._h)
             self._h = None
 
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
+    def __del__(self):
         self.close()
-        return False
 
     def col_bytes(self, c: int) -> int:
         return int(_native.load_library().dyd_csv_col_bytes(self._h, c))
@@ -133,15 +129,15 @@ class CsvIndex:
         pb, po, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
         if L.dyd_csv_extract(self._h, c, C.byref(pb), C.byref(po), C.byref(pn)) != 0:
             return None
-        off = _view(po.value, np.int64, self.n_rows + 1).copy()
-        data = _view(pb.value, np.uint8, int(off[-1]) + 1).copy()
-        na = _view(pn.value, np.uint8, self.n_rows).copy()
+        off = _view(po.value, np.int64, self.n_rows + 1)          # views into the handle: the column keeps it alive
+        data = _view(pb.value, np.uint8, int(off[-1]) + 1)
+        na = _view(pn.value, np.uint8, self.n_rows)
         # pandas infers dtypes per low-memory piece of the file, and a piece whose present cells all look
         # numeric / boolean becomes numbers ("1.50" -> 1.5).  The column is taken natively only when NO
         # present cell could be read as a number / boolean (na == 2): then every piece is object / str.
         if (na == 2).any() or (na != 0).all():
             return None
-        return Utf8Column(data, off, na)
+        return Utf8Column(data, off, na, keep=self)
 
     def project(self, keep: list):
         """CSV text of the file's width in which only the columns `keep` carry their cells (for pandas)"""
@@ -163,28 +159,29 @@ def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
     idx = CsvIndex.open(np.frombuffer(raw, dtype=np.uint8)[start:])
     if idx is None:
         return None
-    with idx:
-        names, n_rows = idx.names, idx.n_rows
-        heavy = {}
-        for nm in heavy_names:
-            if nm not in names:
-                continue
-            col = idx.extract(names.index(nm))
-            if col is None:
-                return None
-            heavy[nm] = col
-        light_idx = [i for i, nm in enumerate(names) if nm not in heavy]
-        if light_idx:
-            text = idx.project(light_idx)
-            if text is None:
-                return None
-            light_names = [names[i] for i in light_idx]
-            light = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names)[light_names]
-            if len(light) != n_rows or list(light.columns) != light_names:
-                return None
-        else:
-            light = pd.DataFrame(index=pd.RangeIndex(n_rows))
-        return SplitTable(names, n_rows, light, heavy)
+    names, n_rows = idx.names, idx.n_rows
+    heavy = {}
+    for nm in heavy_names:
+        if nm not in names:
+            continue
+        col = idx.extract(names.index(nm))
+        if col is None:
+            return None
+        heavy[nm] = col
+    light_idx = [i for i, nm in enumerate(names) if nm not in heavy]
+    if light_idx:
+        text = idx.project(light_idx)
+        if text is None:
+            return None
+        light_names = [names[i] for i in light_idx]
+        light = pd.read_csv(io.BytesIO(text), encoding="utf-8", usecols=light_names)[light_names]
+        if len(light) != n_rows or list(light.columns) != light_names:
+            return None
+    else:
+        light = pd.DataFrame(index=pd.RangeIndex(n_rows))
+    if not heavy:
+        idx.close()
+    return SplitTable(names, n_rows, light, heavy)
 
 
 def frame_from_split(table: "SplitTable", rows=None) -> pd.DataFrame:

@@ -190,3 +190,34 @@ def test_heavy_column_with_a_number_like_cell_is_left_to_pandas(tmp_path):
     with open(path, "w", encoding="utf-8-sig", newline="") as f:
         f.write(f"source,{ANN}\na,{{}}\nb,truely\nc,not json\nd,1 2 x\n")
     assert fastcsv.read_split(path, [ANN]) is not None
+
+
+@pytest.mark.parametrize("chunk", [64, 300, 5000])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_parallel_tokeniser_equals_the_serial_one(tmp_path, monkeypatch, seed, chunk):
+    """the buffer is cut every `chunk` bytes: cuts land inside quoted cells, between doubled quotes, on line ends"""
+    df = _messy_frame(200 + seed, n=300)
+    path = str(tmp_path / "t.csv")
+    df.to_csv(path, index=False, encoding="utf-8-sig")
+    want = pd.read_csv(path, encoding="utf-8-sig")
+    monkeypatch.setenv("DYD_CSV_CHUNK_BYTES", str(chunk))
+    t = fastcsv.read_split(path, [ANN, BBOX])
+    assert t is not None and t.n_rows == len(want)
+    pd.testing.assert_frame_equal(fastcsv.frame_from_split(t), want)
+
+
+def test_parallel_tokeniser_rejects_what_the_serial_one_rejects(tmp_path, monkeypatch):
+    good = "source,%s\n" % ANN + "".join('u%d,"{""k"": ""a,\nb""}"\n' % i for i in range(400))
+    cases = {"stray_quote": good.replace('u200,"', 'u2"00,"'), "ragged": good.replace("u300,", "u300,x,"),
+             "crlf": good.replace('u100,"{""k"": ""a,\nb""}"\n', 'u100,"{}"\r\n'), "unterminated": good[:-3]}
+    for chunk in ("1000000000", "128"):
+        monkeypatch.setenv("DYD_CSV_CHUNK_BYTES", chunk)
+        p = str(tmp_path / "ok.csv")
+        with open(p, "w", encoding="utf-8-sig", newline="") as f:
+            f.write(good)
+        assert fastcsv.read_split(p, [ANN]).n_rows == 400
+        for name, text in cases.items():
+            p = str(tmp_path / f"{name}.csv")
+            with open(p, "w", encoding="utf-8-sig", newline="") as f:
+                f.write(text)
+            assert fastcsv.read_split(p, [ANN]) is None, (name, chunk)
