@@ -252,22 +252,39 @@ int dyd_mt19937_permutation(uint32_t seed, int64_t n, int64_t *out) {
     }
     Mt g(seed);
     for (int64_t i = 0; i < n; ++i) out[i] = i;
-    for (int64_t i = n - 1; i >= 1; --i) {
-        uint64_t bound = (uint64_t)i, mask = bound;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
-        mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
-        uint64_t j;
-        if (bound <= 0xffffffffull) {
-            do { j = g.next() & mask; } while (j > bound);
-        } else {
-            do {
-                uint64_t hi = g.next(), lo = g.next();
-                j = ((hi << 32) | lo) & mask;
-            } while (j > bound);
+    // The draws do not depend on the array, only the swaps do: the partner indices of a block of steps are drawn
+    // first and their cache lines requested, then the swaps are applied in order.  On a table beyond the caches
+    // (165 M records = 1.3 GB) the swap partner is a DRAM miss every step; with the misses of a block in flight
+    // together the loop runs ~3x faster than one miss at a time.
+    constexpr int BLOCK = 64;
+    int64_t partner[BLOCK];
+    int64_t i = n - 1;
+    while (i >= 1) {
+        const int m = (int)((i < BLOCK) ? i : BLOCK);           // steps i, i-1, ..., i-m+1
+        for (int k = 0; k < m; ++k) {
+            const uint64_t bound = (uint64_t)(i - k);
+            uint64_t mask = bound;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
+            mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+            uint64_t j;
+            if (bound <= 0xffffffffull) {
+                do { j = g.next() & mask; } while (j > bound);
+            } else {
+                do {
+                    uint64_t hi = g.next(), lo = g.next();
+                    j = ((hi << 32) | lo) & mask;
+                } while (j > bound);
+            }
+            partner[k] = (int64_t)j;
+            __builtin_prefetch(out + j, 1, 0);
         }
-        int64_t t = out[i];
-        out[i] = out[j];
-        out[j] = t;
+        for (int k = 0; k < m; ++k) {
+            const int64_t a = i - k, j = partner[k];
+            const int64_t t = out[a];
+            out[a] = out[j];
+            out[j] = t;
+        }
+        i -= m;
     }
     return DYD_OK;
 }
