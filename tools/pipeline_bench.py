@@ -94,10 +94,10 @@ def main():
 
     stages = []
 
-    def stage(name, nbytes, fn, **kw):
+    def stage(name, nbytes, fn, post=None, **kw):
         ms = timeit(fn)
         rec = {"stage": name, "ms": round(ms, 3), "alg_GB": round(nbytes / 1e9, 3), "GBs": round(nbytes / ms / 1e6, 1),
-               "rows_per_s": round(N / ms * 1e3), **kw}
+               "rows_per_s": round(N / ms * 1e3), **kw, **(post() if post else {})}
         stages.append(rec)
         print(json.dumps(rec), flush=True)
 
@@ -105,16 +105,16 @@ def main():
           lambda: ck(L.dyd_hash128_dev(data.data_ptr(), off.data_ptr(), N, h.data_ptr(), sp), "k3"))
     U = int(len(np.unique(url_id)))
     stage("K4 dedup keep=first", 16 * N + N + 48 * U,
-          lambda: ck(L.dyd_dedup_dev(h.data_ptr(), N, 0, keep.data_ptr(), sp), "k4"), kept=None)
-    stages[-1]["kept"] = int(keep.sum().item())
+          lambda: ck(L.dyd_dedup_dev(h.data_ptr(), N, 0, keep.data_ptr(), sp), "k4"),
+          post=lambda: {"kept": int(keep.sum().item())})
     stage("K3 hash128(ref) + K5 isin", int(roff_np[-1]) + 8 * (R + 1) + 16 * R + 16 * N + N + 16 * R,
           lambda: (ck(L.dyd_hash128_dev(rdata.data_ptr(), roff.data_ptr(), R, hr.data_ptr(), sp), "k3r"),
-                   ck(L.dyd_isin_dev(h.data_ptr(), N, hr.data_ptr(), R, hit.data_ptr(), sp), "k5")))
-    stages[-1]["hits"] = int(hit.sum().item())
+                   ck(L.dyd_isin_dev(h.data_ptr(), N, hr.data_ptr(), R, hit.data_ptr(), sp), "k5")),
+          post=lambda: {"hits": int(hit.sum().item())})
     stage("K1+K2 fused (poly->bbox + IoU flag)", 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N,
           lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98,
-                                              out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"))
-    stages[-1]["high"] = int(out_high.sum().item())
+                                              out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"),
+          post=lambda: {"high": int(out_high.sum().item())})
 
     # K6: one expanded row per box; catA = c0..c9, catB = c10..c17, c18/c19 unclassified (SURVEY §8d rules)
     cat = torch.where(labels < 10, 0, torch.where(labels < 18, 1, -1)).to(torch.int32).contiguous()
