@@ -779,23 +779,26 @@ def _expand_rows(cells, label_to_category: dict) -> dict:
     all_kind = np.concatenate([e_kind, np.zeros(len(err_rows), np.uint8)])
     all_label = np.concatenate([e_label, np.full(len(err_rows), "", object)])
     eorder = np.argsort(all_src, kind="stable")
-    unclassified = []
-    for ri, kind, label in zip(all_src[eorder].tolist(), all_kind[eorder].tolist(), all_label[eorder].tolist()):
-        if kind == 0:
-            unclassified.append((ri, error[ri], None))
-        elif kind == _nj.EV_NO_NAME:
-            unclassified.append((ri, "标注框缺少name字段", None))
-        elif kind == _nj.EV_UNDEFINED:
-            unclassified.append((ri, f"标签{label}未在规则中定义", label))
-        else:
-            unclassified.append((ri, reasons[ri] if reasons[ri] else "标签无法匹配规则", None))
+    unc_row, unc_kind, unc_label = all_src[eorder], all_kind[eorder], all_label[eorder]
+    # reason text per entry, built per distinct value rather than per entry
+    unc_reason = np.full(len(unc_row), "标注框缺少name字段", object)                      # EV_NO_NAME (:747)
+    is_err, is_undef, is_none = unc_kind == 0, unc_kind == _nj.EV_UNDEFINED, unc_kind == _nj.EV_NOTHING_CLASSIFIED
+    if is_err.any():
+        unc_reason[is_err] = error[unc_row[is_err]]
+    if is_undef.any():
+        uniq, inverse = np.unique(unc_label[is_undef].astype(str), return_inverse=True)
+        unc_reason[is_undef] = np.asarray([f"标签{lab}未在规则中定义" for lab in uniq], object)[inverse]   # :755
+    if is_none.any():
+        why = reasons[unc_row[is_none]]
+        unc_reason[is_none] = np.where(why == "", "标签无法匹配规则", why)                  # :779
+    unc_label = np.where(is_undef, unc_label, None)
     failed = np.asarray([e is not None for e in error], bool) if n else np.zeros(0, bool)
     verdict = np.where(failed | (n_out == 0), "否", np.where(reasons != "", "部分可分类", "是")).astype(object)
     reasons_of_row = reasons.copy()
     for ri in np.flatnonzero(failed).tolist():
         reasons_of_row[ri] = error[ri]                         # split_counts carries the error text there (:726)
     return {"src_row": src, "label": lab, "json": txt, "combo_of_row": combo, "n_out": n_out, "verdict": verdict,
-            "reasons_of_row": reasons_of_row, "unclassified": unclassified}
+            "reasons_of_row": reasons_of_row, "unc_row": unc_row, "unc_reason": unc_reason, "unc_label": unc_label}
 
 
 def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Optional[list] = None,
@@ -833,10 +836,9 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
     names_in_order = list(pd.unique(cat_names)) if len(cat_names) else []          # first-appearance order (:773 dict order)
     categories = {name: i for i, name in enumerate(names_in_order)}
     cat_id = np.asarray([categories[c] for c in cat_names], np.int32) if len(cat_names) else np.zeros(0, np.int32)
-    unclassified = ex["unclassified"]     # (row position, reason, label-or-None) in the reference's append order
     sources = values[:, source_pos] if source_pos is not None else np.full(n, None, object)
-    counts = [{"source": sources[ri], "原始标签组合": ex["combo_of_row"][ri], "拆分条数": int(ex["n_out"][ri]),
-               "是否可分类": ex["verdict"][ri], "无法分类原因": ex["reasons_of_row"][ri]} for ri in range(n)]
+    counts = pd.DataFrame({"source": sources, "原始标签组合": ex["combo_of_row"], "拆分条数": ex["n_out"],
+                           "是否可分类": ex["verdict"], "无法分类原因": ex["reasons_of_row"]}) if n else pd.DataFrame()
 
     # ---- device stage: rank in category -> shuffled position -> split id --------------------
     cat_arr = cat_id
@@ -872,15 +874,15 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
         out_cats[category] = (frame[sp == 0], frame[sp == 1], frame[sp == 2])
         cat_counts[category] = int(len(members))
 
-    if unclassified:
-        rows = np.asarray([u[0] for u in unclassified], np.int64)
-        unc = df.iloc[rows].copy()
-        unc["无法分类原因"] = [u[1] for u in unclassified]
-        if any(u[2] is not None for u in unclassified):
-            unc["无法分类标签"] = [u[2] if u[2] is not None else np.nan for u in unclassified]
+    if len(ex["unc_row"]):                # rows in the reference's append order (:724, :748, :756, :780)
+        unc = df.iloc[ex["unc_row"]].copy()
+        unc["无法分类原因"] = ex["unc_reason"]
+        has_label = np.asarray([v is not None for v in ex["unc_label"]], bool)
+        if has_label.any():
+            unc["无法分类标签"] = np.where(has_label, ex["unc_label"], np.nan)
     else:
         unc = pd.DataFrame()
-    return {"categories": out_cats, "unclassified": unc, "split_counts": pd.DataFrame(counts),
+    return {"categories": out_cats, "unclassified": unc, "split_counts": counts,
             "category_counts": cat_counts,
             "expanded": {"src_row": src_arr, "category_id": cat_arr, "position": pos, "split": split,
                          "category_names": list(categories)}}

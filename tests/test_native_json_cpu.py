@@ -303,7 +303,7 @@ def test_split_expansion_fuzz_matches_cpython(seed, monkeypatch):
     a, b = _norm(native), _norm(plain)
     for key in b:
         assert a[key] == b[key], key
-    assert len(b["json"]) > 100 and len(b["unclassified"]) > 100
+    assert len(b["json"]) > 100 and len(b["unc_row"]) > 100
 
 
 def test_split_expansion_label_rules():
@@ -314,7 +314,8 @@ def test_split_expansion_label_rules():
     assert ex["json"][0] == '{"a": 1, "b": [1.0, "x"], "objects": [{"name": "c1", "id": 1}]}'
     assert ex["json"][3] == '{"a": 1, "b": [1.0, "x"], "objects": [{"name": "c3"}]}'
     assert ex["combo_of_row"].tolist() == ["c1，c2，c3，zz"]
-    assert ex["unclassified"] == [(0, "标签zz未在规则中定义", "zz"), (0, "标注框缺少name字段", None)]
+    assert list(zip(ex["unc_row"].tolist(), ex["unc_reason"].tolist(), ex["unc_label"].tolist())) == \
+        [(0, "标签zz未在规则中定义", "zz"), (0, "标注框缺少name字段", None)]
     assert ex["verdict"].tolist() == ["部分可分类"] and ex["reasons_of_row"].tolist() == ["标签zz未在规则中定义"]
 
 
