@@ -22,7 +22,6 @@ mandatory: without libdyd_gfx950.so and a gfx950 GPU the steps raise (``_native`
 """
 from __future__ import annotations
 
-import copy
 import io
 import json
 import os

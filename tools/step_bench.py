@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
     import pandas as pd
     from deal_yolo_daya_amd import _native, synth
     from deal_yolo_daya_amd.core import processor as P
