@@ -560,31 +560,298 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_kernel(const double *__restr
     }
 }
 
-static int g_k7_rpt = 2;
-static unsigned long long *g_k7_trace = nullptr;   // tuning hook: 8 timestamps per tile
-void set_k7_trace(void *p) { g_k7_trace = static_cast<unsigned long long *>(p); }   // rows per lane (dyd_set_option "k7_variant": 1, 2 or 4)
-void set_k7_variant(int v) { g_k7_rpt = (v == 1 || v == 4) ? v : 2; }
+// ---- two tiles per ticket, software-pipelined -----------------------------------------------------------------
+// The single-tile kernel above idles ~6 us per tile in its look-back: a byte count published by another XCD becomes
+// visible two memory round trips later, and a tile has only its own printing (1.4 us) to do meanwhile.  Here a
+// workgroup takes tiles 2T and 2T+1: it measures A, publishes A's count, prints A into LDS, then measures B and
+// publishes B's count, and only then looks back for A — a whole tile's measuring later, when the counts of the
+// tiles before A have long arrived.  B needs no look-back: its base is A's base plus A's bytes.  A's per-row
+// offsets wait in LDS (the registers are B's by then).  Deadlock-free for the same reason as above: both counts of a
+// ticket are published without waiting for anything.
+template <int RPT>
+__global__ __launch_bounds__(K7_BLOCK) void k7_yolo_pair_kernel(const double *__restrict__ box4,
+                                                                const int32_t *__restrict__ row_off,
+                                                                const uint8_t *__restrict__ sel,
+                                                                const double *__restrict__ width,
+                                                                const double *__restrict__ height,
+                                                                const int32_t *__restrict__ class_id, int64_t n_rows,
+                                                                int64_t *__restrict__ text_off,
+                                                                uint8_t *__restrict__ flag_out, uint8_t *text,
+                                                                int64_t text_cap, unsigned long long *state) {
+    constexpr int TILE = K7_BLOCK * RPT;
+    constexpr int LDS_TEXT = K7_LDS_TEXT * RPT / 2;   // 48 bytes of staging per row
+    __shared__ __attribute__((aligned(16))) unsigned char s_text[LDS_TEXT + 32];
+    __shared__ uint32_t s_wave[RPT][K7_WAVES];
+    __shared__ uint32_t s_park_off[RPT][K7_BLOCK], s_park_meta[RPT][K7_BLOCK];   // tile A: offset, len << 2 | flag
+    __shared__ unsigned long long s_bcast[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_bcast[0] = atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const int64_t ticket = (int64_t)s_bcast[0];
+    unsigned long long *words = state + 2;
+    const int64_t n_tiles = (n_rows + TILE - 1) / TILE;
+    const int64_t tile_a = 2 * ticket, tile_b = tile_a + 1;
+    if (tile_a >= n_tiles) return;
+    const bool have_b = tile_b < n_tiles;
+
+    RowIn r[RPT];
+    RowState st[RPT];
+    bool plain[RPT];
+    uint32_t toff[RPT];
+
+    // loads + lengths + workgroup scan of one tile; leaves the tile's state in r / st / plain / toff
+    auto measure = [&](int64_t tile) -> uint32_t {
+        const int64_t row0 = tile * TILE + tid;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = row0 + (int64_t)k * K7_BLOCK;
+            r[k].b0 = r[k].b1 = 0;
+            r[k].w = r[k].h = 1.0;
+            r[k].cid = 0;
+            if (row < n_rows) {
+                r[k].b0 = row_off[row];
+                r[k].b1 = row_off[row + 1];
+                r[k].w = width[row];
+                r[k].h = height[row];
+                r[k].cid = class_id[row];
+            }
+            r[k].host = (r[k].w == 0.0) || (r[k].h == 0.0) || (r[k].cid < 0);
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const bool live = row0 + (int64_t)k * K7_BLOCK < n_rows;
+            plain[k] = live && plain_row(r[k], box4, sel, st[k].q);
+            if (plain[k]) {
+                st[k].len = plain_len(r[k], st[k].q);
+                st[k].flag = 0;
+            } else {
+                row_measure(r[k], box4, sel, st[k]);
+                if (!live) st[k].len = 0;
+            }
+        }
+        uint32_t incl[RPT];
+        __syncthreads();   // s_wave of the previous tile has been read by everyone
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            incl[k] = st[k].len;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const uint32_t up = __shfl_up(incl[k], d);
+                if (lane >= d) incl[k] += up;
+            }
+            if (lane == kWave - 1) s_wave[k][wave] = incl[k];
+        }
+        __syncthreads();
+        uint32_t bytes = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            uint32_t before = bytes;
+#pragma unroll
+            for (int w = 0; w < K7_WAVES; ++w) {
+                if (w < wave) before += s_wave[k][w];
+                bytes += s_wave[k][w];
+            }
+            toff[k] = before + incl[k] - st[k].len;
+        }
+        return bytes;
+    };
+    auto print_rows = [&](unsigned char *where) {   // the current tile's rows at where + toff (LDS or memory)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            unsigned char *mine = where + toff[k];
+            if (plain[k])
+                plain_print(r[k], st[k], [&](int p, char c) { mine[p] = (unsigned char)c; });
+            else if (st[k].len)
+                row_print(r[k], box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
+        }
+    };
+    auto flush = [&](unsigned char *dst, uint32_t bytes) {   // dst[i] = s_text[i], 16-byte stores, see k7_yolo_kernel
+        const uint32_t phase = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+        const uint32_t end = phase + bytes;
+        const uint32_t n_chunks = (end + 15u) >> 4;
+        unsigned char *aligned = dst - phase;
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s_text);
+        const uint32_t sh = (0u - phase) & 3u;
+        for (uint32_t c = tid; c < n_chunks; c += K7_BLOCK) {
+            const uint32_t lo = c << 4, hi = lo + 16u;
+            if (lo >= phase && hi <= end) {
+                const uint32_t m = (lo - phase) >> 2;
+                const uint32_t d0 = s32[m], d1 = s32[m + 1], d2 = s32[m + 2], d3 = s32[m + 3], d4 = s32[m + 4];
+                uint4 v;
+                v.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                v.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                v.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                v.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                *reinterpret_cast<uint4 *>(aligned + lo) = v;
+            } else {
+                const uint32_t a = lo < phase ? phase : lo, b = hi > end ? end : hi;
+                for (uint32_t i = a; i < b; ++i) aligned[i] = s_text[i - phase];
+            }
+        }
+    };
+    auto offsets_from_regs = [&](int64_t tile, int64_t base) {
+        const int64_t row0 = tile * TILE + tid;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = row0 + (int64_t)k * K7_BLOCK;
+            if (row < n_rows) {
+                text_off[row] = base + toff[k];
+                flag_out[row] = (uint8_t)st[k].flag;
+                if (row == n_rows - 1) text_off[n_rows] = base + toff[k] + st[k].len;
+            }
+        }
+    };
+
+    // ---- tile A: measure, publish, print, park ---------------------------------------------------------------------
+    const uint32_t bytes_a = measure(tile_a);
+    if (tid == 0)
+        __hip_atomic_store(&words[tile_a], (tile_a == 0 ? K7_FLAG_PFX : K7_FLAG_AGG) | (unsigned long long)bytes_a, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    const bool staged_a = text && bytes_a && bytes_a <= (uint32_t)LDS_TEXT;
+    const bool pipelined = have_b && (staged_a || !text || bytes_a == 0);   // a tile too long for LDS is finished first
+    if (staged_a) print_rows(s_text);
+    if (pipelined) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            s_park_off[k][tid] = toff[k];
+            s_park_meta[k][tid] = (st[k].len << 2) | st[k].flag;
+        }
+    }
+    // ---- tile B measured before A is looked back for ------------------------------------------------------------
+    uint32_t bytes_b = 0;
+    if (pipelined) {
+        bytes_b = measure(tile_b);   // (its barriers also order A's printing before A's flush)
+        if (tid == 0)
+            __hip_atomic_store(&words[tile_b], K7_FLAG_AGG | (unsigned long long)bytes_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- look-back for A (wave 0) -----------------------------------------------------------------------------------
+    if (wave == 0) {
+        unsigned long long base = 0;
+        int64_t look = tile_a - 1;
+        bool failed = false;
+        while (look >= 0) {
+            const int64_t t = look - lane;
+            unsigned long long wv = K7_FLAG_PFX;
+            if (t >= 0) {
+                int spins = 0;
+                do {
+                    wv = __hip_atomic_load(&words[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((wv >> 62) == 0 && ++spins > K7_SPIN_LIMIT) {
+                        failed = true;
+                        break;
+                    }
+                    if ((wv >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+                } while ((wv >> 62) == 0);
+            }
+            if (__any(failed)) {
+                failed = true;
+                break;
+            }
+            const unsigned long long has_pfx = __ballot((wv >> 62) == 2);
+            const int first = has_pfx ? __ffsll((long long)has_pfx) - 1 : kWave;
+            unsigned long long part = (lane <= first) ? (wv & K7_VALUE) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            base += part;
+            if (has_pfx) break;
+            look -= kWave;
+        }
+        if (lane == 0) {
+            if (failed) {
+                atomicExch(&state[1], 1ull);
+                base = 0;
+            }
+            if (tile_a != 0)
+                __hip_atomic_store(&words[tile_a], K7_FLAG_PFX | ((base + bytes_a) & K7_VALUE), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (pipelined)   // B's prefix is known without a look-back of its own
+                __hip_atomic_store(&words[tile_b], K7_FLAG_PFX | ((base + bytes_a + bytes_b) & K7_VALUE), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_bcast[1] = base;
+        }
+    }
+    __syncthreads();
+    const int64_t base_a = (int64_t)s_bcast[1];
+    const bool fits_a = base_a + (int64_t)bytes_a <= text_cap;
+    if (text && bytes_a && !fits_a && tid == 0) atomicExch(&state[1], 2ull);
+
+    if (pipelined) {
+        // ---- finish A from the parked offsets -----------------------------------------------------------------------
+        const int64_t row0 = tile_a * TILE + tid;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = row0 + (int64_t)k * K7_BLOCK;   // (tile A is never the last tile here)
+            if (row < n_rows) {
+                text_off[row] = base_a + s_park_off[k][tid];
+                flag_out[row] = (uint8_t)(s_park_meta[k][tid] & 3u);
+            }
+        }
+        if (staged_a && fits_a) flush(text + base_a, bytes_a);
+        // ---- finish B: its state is still in registers --------------------------------------------------------------
+        const int64_t base_b = base_a + (int64_t)bytes_a;
+        offsets_from_regs(tile_b, base_b);
+        if (!text || bytes_b == 0) return;
+        if (base_b + (int64_t)bytes_b > text_cap) {
+            if (tid == 0) atomicExch(&state[1], 2ull);
+            return;
+        }
+        if (bytes_b <= (uint32_t)LDS_TEXT) {
+            __syncthreads();                 // A has left LDS
+            print_rows(s_text);
+            __syncthreads();
+            flush(text + base_b, bytes_b);
+        } else {
+            print_rows(text + base_b);
+        }
+        return;
+    }
+    // ---- not pipelined: A alone (last tile of the grid, or a tile too long for LDS), then B the same way -----------
+    offsets_from_regs(tile_a, base_a);
+    if (text && bytes_a && fits_a) {
+        if (staged_a) flush(text + base_a, bytes_a);
+        else print_rows(text + base_a);
+    }
+    if (!have_b) return;
+    const uint32_t bytes_b2 = measure(tile_b);
+    const int64_t base_b = base_a + (int64_t)bytes_a;
+    if (tid == 0)
+        __hip_atomic_store(&words[tile_b], K7_FLAG_PFX | ((unsigned long long)(base_b + bytes_b2) & K7_VALUE), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    offsets_from_regs(tile_b, base_b);
+    if (!text || bytes_b2 == 0) return;
+    if (base_b + (int64_t)bytes_b2 > text_cap) {
+        if (tid == 0) atomicExch(&state[1], 2ull);
+        return;
+    }
+    if (bytes_b2 <= (uint32_t)LDS_TEXT) {
+        print_rows(s_text);
+        __syncthreads();
+        flush(text + base_b, bytes_b2);
+    } else {
+        print_rows(text + base_b);
+    }
+}
+
+static int g_k7_variant = 22;   // dyd_set_option("k7_variant"): 2 = one 512-row tile per ticket, 22 = two, pipelined (default)
+static unsigned long long *g_k7_trace = nullptr;   // tuning hook (single-tile kernel): 8 timestamps per tile
+void set_k7_trace(void *p) { g_k7_trace = static_cast<unsigned long long *>(p); }
+void set_k7_variant(int v) { g_k7_variant = (v == 2) ? 2 : 22; }
 
 static int yolo_launch(const double *box4, const int32_t *row_off, const uint8_t *sel, const double *width,
                        const double *height, const int32_t *class_id, int64_t n_rows, int64_t *text_off,
                        uint8_t *flag, uint8_t *text, int64_t text_cap, int64_t *total_out, hipStream_t st) {
-    const int rpt = g_k7_rpt;
-    const int64_t n_tiles = ceil_div(n_rows, (int64_t)K7_BLOCK * rpt);
+    const int64_t n_tiles = ceil_div(n_rows, (int64_t)K7_BLOCK * 2);
     void *scr = nullptr;
     const size_t state_bytes = (size_t)(n_tiles + 2) * 8;
     int rc = get_scratch(state_bytes, &scr, st);
     if (rc) return rc;
     DYD_HIP(hipMemsetAsync(scr, 0, state_bytes, st));
     unsigned long long *state = static_cast<unsigned long long *>(scr);
-    const unsigned blocks = (unsigned)n_tiles;
-    if (rpt == 1)
-        hipLaunchKernelGGL((k7_yolo_kernel<1>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
-                           class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
-    else if (rpt == 4)
-        hipLaunchKernelGGL((k7_yolo_kernel<4>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
-                           class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
+    if (g_k7_variant == 22)
+        hipLaunchKernelGGL((k7_yolo_pair_kernel<2>), dim3((unsigned)ceil_div(n_tiles, 2)), dim3(K7_BLOCK), 0, st, box4, row_off, sel,
+                           width, height, class_id, n_rows, text_off, flag, text, text_cap, state);
     else
-        hipLaunchKernelGGL((k7_yolo_kernel<2>), dim3(blocks), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+        hipLaunchKernelGGL((k7_yolo_kernel<2>), dim3((unsigned)n_tiles), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
                            class_id, n_rows, text_off, flag, text, text_cap, state, g_k7_trace);
     DYD_HIP(hipGetLastError());
     unsigned long long err = 0;

@@ -65,9 +65,18 @@ def _random_case(rng, n_rows, max_boxes, with_sel, special=True):
     return box, row_off, sel, w, h, cid
 
 
-@pytest.mark.parametrize("n_rows,max_boxes,with_sel", [(1, 1, False), (255, 3, True), (256, 1, False), (257, 2, True), (5000, 4, True),
+@pytest.fixture(params=[22, 2], ids=["paired", "single"])
+def k7_variant(request, native):
+    """22 = two tiles per ticket, software-pipelined (default); 2 = one tile per ticket"""
+    native.check(native.lib().dyd_set_option(b"k7_variant", request.param), "opt")
+    yield request.param
+    native.check(native.lib().dyd_set_option(b"k7_variant", 22), "opt")
+
+
+@pytest.mark.parametrize("n_rows,max_boxes,with_sel", [(1, 1, False), (255, 3, True), (256, 1, False), (257, 2, True), (512, 1, False),
+                                                       (513, 2, True), (1024, 1, False), (1025, 1, True), (5000, 4, True),
                                                        (70001, 1, False), (3000, 40, True)])
-def test_k7_random_matches_oracle(native, n_rows, max_boxes, with_sel):
+def test_k7_random_matches_oracle(native, k7_variant, n_rows, max_boxes, with_sel):
     rng = np.random.default_rng(n_rows * 7 + max_boxes)
     flag = _check_against_oracle(native, *_random_case(rng, n_rows, max_boxes, with_sel))
     if n_rows >= 255:
@@ -113,7 +122,7 @@ def _format_cases(native, xs):
     return flag
 
 
-def test_k7_exact_rounding_ties_and_carries(native):
+def test_k7_exact_rounding_ties_and_carries(native, k7_variant):
     xs = []
     for j in range(1, 40):                              # k / 2^j: every exactly representable tie at 6 decimals
         for k in (1, 3, 5, 7, 15625, 15627, 46875, 78125, 999999, 1000001):
@@ -150,7 +159,7 @@ def test_k7_signs_nan_inf(native):
     assert _rows(off, text, 6)[5] == b"5 -0.000000 0.000000 -0.000000 0.000000"
 
 
-def test_k7_long_rows_bypass_lds(native):
+def test_k7_long_rows_bypass_lds(native, k7_variant):
     """tiles whose text exceeds the LDS staging buffer are printed straight to memory"""
     rng = np.random.default_rng(5)
     n_rows = 600
@@ -175,7 +184,7 @@ def test_k7_golden_cases_through_the_step(native):
     assert stats["device_rows"] > 20
 
 
-def test_k7_dev_capacity_and_measure_mode(native):
+def test_k7_dev_capacity_and_measure_mode(native, k7_variant):
     import torch
     L = native.lib()
     n = 5000
@@ -206,7 +215,7 @@ def test_k7_dev_capacity_and_measure_mode(native):
     assert np.array_equal(d_flag.cpu().numpy(), want_flag)
 
 
-def test_k7_full_size_properties(native):
+def test_k7_full_size_properties(native, k7_variant):
     """20 M single-box rows (the shape of a split sheet): offsets are the running sum of the line lengths,
     the text is lines of five tokens, and sampled rows equal Python's own formatting."""
     import torch

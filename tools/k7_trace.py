@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=16_000_000)
-    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=2, help="the phase stamps exist in the single-tile kernel (variant 2) only")
     ap.add_argument("--measure", action="store_true")
     a = ap.parse_args()
     import torch

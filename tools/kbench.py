@@ -180,7 +180,7 @@ def main():
         text = torch.empty(T, dtype=torch.uint8, device=dev)
         import os
         modes = os.environ.get("K7MODE", "full,measure").split(",")
-        for variant in [int(v) for v in os.environ.get("K7V", "2,4").split(",")]:
+        for variant in [int(v) for v in os.environ.get("K7V", "2,22").split(",")]:
             ck(L.dyd_set_option(b"k7_variant", variant), "opt")
             if "full" in modes:
               med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
@@ -194,7 +194,7 @@ def main():
                                                               cid.data_ptr(), E, toff.data_ptr(), flag.data_ptr(), None, 0,
                                                               C.byref(total), sp), "k7"))
             report(f"k7_measure_only_rpt{variant}", 32 * E + 4 * (E + 1) + 20 * E + 8 * (E + 1) + E, med, mn, rows=E)
-        ck(L.dyd_set_option(b"k7_variant", 2), "opt")
+        ck(L.dyd_set_option(b"k7_variant", 22), "opt")
 
 
 if __name__ == "__main__":
