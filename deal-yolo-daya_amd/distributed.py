@@ -13,6 +13,9 @@ need no communication.  The two set-valued stages exchange hashes exactly once:
                 (dyd_split_ids_sharded_dev); the MT19937 permutation of each GLOBAL category size
                 is computed on every host identically.
 
+    label lines rows are independent (K7 per shard); ONE all-gather of the shards' text sizes (8 B each) turns the
+                local byte offsets into offsets inside the concatenated text of all ranks
+
 ``torch.distributed`` is the plumbing (backend "nccl" is RCCL on ROCm; tests use "gloo" on CPU).
 The device work goes through an ``ops`` object: ``HipOps`` (below) drives the ``_dev`` entry
 points of libdyd_gfx950.so on tensors resident in HBM; the CPU test-suite injects its own.
@@ -98,6 +101,22 @@ class HipOps:
     def permutation(self, seed: int, n: int) -> np.ndarray:
         return self.native.mt19937_permutation(seed, n)
 
+    def yolo_lines(self, box4, row_off, sel, width, height, class_id):
+        """K7 on tensors in HBM -> (text_off int64 [n+1], flag u8 [n], text u8 [total]) on the device"""
+        import ctypes as C
+        n = row_off.numel() - 1
+        toff = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        flag = torch.zeros(max(n, 1), dtype=torch.uint8, device=self.device)[:n]
+        total = C.c_int64()
+        args = (box4.data_ptr(), row_off.data_ptr(), sel.data_ptr() if sel is not None else None, width.data_ptr(),
+                height.data_ptr(), class_id.data_ptr(), n, toff.data_ptr(), flag.data_ptr())
+        self.native.check(self.L.dyd_yolo_lines_dev(*args, None, 0, C.byref(total), self._stream()), "dyd_yolo_lines_dev")
+        text = torch.empty(max(total.value, 1), dtype=torch.uint8, device=self.device)
+        if total.value:
+            self.native.check(self.L.dyd_yolo_lines_dev(*args, text.data_ptr(), total.value, C.byref(total), self._stream()),
+                              "dyd_yolo_lines_dev")
+        return toff, flag, text[:total.value]
+
 
 def all_gather_rows(t: torch.Tensor, group=None) -> tuple:
     """Concatenate every rank's [n_r, ...] tensor in rank order with ONE data collective
@@ -180,3 +199,20 @@ def split_ids_sharded(local_cat: np.ndarray, n_cat: int, train_ratio=0.8, val_ra
     split, pos = ops.split_ids_sharded(ops.tensor(local_cat), ops.tensor(perm), ops.tensor(cat_off),
                                        ops.tensor(n_train), ops.tensor(n_val), ops.tensor(rank_base))
     return split.cpu().numpy(), pos.cpu().numpy()
+
+
+def yolo_lines_sharded(box4, row_off, sel, width, height, class_id, ops=None, group=None) -> tuple:
+    """Label lines (reference core/processor.py:1046-1054) of this rank's shard of the rows.
+    -> (global byte offset of every local row [n+1], flag [n], local text, total bytes of all ranks): the rows'
+    texts of all ranks, concatenated in rank order, are what one process would have produced."""
+    ops = ops or HipOps()
+    rank = dist.get_rank(group)
+    toff, flag, text = ops.yolo_lines(ops.tensor(np.ascontiguousarray(box4, np.float64).reshape(-1)),
+                                      ops.tensor(np.ascontiguousarray(row_off, np.int32)),
+                                      None if sel is None else ops.tensor(np.ascontiguousarray(sel, np.uint8)),
+                                      ops.tensor(np.ascontiguousarray(width, np.float64)),
+                                      ops.tensor(np.ascontiguousarray(height, np.float64)),
+                                      ops.tensor(np.ascontiguousarray(class_id, np.int32)))
+    sizes, _ = all_gather_rows(ops.tensor(np.asarray([[int(text.numel())]], np.int64)), group)
+    sizes = sizes.cpu().numpy().reshape(-1)
+    return toff.cpu().numpy() + int(sizes[:rank].sum()), flag.cpu().numpy(), text.cpu().numpy().tobytes(), int(sizes.sum())

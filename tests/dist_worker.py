@@ -45,6 +45,11 @@ class OracleOps:
     def permutation(self, seed, n):
         return olib.mt19937_permutation(seed, n)
 
+    def yolo_lines(self, box4, row_off, sel, width, height, class_id):
+        off, flag, text = olib.yolo_lines(box4.numpy(), row_off.numpy(), None if sel is None else sel.numpy(), width.numpy(),
+                                          height.numpy(), class_id.numpy())
+        return torch.from_numpy(off), torch.from_numpy(flag), torch.from_numpy(np.frombuffer(text, np.uint8).copy())
+
 
 def main():
     rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
@@ -70,6 +75,13 @@ def main():
     res["ref_hit"] = D.ref_hit_mask_sharded(src.iloc[lo:hi], ref.iloc[rlo:rhi], ops).astype(int).tolist()
     split, pos = D.split_ids_sharded(cat[lo:hi], 3, 0.8, 0.1, 0.1, 42, ops)
     res["split"], res["pos"] = split.tolist(), pos.tolist()
+    boxes = np.round(rng.random((n, 4)) * 500, 1)
+    boxes[:, 2:] += boxes[:, :2] + 1
+    boxes[::50, 2] = boxes[::50, 0]                            # zero-width boxes: no line
+    goff, gflag, gtext, gtotal = D.yolo_lines_sharded(boxes[lo:hi], np.arange(hi - lo + 1, dtype=np.int32), None,
+                                                      np.full(hi - lo, 640.0), np.full(hi - lo, 480.0),
+                                                      (np.arange(lo, hi) % 13).astype(np.int32), ops)
+    res["yolo_off"], res["yolo_flag"], res["yolo_text"], res["yolo_total"] = goff.tolist(), gflag.tolist(), gtext.decode(), gtotal
     g, counts = D.all_gather_rows(torch.arange(lo, hi).reshape(-1, 1))
     res["gathered_ok"] = bool(torch.equal(g.flatten(), torch.arange(n))) and counts == [
         D.shard_bounds(n, world, r)[1] - D.shard_bounds(n, world, r)[0] for r in range(world)]

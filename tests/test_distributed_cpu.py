@@ -61,6 +61,16 @@ def test_sharded_steps_match_single_process(world, tmp_path):
     assert np.array_equal(np.concatenate([r["split"] for r in res]), split)
     assert np.array_equal(np.concatenate([r["pos"] for r in res]), pos)
 
+    boxes = np.round(rng.random((n, 4)) * 500, 1)              # the worker draws the same numbers after `cat`
+    boxes[:, 2:] += boxes[:, :2] + 1
+    boxes[::50, 2] = boxes[::50, 0]
+    off, flag, text = olib.yolo_lines(boxes, np.arange(n + 1, dtype=np.int32), None, np.full(n, 640.0), np.full(n, 480.0),
+                                      (np.arange(n) % 13).astype(np.int32))
+    assert "".join(r["yolo_text"] for r in res).encode() == text and all(r["yolo_total"] == len(text) for r in res)
+    assert np.array_equal(np.concatenate([r["yolo_flag"] for r in res]), flag)
+    starts = np.concatenate([np.asarray(r["yolo_off"][:-1]) for r in res] + [[res[-1]["yolo_off"][-1]]])
+    assert np.array_equal(starts, off)
+
 
 def test_shard_bounds_cover_and_balance():
     from deal_yolo_daya_amd.distributed import shard_bounds, shard_bounds_weighted

@@ -282,5 +282,14 @@ def test_sharded_functions_world1_rccl(native):
         assert D.ref_hit_mask_sharded(src, ref, ops).tolist() == want
         split, pos = D.split_ids_sharded(np.array([0, 1, 0, -1, 0, 1], np.int32), 2, ops=ops)
         assert split[3] == 255 and sorted(pos[[0, 2, 4]].tolist()) == [0, 1, 2]
+        rng = np.random.default_rng(3)
+        box = np.round(rng.random((3000, 4)) * 400, 1)
+        box[:, 2:] += box[:, :2] + 1
+        box[::40, 3] = box[::40, 1]
+        row_off = np.arange(3001, dtype=np.int32)
+        w, h, cid = np.full(3000, 640.0), np.full(3000, 480.0), (np.arange(3000) % 17).astype(np.int32)
+        goff, gflag, gtext, gtotal = D.yolo_lines_sharded(box, row_off, None, w, h, cid, ops)
+        ooff, oflag, otext = olib.yolo_lines(box, row_off, None, w, h, cid)
+        assert gtext == otext and gtotal == len(otext) and np.array_equal(goff, ooff) and np.array_equal(gflag, oflag)
     finally:
         dist.destroy_process_group()
