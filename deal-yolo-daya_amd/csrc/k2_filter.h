@@ -51,6 +51,17 @@ __device__ __forceinline__ float f32_above(double v) {
     }
     return f;
 }
+// lane mask of a > b (false for NaN), kept in an SGPR pair: written as C++ the four tests of a pair are widened to
+// integers and recombined with 16-bit VALU ops (17 VALU instructions per pair instead of 4 compares + scalar ANDs)
+__device__ __forceinline__ unsigned long long gt_mask(float a, float b) {
+    unsigned long long m;
+    asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ unsigned long long overlap_mask(const float4 &a, const float4 &b) {
+    return gt_mask(a.z, b.x) & gt_mask(b.z, a.x) & gt_mask(a.w, b.y) & gt_mask(b.w, a.y);
+}
+
 __device__ __forceinline__ float4 outward_f32(const Corners &c) {
     return make_float4(f32_below(c.x1), f32_below(c.y1), f32_above(c.x2), f32_above(c.y2));
 }
@@ -143,11 +154,9 @@ __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t 
                         const int32_t j0 = (ib + 1 > tj) ? ib + 1 : tj;  // smallest partner any lane of the group needs
                         for (int32_t j = j0; j < tj + tn; ++j) {
                             const float4 o = S.cf[j - tj];
-                            const int cand = (int)(have && j > i) & (int)(mef.z > o.x) & (int)(o.z > mef.x) & (int)(mef.w > o.y) &
-                                             (int)(o.w > mef.y);
-                            const unsigned long long m = __ballot(cand != 0);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(have && j > i) & overlap_mask(mef, o);
                             if (m) {
-                                if (cand) {
+                                if ((m >> lane) & 1ull) {
                                     const int slot = qn + __popcll(m & lt);
                                     S.qa[slot] = (uint32_t)i;
                                     S.qb[slot] = (uint32_t)j;
@@ -255,11 +264,9 @@ __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t 
                     const int32_t kj = rs + j;  // partner of this trip
                     j = (j + 1 >= n) ? 0 : j + 1;
                     nxt = S.cf[rs + j];
-                    const int cand = (int)(d <= trips) & (int)(mef.z > o.x) & (int)(o.z > mef.x) & (int)(mef.w > o.y) &
-                                     (int)(o.w > mef.y);
-                    const unsigned long long m = __ballot(cand != 0);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(d <= trips) & overlap_mask(mef, o);
                     if (m) {  // wave-uniform
-                        if (cand) {
+                        if ((m >> lane) & 1ull) {
                             const int slot = qn + __popcll(m & lt);
                             S.qa[slot] = (uint32_t)k;
                             S.qb[slot] = (uint32_t)kj;
