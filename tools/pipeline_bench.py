@@ -132,6 +132,23 @@ def main():
           lambda: ck(L.dyd_split_ids_dev(cat.data_ptr(), B, perm.data_ptr(), cat_off.data_ptr(), n_train.data_ptr(),
                                          n_val.data_ptr(), 2, split.data_ptr(), pos.data_ptr(), sp), "k6"),
           expanded_rows=B, host_mt19937_s=round(host_perm_s, 2))
+    # K7: one label line per record (= per box of K1's output), the shape of the split sheets
+    import ctypes as C
+    del split, pos, perm, cat
+    one = torch.arange(B + 1, dtype=torch.int32, device=dev)
+    w = torch.full((B,), 1920.0, dtype=torch.float64, device=dev); hh = torch.full((B,), 1080.0, dtype=torch.float64, device=dev)
+    cid = (torch.arange(B, device=dev, dtype=torch.int32) % 20).contiguous()
+    toff = torch.empty(B + 1, dtype=torch.int64, device=dev); flag = torch.empty(B, dtype=torch.uint8, device=dev)
+    tot = C.c_int64()
+    ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), hh.data_ptr(), cid.data_ptr(), B, toff.data_ptr(),
+                            flag.data_ptr(), None, 0, C.byref(tot), sp), "k7 measure")
+    T = tot.value
+    text = torch.empty(T, dtype=torch.uint8, device=dev)
+    stage("K7 label lines (one per record; after the 5-stage total below)", 32 * B + 4 * (B + 1) + 20 * B + 8 * (B + 1) + B + T,
+          lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), hh.data_ptr(), cid.data_ptr(), B,
+                                          toff.data_ptr(), flag.data_ptr(), text.data_ptr(), T, C.byref(tot), sp), "k7"),
+          records=B, text_GB=round(T / 1e9, 2))
+    k7 = stages.pop()
     total = sum(s["ms"] for s in stages)
     print(json.dumps({"stage": "TOTAL device pipeline (sum of stages, full table at every stage)", "ms": round(total, 3),
                       "rows": N, "rows_per_s": round(N / total * 1e3), "device": _native.device_name()}), flush=True)
