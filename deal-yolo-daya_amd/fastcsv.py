@@ -110,7 +110,10 @@ class CsvIndex:
 
     def close(self):
         if self._h is not None:
-            _native.load_library().dyd_csv_free(self._h)
+            try:
+                _native.load_library().dyd_csv_free(self._h)
+            except Exception:  # noqa: BLE001 - interpreter shutdown: the library may already be gone
+                pass
             self._h = None
 
     def __del__(self):
