@@ -258,3 +258,20 @@ def test_generate_yolo_datasets_on_the_device(native, tmp_path):
     import test_yolo_host_cpu as host
     got = host.check_yolo_step(tmp_path, None)
     assert sum(got["stats"]["catA"].values()) > 30
+
+
+def test_k7_signed_values_at_scale(native, k7_variant):
+    """coordinates and image sizes of either sign: minus signs change the line lengths row by row, which is what
+    the in-tile scan and the look-back carry; 300 k single-box rows against the C oracle, byte for byte"""
+    rng = np.random.default_rng(123)
+    n = 300_000
+    c = np.round(rng.uniform(-600, 600, (n, 2)), 2)
+    d = np.round(rng.uniform(0.01, 300, (n, 2)), 2)
+    box = np.concatenate([c, c + d], axis=1)
+    flip = rng.random(n) < 0.5
+    box[flip] = box[flip][:, [2, 3, 0, 1]]
+    w = rng.choice([1920.0, -1920.0, 640.0, -333.0, 1e4, -1e-3], n)
+    h = rng.choice([1080.0, -1080.0, 77.0, -0.5, 2e5], n)
+    cid = rng.integers(0, 150, n).astype(np.int32)
+    flag = _check_against_oracle(native, box, np.arange(n + 1, dtype=np.int32), None, w, h, cid)
+    assert (flag == 0).sum() > n * 0.9
