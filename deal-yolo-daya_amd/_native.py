@@ -115,6 +115,7 @@ SIGNATURES = {
     "dyd_csv_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "dyd_csv_col_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
     "dyd_csv_row_end": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "dyd_csv_has_cr": (C.c_int, [C.c_void_p]),
     "dyd_csv_free": (None, [C.c_void_p]),
     "dyd_csv_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

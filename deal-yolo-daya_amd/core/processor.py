@@ -92,7 +92,7 @@ def _merge_file_native(csv_file: Path, output_file: str, encoding: str, chunk_si
     if idx is None:
         return None
     names, n_rows = idx.names, idx.n_rows
-    if n_rows == 0 or "source_file" in names:
+    if n_rows == 0 or "source_file" in names or idx.has_cr():   # (CR LF: the text-mode handle's f.tell() is not emulated)
         return None
     heavy = {}
     for c, nm in enumerate(names):

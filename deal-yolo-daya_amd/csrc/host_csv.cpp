@@ -82,6 +82,7 @@ struct dyd_csv {
     int64_t len = 0;
     int64_t n_rows = 0;   // data rows (header excluded)
     int32_t n_cols = 0;
+    bool has_cr = false;   // some line ends are "\r\n"
     std::vector<Field> header;
     std::vector<Field> fields;  // n_rows * n_cols, row-major
     // outputs owned by the handle: one store per extracted column, alive until dyd_csv_free
@@ -100,11 +101,20 @@ namespace {
 // appended to `fields` (n_cols per record once n_cols > 0; with n_cols == 0 exactly ONE record, the header, is
 // read and its width returned through n_cols).  false = something the fast path does not reproduce exactly.
 bool tokenize(const char *base, const char *p, const char *stop, const char *end, int32_t &n_cols, std::vector<Field> &fields,
-              int64_t &rows, const char **next) {
+              int64_t &rows, const char **next, bool *saw_cr) {
     const bool header_only = (n_cols == 0);
+    // a line ends with "\n" or "\r\n"; any other CR (alone, or inside a quoted cell, where pandas keeps it but a
+    // text-mode reader would not) is left to pandas
+    auto line_end = [&](const char *q) -> int {   // 0: not a line end, 1 / 2: its length, -1: stray CR
+        if (q >= end) return 0;
+        if (*q == '\n') return 1;
+        if (*q == '\r') return (q + 1 < end && q[1] == '\n') ? 2 : -1;
+        return 0;
+    };
     while (p < stop) {
-        if (*p == '\n') { ++p; continue; }                      // blank line: skipped (skip_blank_lines)
-        if (*p == '\r') return false;                           // CR line ends: leave to pandas
+        const int blank = line_end(p);
+        if (blank < 0) return false;
+        if (blank > 0) { if (blank == 2) *saw_cr = true; p += blank; continue; }   // blank line: skipped (skip_blank_lines)
         const size_t row_start = fields.size();
         while (true) {
             Field f{};
@@ -119,13 +129,15 @@ bool tokenize(const char *base, const char *p, const char *stop, const char *end
                     p = q + 1;
                     break;
                 }
-                if (p < end && *p != ',' && *p != '\n') return false;   // text after the closing quote / CR
+                if (memchr(base + f.b, '\r', (size_t)(f.e - f.b))) return false;   // CR inside a quoted cell
+                if (p < end && *p != ',' && line_end(p) <= 0) return false;        // text after the closing quote / stray CR
             } else {
                 f.b = p - base;
-                while (p < end && *p != ',' && *p != '\n') {
-                    if (*p == '"' || *p == '\r') return false;  // stray quote / CR
+                while (p < end && *p != ',' && *p != '\n' && *p != '\r') {
+                    if (*p == '"') return false;                 // stray quote
                     ++p;
                 }
+                if (p < end && *p == '\r' && line_end(p) < 0) return false;
                 f.e = p - base;
             }
             fields.push_back(f);
@@ -134,7 +146,9 @@ bool tokenize(const char *base, const char *p, const char *stop, const char *end
                 if (p == end) { fields.push_back(Field{p - base, p - base, 0}); break; }
                 continue;
             }
-            if (p < end) ++p;  // the line end
+            const int le = line_end(p);
+            if (le == 2) *saw_cr = true;
+            p += (le > 0) ? le : 0;
             break;
         }
         const int32_t width = (int32_t)(fields.size() - row_start);
@@ -173,7 +187,9 @@ int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out) {
         const char *body = base;
         int64_t none = 0;
         while (body < end && *body == '\n') ++body;
-        if (body >= end || !tokenize(base, body, end, end, h->n_cols, h->header, none, &body) || h->n_cols <= 0) {
+        bool cr0 = false;
+        while (body + 1 < end && body[0] == '\r' && body[1] == '\n') body += 2;
+        if (body >= end || !tokenize(base, body, end, end, h->n_cols, h->header, none, &body, &cr0) || h->n_cols <= 0) {
             delete h;
             return DYD_ERR_INVALID;
         }
@@ -183,7 +199,8 @@ int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out) {
         int T = (int)std::min<int64_t>(std::min<unsigned>(32u, std::max(2u, std::thread::hardware_concurrency())), rest / chunk_bytes);
         if (T <= 1) {
             const char *next = body;
-            if (!tokenize(base, body, end, end, h->n_cols, h->fields, h->n_rows, &next)) { delete h; return DYD_ERR_INVALID; }
+            if (!tokenize(base, body, end, end, h->n_cols, h->fields, h->n_rows, &next, &cr0)) { delete h; return DYD_ERR_INVALID; }
+            h->has_cr = cr0;
         } else {
             std::vector<const char *> cut((size_t)T + 1);
             for (int t = 0; t <= T; ++t) cut[(size_t)t] = body + rest * t / T;
@@ -216,7 +233,7 @@ int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out) {
                 start[(size_t)t] = q;
             }
             for (int t = 1; t <= T; ++t) if (start[(size_t)t] < start[(size_t)t - 1]) start[(size_t)t] = start[(size_t)t - 1];
-            struct Part { std::vector<Field> fields; int64_t rows = 0; bool ok = true; };
+            struct Part { std::vector<Field> fields; int64_t rows = 0; bool ok = true; bool cr = false; };
             std::vector<Part> parts((size_t)T);
             {
                 std::vector<std::thread> th;
@@ -227,7 +244,7 @@ int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out) {
                         int32_t nc = h->n_cols;
                         try {
                             pt.fields.reserve((size_t)((start[(size_t)t + 1] - start[(size_t)t]) / 64 + 16));
-                            pt.ok = tokenize(base, start[(size_t)t], start[(size_t)t + 1], end, nc, pt.fields, pt.rows, &next);
+                            pt.ok = tokenize(base, start[(size_t)t], start[(size_t)t + 1], end, nc, pt.fields, pt.rows, &next, &pt.cr);
                         } catch (const std::bad_alloc &) {
                             pt.ok = false;
                         }
@@ -235,10 +252,12 @@ int dyd_csv_index(const uint8_t *text, int64_t len, dyd_csv **out) {
                 for (auto &x : th) x.join();
             }
             size_t total = 0;
+            h->has_cr = cr0;
             for (auto &pt : parts) {
                 if (!pt.ok) { delete h; return DYD_ERR_INVALID; }
                 total += pt.fields.size();
                 h->n_rows += pt.rows;
+                h->has_cr = h->has_cr || pt.cr;
             }
             h->fields.resize(total);
             std::vector<size_t> at((size_t)T, 0);
@@ -415,9 +434,13 @@ int64_t dyd_csv_col_bytes(const dyd_csv *h, int32_t c) {
 int64_t dyd_csv_row_end(const dyd_csv *h, int64_t row) {
     if (!h || row < -1 || row >= h->n_rows || h->n_cols <= 0) return -1;
     const Field &f = row < 0 ? h->header[(size_t)h->n_cols - 1] : h->fields[(size_t)(row * h->n_cols + h->n_cols - 1)];
-    const int64_t e = f.e + (f.quoted ? 1 : 0) + 1;
+    int64_t e = f.e + (f.quoted ? 1 : 0);
+    if (e < h->len && h->text[e] == '\r') ++e;
+    if (e < h->len && h->text[e] == '\n') ++e;
     return e < h->len ? e : h->len;
 }
+
+int dyd_csv_has_cr(const dyd_csv *h) { return h && h->has_cr ? 1 : 0; }   // "\r\n" line ends seen
 
 void dyd_csv_free(dyd_csv *h) { delete h; }
 

@@ -119,6 +119,10 @@ class CsvIndex:
     def __del__(self):
         self.close()
 
+    def has_cr(self) -> bool:
+        """some lines of the file end with CR LF (a text-mode reader would rewrite those; path readers do not)"""
+        return bool(_native.load_library().dyd_csv_has_cr(self._h))
+
     def col_bytes(self, c: int) -> int:
         return int(_native.load_library().dyd_csv_col_bytes(self._h, c))
 

@@ -274,6 +274,7 @@ int dyd_csv_extract(dyd_csv *csv, int32_t col, const uint8_t **bytes, const int6
 int dyd_csv_project(dyd_csv *csv, const int32_t *keep, int32_t n_keep, const uint8_t **text, int64_t *len);
 int64_t dyd_csv_col_bytes(const dyd_csv *csv, int32_t col);   /* total cell bytes of a column */
 int64_t dyd_csv_row_end(const dyd_csv *csv, int64_t row);     /* byte offset behind data row `row` (-1: the header) */
+int dyd_csv_has_cr(const dyd_csv *csv);                       /* 1: some lines end with "\r\n" */
 void dyd_csv_free(dyd_csv *csv);
 /* mode 0: write `path` anew, 1: to memory (*mem_out, dyd_host_free), 2: append to `path` (merge step, :73-76) */
 int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, const dyd_csv_col *cols,

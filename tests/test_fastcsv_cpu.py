@@ -72,7 +72,9 @@ def test_write_table_equals_to_csv(tmp_path, seed):
 
 
 def test_reader_refuses_what_it_does_not_reproduce(tmp_path):
-    cases = {"crlf": "source,%s\r\na,{}\r\n" % ANN, "ragged": "source,%s\na\n" % ANN, "stray_quote": 'source,%s\na"b,{}\n' % ANN,
+    cases = {"lone_cr": "source,%s\ra,{}\r" % ANN, "cr_in_quoted_cell": 'source,%s\na,"{""k"": ""x\r\ny""}"\n' % ANN,
+             "cr_inside_line": "source,%s\na\rb,{}\n" % ANN,
+             "ragged": "source,%s\na\n" % ANN, "stray_quote": 'source,%s\na"b,{}\n' % ANN,
              "dup_names": "a,a,%s\n1,2,{}\n" % ANN, "numeric_heavy": "source,%s\na,5\nb,7\n" % ANN, "empty": ""}
     for name, text in cases.items():
         p = str(tmp_path / f"{name}.csv")
@@ -209,7 +211,7 @@ def test_parallel_tokeniser_equals_the_serial_one(tmp_path, monkeypatch, seed, c
 def test_parallel_tokeniser_rejects_what_the_serial_one_rejects(tmp_path, monkeypatch):
     good = "source,%s\n" % ANN + "".join('u%d,"{""k"": ""a,\nb""}"\n' % i for i in range(400))
     cases = {"stray_quote": good.replace('u200,"', 'u2"00,"'), "ragged": good.replace("u300,", "u300,x,"),
-             "crlf": good.replace('u100,"{""k"": ""a,\nb""}"\n', 'u100,"{}"\r\n'), "unterminated": good[:-3]}
+             "lone_cr": good.replace('u100,"{""k"": ""a,\nb""}"\n', 'u100,"{}"\r'), "unterminated": good[:-3]}
     for chunk in ("1000000000", "128"):
         monkeypatch.setenv("DYD_CSV_CHUNK_BYTES", chunk)
         p = str(tmp_path / "ok.csv")
@@ -221,3 +223,38 @@ def test_parallel_tokeniser_rejects_what_the_serial_one_rejects(tmp_path, monkey
             with open(p, "w", encoding="utf-8-sig", newline="") as f:
                 f.write(text)
             assert fastcsv.read_split(p, [ANN]) is None, (name, chunk)
+
+
+@pytest.mark.parametrize("chunk", ["1000000000", "200"])
+def test_crlf_line_ends_are_read_like_pandas(tmp_path, monkeypatch, chunk):
+    """Windows line ends (all lines, or only some): same frame as pandas, and the steps write the same files"""
+    monkeypatch.setenv("DYD_CSV_CHUNK_BYTES", chunk)
+    df = _messy_frame(321, n=200)
+    df["txt"] = df["txt"].str.replace("\n", " ")                    # a CR LF inside a quoted cell is left to pandas (tested above)
+    lf = df.to_csv(index=False)
+    crlf = df.to_csv(index=False, lineterminator="\r\n")
+    lines = lf.split("\n")
+    mixed = "".join(ln + ("\r\n" if i % 3 else "\n") for i, ln in enumerate(lines[:-1]))
+    for name, text in (("crlf", crlf), ("mixed", mixed), ("blank_lines", crlf.replace("\r\n", "\r\n\r\n", 5))):
+        p = str(tmp_path / f"{name}.csv")
+        with open(p, "w", encoding="utf-8-sig", newline="") as f:
+            f.write(text)
+        want = pd.read_csv(p, encoding="utf-8-sig")
+        t = fastcsv.read_split(p, [ANN, BBOX])
+        assert t is not None, name
+        pd.testing.assert_frame_equal(fastcsv.frame_from_split(t), want)
+
+
+def test_steps_on_a_crlf_file_write_what_the_pandas_path_writes(oracle_backend, tmp_path, monkeypatch):
+    text = golden_csv_text("e2e_filtered.csv.gz").replace("\n", "\r\n")
+    write_csv_text(str(tmp_path / "in.csv"), text)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DYD_NATIVE_CSV", mode)
+        Q = lambda n: str(tmp_path / f"{n}_{mode}.csv")  # noqa: E731
+        P.deduplicate_csv_by_source(str(tmp_path / "in.csv"), Q("dedup"), backend=oracle_backend, verbose=False)
+        P.process_csv_replace_ptlist(str(tmp_path / "in.csv"), Q("proc"), Q("exc"), backend=oracle_backend)
+        if mode == "1":
+            assert P.LAST_IO_PATH["replace"] == "native" and P.LAST_IO_PATH["dedup"] == "native"
+        outs[mode] = [open(Q(n), "rb").read() for n in ("dedup", "proc", "exc")]
+    assert outs["1"] == outs["0"]
