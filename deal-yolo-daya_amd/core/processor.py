@@ -52,20 +52,25 @@ _HEAVY_BYTES_PER_ROW = 64     # a column averaging more than this per cell is ca
 
 class _TellEmulator:
     """What ``f.tell()`` shows after pandas has parsed up to a given row when it reads a text-mode handle in
-    blocks of 262144 characters (reference processor.py:80): the byte offset behind the last block read."""
+    blocks of 262144 characters (reference processor.py:80): the byte offset behind the last block read.
+    Characters are counted as the text layer delivers them: one per UTF-8 lead byte, a CR LF pair as one."""
 
-    def __init__(self, raw: bytes, bom_len: int):
+    def __init__(self, raw: bytes, bom_len: int, crlf: bool):
         self.b = np.frombuffer(raw, np.uint8)
         self.pos = bom_len
+        self.crlf = crlf            # every CR of the file is the first half of a CR LF line end (checked by the tokeniser)
 
     def _read_block(self):
         need, pos, n = _READ_CHARS, self.pos, len(self.b)
         while need > 0 and pos < n:
             seg = self.b[pos:pos + need]
-            need -= int(np.count_nonzero((seg & 0xC0) != 0x80))        # characters that start inside the segment
+            chars = int(np.count_nonzero((seg & 0xC0) != 0x80))         # characters that start inside the segment
+            if self.crlf:
+                chars -= int(np.count_nonzero(seg == 13))               # a CR and its LF arrive as one "\n"
+            need -= chars
             pos += len(seg)
-        while pos < n and (self.b[pos] & 0xC0) == 0x80:               # the tail bytes of the last character
-            pos += 1
+        while pos < n and ((self.b[pos] & 0xC0) == 0x80 or (self.crlf and self.b[pos] == 10 and self.b[pos - 1] == 13)):
+            pos += 1                                                     # the tail of the last character / its LF
         self.pos = pos
 
     def after(self, byte_end: int) -> int:
@@ -92,7 +97,7 @@ def _merge_file_native(csv_file: Path, output_file: str, encoding: str, chunk_si
     if idx is None:
         return None
     names, n_rows = idx.names, idx.n_rows
-    if n_rows == 0 or "source_file" in names or idx.has_cr():   # (CR LF: the text-mode handle's f.tell() is not emulated)
+    if n_rows == 0 or "source_file" in names:
         return None
     heavy = {}
     for c, nm in enumerate(names):
@@ -112,7 +117,7 @@ def _merge_file_native(csv_file: Path, output_file: str, encoding: str, chunk_si
                                  chunksize=chunk_size)
     else:
         light_iter = (pd.DataFrame(index=pd.RangeIndex(r1 - r0)) for r0, r1 in bounds)
-    tell = _TellEmulator(raw, bom)
+    tell = _TellEmulator(raw, bom, idx.has_cr())
     out_names = names + ["source_file"]
     base = os.path.basename(csv_file)
     written = 0

@@ -46,7 +46,7 @@ def test_merge_matches_reference(tmp_path, sorted_glob, run_idx):
     assert got["return"] == want["return"]
     paths = P.LAST_IO_PATH["merge"]
     assert paths["a_main.csv"] == "native" and paths["b_other_order.csv"] == "native"
-    assert paths["c_narrow.csv"] == "pandas" and paths["d_crlf.csv"] == "pandas" and paths["h_has_source_file.csv"] == "pandas"
+    assert paths["c_narrow.csv"] == "pandas" and paths["d_crlf.csv"] == "native" and paths["h_has_source_file.csv"] == "pandas"
 
 
 def test_merge_progress_offsets_follow_the_parser_reads(tmp_path, monkeypatch, sorted_glob):
@@ -80,3 +80,23 @@ def test_merge_errors_and_empty_folder(tmp_path, capsys):
     (tmp_path / "e" / "x.csv").write_text("")
     assert P.merge_all_csv_in_folder(str(tmp_path / "e"), str(tmp_path / "o.csv")) is None
     assert "没有可合并的有效CSV数据" in capsys.readouterr().out
+
+
+def test_merge_crlf_files_native_equals_the_pandas_loop(tmp_path, monkeypatch, sorted_glob):
+    """CR LF inputs: the text-mode handle delivers "\n" for every CR LF, which moves both the parsed text and the
+    f.tell() positions the progress callback reports"""
+    folder = tmp_path / "in"
+    folder.mkdir()
+    df = synth.to_frame(synth.generate(1500, seed=4, max_boxes=6))
+    df["说明"] = ["中文说明，带逗号" * (1 + i % 4) for i in range(len(df))]
+    df.to_csv(folder / "w1.csv", index=False, encoding="utf-8-sig", lineterminator="\r\n")
+    text = df.iloc[::-1].to_csv(index=False)
+    lines = text.split("\n")
+    with open(folder / "w2_mixed.csv", "w", encoding="utf-8-sig", newline="") as f:
+        f.write("".join(ln + ("\r\n" if i % 2 else "\n") for i, ln in enumerate(lines[:-1])))
+    native = _run(str(folder), str(tmp_path / "n.csv"), 170, tmp_path)
+    assert set(P.LAST_IO_PATH["merge"].values()) == {"native"}
+    monkeypatch.setenv("DYD_NATIVE_CSV", "0")
+    plain = _run(str(folder), str(tmp_path / "p.csv"), 170, tmp_path)
+    assert native["merged"] == plain["merged"] and native["return"] == plain["return"] == 3000
+    assert native["calls"] == plain["calls"]
