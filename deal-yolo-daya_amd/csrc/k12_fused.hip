@@ -62,15 +62,16 @@ __global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__re
 }
 
 // wave-autonomous variant: boxes go from K1 to K2 through LDS, no workgroup barrier (k12_wave.h)
-__global__ __launch_bounds__(K1_BLOCK) void k12_wave_kernel(const double2 *__restrict__ xy,
+template <int WPB>   // waves per workgroup: the waves are autonomous, so this only sets the dispatch granularity
+__global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__restrict__ xy,
                                                             const int32_t *__restrict__ pt_off,
                                                             const int32_t *__restrict__ box_off, int64_t n_rows,
                                                             int32_t min_boxes, double thr, double *out_box4,
                                                             int32_t *__restrict__ out_arg4,
                                                             uint8_t *__restrict__ out_high) {
-    __shared__ WaveFuse s_all[K2_WAVES];
+    __shared__ WaveFuse s_all[WPB];
     const int wave = threadIdx.x >> 6;
-    const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * KW_ROWS;
+    const int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * KW_ROWS;
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
     k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave]);
@@ -132,15 +133,23 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     // sparse rows (<= 24 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
     // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
     if (v < 0) v = (n_boxes <= 24 * n_rows) ? 4 : 6;
-    if (v == 4) {
-        const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * KW_ROWS);
+    if (v == 4 || v == 7 || v == 8) {
+        const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
+        const int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);
         if (blocks > 0x7fffffffLL) {
             set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
             return DYD_ERR_RANGE;
         }
-        hipLaunchKernelGGL(k12_wave_kernel, dim3((unsigned)blocks), dim3(K1_BLOCK), 0, st,
-                           reinterpret_cast<const double2 *>(xy), pt_off, box_off, n_rows, min_boxes, thr, out_box4,
-                           out_arg4, out_high);
+        const double2 *xy2 = reinterpret_cast<const double2 *>(xy);
+        if (wpb == 4)
+            hipLaunchKernelGGL(k12_wave_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
+                               thr, out_box4, out_arg4, out_high);
+        else if (wpb == 2)
+            hipLaunchKernelGGL(k12_wave_kernel<2>, dim3((unsigned)blocks), dim3(128), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
+                               thr, out_box4, out_arg4, out_high);
+        else
+            hipLaunchKernelGGL(k12_wave_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
+                               thr, out_box4, out_arg4, out_high);
         DYD_HIP(hipGetLastError());
         return DYD_OK;
     }

@@ -30,7 +30,7 @@ def _table(rng, n_rows, max_boxes, max_pts, special):
                                                               (65, 32, 12, True), (3000, 32, 12, True),
                                                               (700, 90, 30, False), (50, 300, 6, False),
                                                               (20, 4, 900, True)])
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, variant):
     import torch
 

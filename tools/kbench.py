@@ -43,6 +43,18 @@ def main():
             ts.append(a.elapsed_time(b))
         return float(np.median(ts)), float(np.min(ts))
 
+    def timeit_b2b(fn, n=100, warm=10):
+        """ms per launch when the launches are queued back to back (what bench.py times): one event pair around n launches"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record(); b.synchronize()
+        return a.elapsed_time(b) / n
+
     def report(name, nbytes, med, mn, **kw):
         print(json.dumps({"kernel": name, "ms_median": round(med, 4), "ms_min": round(mn, 4),
                           "alg_GB": round(nbytes / 1e9, 4), "GBs_median": round(nbytes / med / 1e6, 1),
@@ -114,15 +126,23 @@ def main():
         k12_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N
         res = {}
         for rnd in range(2):
-            for variant in (0, 1, 2, 3, 4, 5, 6):
+            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
                 ck(L.dyd_set_option(b"fused_variant", variant), "opt")
                 med, mn = timeit(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(),
                                                                       N, B, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
                                                                       out_high.data_ptr(), sp), "k12"))
                 res.setdefault(variant, []).append((med, mn))
+        b2b = {}
+        for variant in (4, 8, 7):
+            ck(L.dyd_set_option(b"fused_variant", variant), "opt")
+            b2b[variant] = timeit_b2b(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2,
+                                                                          0.98, out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(),
+                                                                          sp), "k12"))
+        print(json.dumps({"k12_wave_back_to_back_ms": {"4 waves/wg (default)": round(b2b[4], 4), "2 waves/wg": round(b2b[8], 4),
+                                                        "1 wave/wg": round(b2b[7], 4)}}), flush=True)
         ck(L.dyd_set_option(b"fused_variant", -1), "opt")
         for variant, name in ((0, "k12_fused<2048,16,256>"), (2, "k12_fused<1024,8,128>"), (3, "k12_fused<1024,16,256>"),
-                              (4, "k12_wave_kernel"), (5, "k12_fused<2048,16,256,filter>"), (6, "k12_fused<1024,8,128,filter>"),
+                              (4, "k12_wave_kernel"), (8, "k12_wave_kernel, 2 waves per workgroup"), (7, "k12_wave_kernel, 1 wave per workgroup"), (5, "k12_fused<2048,16,256,filter>"), (6, "k12_fused<1024,8,128,filter>"),
                               (1, "k1_then_k2_two_launches")):
             med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
             report(name, k12_bytes, med, mn, rows_per_s=round(N / med * 1e3), high=int(out_high.sum().item()))
