@@ -353,10 +353,24 @@ def make_e2e(n_rows=240):
         P = lambda n: os.path.join(d, n)  # noqa: E731
         df.to_csv(P("merged.csv"), index=False, encoding="utf-8-sig")
         ref_df.to_csv(P("ref.csv"), index=False, encoding="utf-8-sig")
-        ref.deduplicate_csv_by_source(P("merged.csv"), P("dedup.csv"), verbose=False)
-        ref.remove_duplicates_between_csv(P("dedup.csv"), P("ref.csv"), P("filtered.csv"), verbose=False)
-        ref.process_csv_replace_ptlist(P("filtered.csv"), P("processed.csv"), P("excluded.csv"))
-        ref.filter_by_box_count_and_iou(P("processed.csv"), P("high.csv"), P("other.csv"), 2, 0.98)
+        import contextlib
+        prints = {}
+
+        def logged(name, fn, *a, **k):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                out = fn(*a, **k)
+            prints[name] = buf.getvalue().replace(d, "<TMP>")
+            return out
+
+        logged("dedup", ref.deduplicate_csv_by_source, P("merged.csv"), P("dedup.csv"))
+        logged("ref_filter", ref.remove_duplicates_between_csv, P("dedup.csv"), P("ref.csv"), P("filtered.csv"))
+        logged("replace", ref.process_csv_replace_ptlist, P("filtered.csv"), P("processed.csv"), P("excluded.csv"))
+        logged("iou", ref.filter_by_box_count_and_iou, P("processed.csv"), P("high.csv"), P("other.csv"), 2, 0.98)
+        logged("replace_missing_file", ref.process_csv_replace_ptlist, P("nope.csv"), P("x.csv"), P("y.csv"))
+        logged("iou_missing_column", ref.filter_by_box_count_and_iou, P("ref.csv"), P("h2.csv"), P("o2.csv"))
+        logged("replace_missing_column", ref.process_csv_replace_ptlist, P("ref.csv"), P("x.csv"), P("y.csv"))
+        _dump("e2e_prints.json", prints)
         for n in ("merged", "ref", "dedup", "filtered", "processed", "excluded", "high", "other"):
             with open(P(n + ".csv"), "rb") as f, gzip.GzipFile(os.path.join(HERE, f"e2e_{n}.csv.gz"), "wb", mtime=0) as g:
                 g.write(f.read())

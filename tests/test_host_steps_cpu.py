@@ -210,3 +210,29 @@ def test_synth_is_regular_and_deterministic(oracle_backend):
     mask = P.iou_high_mask(kept[P.BBOX_COL].tolist(), 2, 0.98, oracle_backend, stats)
     assert stats["host_rows"] == 0
     assert 0 < mask.sum() < len(mask)
+
+
+def test_printed_lines_match_the_reference(oracle_backend, tmp_path, capsys):
+    """run_step captures stdout for the UI (reference ui/pages/processing.py): the log lines are part of the drop-in"""
+    g = load_golden("e2e_prints.json")
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    for n in ("merged", "ref"):
+        write_csv_text(Q(n + ".csv"), golden_csv_text(f"e2e_{n}.csv.gz"))
+
+    def printed(fn, *a, **k):
+        capsys.readouterr()
+        fn(*a, **k, backend=oracle_backend)
+        return capsys.readouterr().out.replace(str(tmp_path), "<TMP>")
+
+    for native_csv in ("1", "0"):
+        os.environ["DYD_NATIVE_CSV"] = native_csv
+        try:
+            assert printed(P.deduplicate_csv_by_source, Q("merged.csv"), Q("dedup.csv")) == g["dedup"]
+            assert printed(P.remove_duplicates_between_csv, Q("dedup.csv"), Q("ref.csv"), Q("filtered.csv")) == g["ref_filter"]
+            assert printed(P.process_csv_replace_ptlist, Q("filtered.csv"), Q("processed.csv"), Q("excluded.csv")) == g["replace"]
+            assert printed(P.filter_by_box_count_and_iou, Q("processed.csv"), Q("high.csv"), Q("other.csv"), 2, 0.98) == g["iou"]
+            assert printed(P.process_csv_replace_ptlist, Q("nope.csv"), Q("x.csv"), Q("y.csv")) == g["replace_missing_file"]
+            assert printed(P.filter_by_box_count_and_iou, Q("ref.csv"), Q("h2.csv"), Q("o2.csv")) == g["iou_missing_column"]
+            assert printed(P.process_csv_replace_ptlist, Q("ref.csv"), Q("x.csv"), Q("y.csv")) == g["replace_missing_column"]
+        finally:
+            os.environ.pop("DYD_NATIVE_CSV", None)
