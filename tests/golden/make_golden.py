@@ -370,6 +370,29 @@ def make_e2e(n_rows=240):
         logged("replace_missing_file", ref.process_csv_replace_ptlist, P("nope.csv"), P("x.csv"), P("y.csv"))
         logged("iou_missing_column", ref.filter_by_box_count_and_iou, P("ref.csv"), P("h2.csv"), P("o2.csv"))
         logged("replace_missing_column", ref.process_csv_replace_ptlist, P("ref.csv"), P("x.csv"), P("y.csv"))
+        errors = {}
+
+        def raised(name, fn, *a, **k):
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    fn(*a, **k)
+                errors[name] = None
+            except Exception as e:  # noqa: BLE001
+                errors[name] = [type(e).__name__, str(e).replace(d, "<TMP>")]
+
+        open(P("a.txt"), "w").write("source\n1\n")
+        open(P("nosource.csv"), "w").write("a,b\n1,2\n")
+        raised("dedup_missing_file", ref.deduplicate_csv_by_source, P("missing.csv"))
+        raised("dedup_not_csv", ref.deduplicate_csv_by_source, P("a.txt"))
+        raised("dedup_no_source_column", ref.deduplicate_csv_by_source, P("nosource.csv"), None)
+        raised("ref_missing_ref_file", ref.remove_duplicates_between_csv, P("nosource.csv"), P("missing.csv"))
+        raised("ref_missing_main_file", ref.remove_duplicates_between_csv, P("missing.csv"), P("nosource.csv"))
+        raised("ref_not_csv", ref.remove_duplicates_between_csv, P("a.txt"), P("nosource.csv"))
+        raised("ref_no_column", ref.remove_duplicates_between_csv, P("nosource.csv"), P("nosource.csv"), P("o.csv"))
+        raised("ref_no_column_in_ref", ref.remove_duplicates_between_csv, P("merged.csv"), P("nosource.csv"), P("o.csv"))
+        raised("split_missing_input", ref.split_dataset_by_rules, P("missing.csv"), P("nosource.csv"), P("out"))
+        raised("split_missing_rules", ref.split_dataset_by_rules, P("merged.csv"), P("missing.xlsx"), P("out"))
+        prints["errors"] = errors
         _dump("e2e_prints.json", prints)
         for n in ("merged", "ref", "dedup", "filtered", "processed", "excluded", "high", "other"):
             with open(P(n + ".csv"), "rb") as f, gzip.GzipFile(os.path.join(HERE, f"e2e_{n}.csv.gz"), "wb", mtime=0) as g:

@@ -236,3 +236,33 @@ def test_printed_lines_match_the_reference(oracle_backend, tmp_path, capsys):
             assert printed(P.process_csv_replace_ptlist, Q("ref.csv"), Q("x.csv"), Q("y.csv")) == g["replace_missing_column"]
         finally:
             os.environ.pop("DYD_NATIVE_CSV", None)
+
+
+def test_exception_messages_match_the_reference(oracle_backend, tmp_path):
+    g = load_golden("e2e_prints.json")["errors"]
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    write_csv_text(Q("merged.csv"), golden_csv_text("e2e_merged.csv.gz"))
+    (tmp_path / "a.txt").write_text("source\n1\n")
+    (tmp_path / "nosource.csv").write_text("a,b\n1,2\n")
+    calls = {
+        "dedup_missing_file": (P.deduplicate_csv_by_source, (Q("missing.csv"),)),
+        "dedup_not_csv": (P.deduplicate_csv_by_source, (Q("a.txt"),)),
+        "dedup_no_source_column": (P.deduplicate_csv_by_source, (Q("nosource.csv"), None)),
+        "ref_missing_ref_file": (P.remove_duplicates_between_csv, (Q("nosource.csv"), Q("missing.csv"))),
+        "ref_missing_main_file": (P.remove_duplicates_between_csv, (Q("missing.csv"), Q("nosource.csv"))),
+        "ref_not_csv": (P.remove_duplicates_between_csv, (Q("a.txt"), Q("nosource.csv"))),
+        "ref_no_column": (P.remove_duplicates_between_csv, (Q("nosource.csv"), Q("nosource.csv"), Q("o.csv"))),
+        "ref_no_column_in_ref": (P.remove_duplicates_between_csv, (Q("merged.csv"), Q("nosource.csv"), Q("o.csv"))),
+        "split_missing_input": (P.split_dataset_by_rules, (Q("missing.csv"), Q("nosource.csv"), Q("out"))),
+        "split_missing_rules": (P.split_dataset_by_rules, (Q("merged.csv"), Q("missing.xlsx"), Q("out"))),
+    }
+    assert set(calls) == set(g)
+    for native_csv in ("1", "0"):
+        os.environ["DYD_NATIVE_CSV"] = native_csv
+        try:
+            for name, (fn, args) in calls.items():
+                with pytest.raises(Exception) as info:
+                    fn(*args, backend=oracle_backend)
+                assert [type(info.value).__name__, str(info.value).replace(str(tmp_path), "<TMP>")] == g[name], (name, native_csv)
+        finally:
+            os.environ.pop("DYD_NATIVE_CSV", None)
