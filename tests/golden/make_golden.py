@@ -339,6 +339,14 @@ def make_split():
     out = {"input": _frame_records(df), "rules": _frame_records(rules_df), "seed": 42, "ratios": [0.8, 0.1, 0.1],
            "summary": summary, "category_files": files,
            "sheets": {k: {s: _frame_records(f) for s, f in v.items()} for k, v in sheets.items()}}
+    # the other rule sheet layout (:697-703): one (label, category) pair per row, with blanks / NaN / "nan" to be skipped,
+    # plus non-default ratios (normalised by their sum, :673-676) and another seed
+    two = pd.DataFrame({"标签": [" c1 ", "c2", None, "nan", "c12", "c3", "c19", ""], "类别": ["catA", " catA ", "catB", "catB", "catB", None, "NaN", "catC"],
+                        "备注": list("abcdefgh")})
+    sheets2, summary2, files2 = run_reference_split(df, two, seed=7, ratios=(6, 3, 1), rule_mode="two_column", label_col="标签", category_col="类别")
+    out["two_column"] = {"rules": _frame_records(two), "seed": 7, "ratios": [6, 3, 1], "label_col": "标签", "category_col": "类别",
+                         "summary": summary2, "category_files": files2,
+                         "sheets": {k: {s: _frame_records(f) for s, f in v.items()} for k, v in sheets2.items()}}
     _dump("split_case.json", out)
 
 

@@ -97,6 +97,17 @@ def run_split_golden(backend):
             _frames_equal(frame, g["sheets"][f"{cat}.xlsx"][name], (cat, name))
     _frames_equal(res["unclassified"], g["sheets"]["unclassified.xlsx"]["Sheet1"], "unclassified")
     _frames_equal(res["split_counts"], g["sheets"]["split_counts.xlsx"]["Sheet1"], "split_counts")
+    t = g["two_column"]                                  # rule_mode="two_column", ratios 6:3:1, seed 7
+    rules = pd.DataFrame(t["rules"]["data"], columns=t["rules"]["columns"])
+    res = P.split_frames(df, P.rules_to_label_map(rules, "two_column", t["label_col"], t["category_col"]), None, *t["ratios"],
+                         random_seed=t["seed"], backend=backend)
+    assert res["category_counts"] == t["summary"]["category_counts"]
+    assert list(res["categories"]) == [f[:-5] for f in t["category_files"]]
+    for cat, frames in res["categories"].items():
+        for name, frame in zip(("train", "val", "test"), frames):
+            _frames_equal(frame, t["sheets"][f"{cat}.xlsx"][name], (cat, name, "two_column"))
+    _frames_equal(res["unclassified"], t["sheets"]["unclassified.xlsx"]["Sheet1"], "unclassified two_column")
+    _frames_equal(res["split_counts"], t["sheets"]["split_counts.xlsx"]["Sheet1"], "split_counts two_column")
 
 
 def run_e2e_golden(backend, tmp_path):
