@@ -254,19 +254,15 @@ struct RowState {   // what the measuring pass keeps for the printing pass
 // one integer digit ("d.dddddd" or "-d.dddddd"); its line is cd + 36 bytes plus the minus signs.  Lanes holding a
 // plain row keep the four rounded values (bit 31 = sign) and print them straight; the other lanes go through
 // row_measure / row_print below.
-__device__ __forceinline__ bool plain_row(const RowIn &r, const double *__restrict__ box4,
-                                          const uint8_t *__restrict__ sel, uint32_t q[4]) {
-    q[0] = q[1] = q[2] = q[3] = 0;
-    if (r.host || r.b1 - r.b0 != 1 || (uint32_t)r.cid >= 100u) return false;
-    if (sel && !sel[r.b0]) return false;
-    const double *b = box4 + 4 * (int64_t)r.b0;
+// one box of a row of width w, height h: true when its line is plain; q = the four values as round(|v| * 10^6), bit 31 = sign
+__device__ __forceinline__ bool plain_box(const double *__restrict__ b, double w, double h, uint32_t q[4]) {
     const double2 lo2 = *reinterpret_cast<const double2 *>(b), hi2 = *reinterpret_cast<const double2 *>(b + 2);
     const double ax = lo2.x, ay = lo2.y, bx = hi2.x, by = hi2.y;
     const double x1 = (bx < ax) ? bx : ax, x2 = (bx > ax) ? bx : ax;
     const double y1 = (by < ay) ? by : ay, y2 = (by > ay) ? by : ay;
     const double bw = x2 - x1, bh = y2 - y1;            // max(d, 0.0) == d for the d > 0 accepted here
     bool ok = (bw > 0.0) && (bh > 0.0);
-    const double v[4] = {(x1 + x2) / 2.0 / r.w, (y1 + y2) / 2.0 / r.h, bw / r.w, bh / r.h};
+    const double v[4] = {(x1 + x2) / 2.0 / w, (y1 + y2) / 2.0 / h, bw / w, bh / h};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const double a = fabs(v[k]);
@@ -275,6 +271,14 @@ __device__ __forceinline__ bool plain_row(const RowIn &r, const double *__restri
         q[k] = round6(in_range ? a : 0.0) | ((uint32_t)((uint64_t)__double_as_longlong(v[k]) >> 63) << 31);
     }
     return ok;
+}
+
+__device__ __forceinline__ bool plain_row(const RowIn &r, const double *__restrict__ box4,
+                                          const uint8_t *__restrict__ sel, uint32_t q[4]) {
+    q[0] = q[1] = q[2] = q[3] = 0;
+    if (r.host || r.b1 - r.b0 != 1 || (uint32_t)r.cid >= 100u) return false;
+    if (sel && !sel[r.b0]) return false;
+    return plain_box(box4 + 4 * (int64_t)r.b0, r.w, r.h, q);
 }
 
 // "d.dddddd" for q < 10^7
@@ -832,22 +836,388 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_pair_kernel(const double *__
     }
 }
 
-static int g_k7_variant = 22;   // dyd_set_option("k7_variant"): 2 = one 512-row tile per ticket, 22 = two, pipelined (default)
+// ---- rows of many boxes: tiles cut by BOXES, one lane per box ----------------------------------------------------
+// The row-tiled kernels give a lane a whole row; with 1..32 boxes per row a 512-row tile's text (300 KB) no longer fits
+// LDS, the lanes loop over their boxes one after the other and print byte by byte to memory: 332 ms for 16.5 M lines
+// (measured).  Here a tile is the set of rows whose FIRST box falls into a window of K7B_WINDOW consecutive boxes
+// (two binary searches in row_off; every row, empty ones included, belongs to exactly one tile), a lane owns a box,
+// and what a row needs from its boxes comes out of workgroup scans over the boxes of the tile: the number of lines
+// before a box (the first line of a row has no "\n" in front, the others do) and the bytes before it.  One line the
+// host must print (a value of 2^43 or more) makes the whole row the host's, so when a tile has such a line a third scan
+// tells every box whether its row holds one.  Tiles of more than K7B_CAP boxes (a row of hundreds of boxes) take
+// the row-per-lane route in chunks of 256 rows.
+constexpr int K7B_WINDOW = 448;
+constexpr int K7B_CAP = 512;                 // boxes the LDS arrays of a tile hold: two per lane
+constexpr int K7B_PER = K7B_CAP / K7_BLOCK;
+
+// first i in [0, n] with off[i] >= x
+__device__ __forceinline__ int64_t lower_bound_off(const int32_t *__restrict__ off, int64_t n, int64_t x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (off[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// tile t owns the rows [tile_row[t], tile_row[t + 1]): one binary search per tile, all tiles at once (inside the tile
+// kernel the 20 dependent loads of a search cost more than the rest of the tile)
+__global__ __launch_bounds__(K7_BLOCK) void k7_tile_rows_kernel(const int32_t *__restrict__ row_off, int64_t n_rows, int64_t n_tiles,
+                                                                int64_t *__restrict__ tile_row) {
+    const int64_t t = (int64_t)blockIdx.x * K7_BLOCK + threadIdx.x;
+    if (t > n_tiles) return;
+    tile_row[t] = (t == n_tiles) ? n_rows : lower_bound_off(row_off, n_rows, t * K7B_WINDOW);
+}
+
+__global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__restrict__ box4,
+                                                               const int32_t *__restrict__ row_off,
+                                                               const uint8_t *__restrict__ sel,
+                                                               const double *__restrict__ width,
+                                                               const double *__restrict__ height,
+                                                               const int32_t *__restrict__ class_id, int64_t n_rows,
+                                                               int64_t n_tiles, const int64_t *__restrict__ tile_row,
+                                                               int64_t *__restrict__ text_off,
+                                                               uint8_t *__restrict__ flag_out, uint8_t *text,
+                                                               int64_t text_cap, unsigned long long *state) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_text[K7_LDS_TEXT + 32];
+    __shared__ uint32_t s_cnt[K7B_CAP + 1], s_pos[K7B_CAP + 1], s_ex[K7B_CAP + 1];   // exclusive scans over the boxes: lines / bytes / host lines
+    __shared__ uint32_t s_wave[K7B_PER][K7_WAVES];
+    __shared__ unsigned long long s_bcast[2];
+    __shared__ uint32_t s_bad;           // the tile holds a line only the host can print
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_bcast[0] = atomicAdd(&state[0], 1ull);   // ticket order, as in the row kernels
+    __syncthreads();
+    const int64_t tile = (int64_t)s_bcast[0];
+    unsigned long long *words = state + 2;
+    if (tile >= n_tiles) return;
+    if (tid == 0) s_bad = 0;
+    const int64_t r_lo = tile_row[tile], r_hi = tile_row[tile + 1];           // rows [r_lo, r_hi), possibly none
+    const int64_t b_lo = row_off[r_lo], nb = (int64_t)row_off[r_hi] - b_lo;
+    const int64_t nr = r_hi - r_lo;
+    const bool small = nb <= K7B_CAP;
+
+    // exclusive workgroup scan in box order j = k * K7_BLOCK + tid; out[j] for every j <= K7B_CAP, returns the total
+    auto block_scan = [&](const uint32_t (&x)[K7B_PER], uint32_t *out) -> uint32_t {
+        uint32_t incl[K7B_PER];
+        __syncthreads();   // s_wave may still be read by the scan before
+#pragma unroll
+        for (int k = 0; k < K7B_PER; ++k) {
+            incl[k] = x[k];
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const uint32_t up = __shfl_up(incl[k], d);
+                if (lane >= d) incl[k] += up;
+            }
+            if (lane == kWave - 1) s_wave[k][wave] = incl[k];
+        }
+        __syncthreads();
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < K7B_PER; ++k) {
+            uint32_t before = total;
+#pragma unroll
+            for (int w = 0; w < K7_WAVES; ++w) {
+                if (w < wave) before += s_wave[k][w];
+                total += s_wave[k][w];
+            }
+            out[k * K7_BLOCK + tid] = before + incl[k] - x[k];
+        }
+        if (tid == 0) out[K7B_CAP] = total;
+        __syncthreads();
+        return total;
+    };
+
+    uint32_t tile_bytes = 0;
+    // what a lane keeps of its boxes
+    RowIn in[K7B_PER];          // the row of the box (b0 / b1 relative to b_lo)
+    uint32_t q[K7B_PER][4], len[K7B_PER], line[K7B_PER];
+    bool plain[K7B_PER];
+    if (small) {
+        // the tile's row offsets, relative, in LDS (the text area is free until the printing) when they fit
+        uint32_t *s_off = reinterpret_cast<uint32_t *>(s_text);
+        const bool offs_in_lds = nr <= K7B_CAP;
+        if (offs_in_lds)
+            for (int64_t i = tid; i <= nr; i += K7_BLOCK) s_off[i] = (uint32_t)(row_off[r_lo + i] - b_lo);
+        __syncthreads();
+        uint32_t host_line[K7B_PER];
+#pragma unroll
+        for (int k = 0; k < K7B_PER; ++k) {
+            const int64_t j = (int64_t)k * K7_BLOCK + tid;
+            len[k] = line[k] = host_line[k] = 0;
+            plain[k] = false;
+            in[k].b0 = in[k].b1 = 0;
+            in[k].w = in[k].h = 1.0;
+            in[k].cid = 0;
+            in[k].host = true;
+            if (j < nb) {
+                int64_t lo = 0, hi = nr;   // the last row of the tile that starts at or before box j
+                if (offs_in_lds) {
+                    while (hi - lo > 1) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (s_off[mid] <= (uint32_t)j) lo = mid; else hi = mid;
+                    }
+                    in[k].b0 = (int32_t)s_off[lo];
+                    in[k].b1 = (int32_t)s_off[lo + 1];
+                } else {
+                    while (hi - lo > 1) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (row_off[r_lo + mid] - b_lo <= j) lo = mid; else hi = mid;
+                    }
+                    in[k].b0 = (int32_t)(row_off[r_lo + lo] - b_lo);
+                    in[k].b1 = (int32_t)(row_off[r_lo + lo + 1] - b_lo);
+                }
+                const int64_t row = r_lo + lo;
+                in[k].w = width[row];
+                in[k].h = height[row];
+                in[k].cid = class_id[row];
+                in[k].host = (in[k].w == 0.0) || (in[k].h == 0.0) || (in[k].cid < 0);
+                if (!in[k].host && (!sel || sel[b_lo + j])) {
+                    const double *b = box4 + 4 * (b_lo + j);
+                    if ((uint32_t)in[k].cid < 100u && plain_box(b, in[k].w, in[k].h, q[k])) {
+                        plain[k] = true;
+                        line[k] = 1;
+                        len[k] = plain_len(in[k], q[k]);
+                    } else {
+                        const Line l = box_line(b, in[k].w, in[k].h);
+                        if (l.valid) {
+                            line[k] = 1;
+                            if (l.exotic) host_line[k] = 1;
+                            else len[k] = (uint32_t)line_len(l, cid_digits((uint32_t)in[k].cid));
+                        }
+                    }
+                }
+            }
+            if (host_line[k]) atomicOr(&s_bad, 1u);
+        }
+        __syncthreads();
+        const bool bad = s_bad != 0;
+        if (bad) {   // rare: rows holding a host line give no text at all
+            block_scan(host_line, s_ex);
+#pragma unroll
+            for (int k = 0; k < K7B_PER; ++k)
+                if (s_ex[in[k].b1] > s_ex[in[k].b0]) len[k] = line[k] = 0;
+        }
+        block_scan(line, s_cnt);
+#pragma unroll
+        for (int k = 0; k < K7B_PER; ++k) {   // every line but the first of its row carries a "\n" in front
+            const int64_t j = (int64_t)k * K7_BLOCK + tid;
+            if (line[k] && s_cnt[j] > s_cnt[in[k].b0]) {
+                len[k] += 1;
+                line[k] = 2;
+            }
+        }
+        tile_bytes = block_scan(len, s_pos);
+    } else {
+        // ---- more boxes than the LDS arrays hold: a lane per row, 256 rows at a time; offsets relative to the tile -----
+        uint32_t carry = 0;
+        for (int64_t c = 0; c < nr; c += K7_BLOCK) {
+            const int64_t r = r_lo + c + tid;
+            RowState st;
+            st.len = 0;
+            st.flag = 1;
+            if (r < r_hi) {
+                RowIn ri;
+                ri.b0 = row_off[r];
+                ri.b1 = row_off[r + 1];
+                ri.w = width[r];
+                ri.h = height[r];
+                ri.cid = class_id[r];
+                ri.host = (ri.w == 0.0) || (ri.h == 0.0) || (ri.cid < 0);
+                row_measure(ri, box4, sel, st);
+            }
+            uint32_t incl = st.len;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            __syncthreads();
+            if (lane == kWave - 1) s_wave[0][wave] = incl;
+            __syncthreads();
+            uint32_t before = carry;
+#pragma unroll
+            for (int w = 0; w < K7_WAVES; ++w) {
+                if (w < wave) before += s_wave[0][w];
+                carry += s_wave[0][w];
+            }
+            if (r < r_hi) {
+                text_off[r] = (int64_t)(before + incl - st.len);   // the tile's base is added below
+                flag_out[r] = (uint8_t)st.flag;
+            }
+        }
+        tile_bytes = carry;
+    }
+
+    // ---- publish; print into LDS while the tiles before publish theirs; look back (wave 0) ---------------------------------
+    if (tid == 0)
+        __hip_atomic_store(&words[tile], (tile == 0 ? K7_FLAG_PFX : K7_FLAG_AGG) | (unsigned long long)tile_bytes, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    const bool staged = small && text && tile_bytes && tile_bytes <= (uint32_t)K7_LDS_TEXT;
+    auto print_box = [&](int k, int64_t j, unsigned char *where) {
+        auto put = [&](int p, char c) { where[p] = (unsigned char)c; };
+        int pos = 0;
+        if (line[k] == 2) put(pos++, '\n');
+        if (plain[k]) {
+            RowState st;
+            st.q[0] = q[k][0]; st.q[1] = q[k][1]; st.q[2] = q[k][2]; st.q[3] = q[k][3];
+            plain_print(in[k], st, [&](int p, char c) { where[pos + p] = (unsigned char)c; });
+        } else {
+            const Line l = box_line(box4 + 4 * (b_lo + j), in[k].w, in[k].h);   // converted again: the rare kind of line
+            line_put(l, (uint32_t)in[k].cid, cid_digits((uint32_t)in[k].cid), pos, put);
+        }
+    };
+    if (staged) {   // (the row offsets parked in s_text are not needed any more: every lane holds b0 / b1 of its boxes)
+#pragma unroll
+        for (int k = 0; k < K7B_PER; ++k) {
+            const int64_t j = (int64_t)k * K7_BLOCK + tid;
+            if (small && line[k]) print_box(k, j, s_text + s_pos[j]);
+        }
+    }
+    if (wave == 0) {
+        unsigned long long base = 0;
+        int64_t look = tile - 1;
+        bool failed = false;
+        while (look >= 0) {
+            const int64_t t = look - lane;
+            unsigned long long wv = K7_FLAG_PFX;
+            if (t >= 0) {
+                int spins = 0;
+                do {
+                    wv = __hip_atomic_load(&words[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((wv >> 62) == 0) {
+                        if (++spins > K7_SPIN_LIMIT) {
+                            failed = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                } while ((wv >> 62) == 0);
+            }
+            if (__any(failed)) {
+                failed = true;
+                break;
+            }
+            const unsigned long long has_pfx = __ballot((wv >> 62) == 2);
+            const int first = has_pfx ? __ffsll((long long)has_pfx) - 1 : kWave;   // nearest lane holding a prefix
+            unsigned long long part = (lane <= first) ? (wv & K7_VALUE) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            base += part;
+            if (has_pfx) break;
+            look -= kWave;
+        }
+        if (lane == 0) {
+            if (failed) {
+                atomicExch(&state[1], 1ull);
+                base = 0;
+            }
+            if (tile != 0)
+                __hip_atomic_store(&words[tile], K7_FLAG_PFX | ((base + tile_bytes) & K7_VALUE), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_bcast[1] = base;
+        }
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)s_bcast[1];
+    const bool fits = base + (int64_t)tile_bytes <= text_cap;
+    if (text && tile_bytes && !fits && tid == 0) atomicExch(&state[1], 2ull);   // the host reads the size needed in text_off[n_rows]
+
+    if (small) {
+        // ---- the rows' offsets and verdicts from the scans --------------------------------------------------------------
+        const bool bad = s_bad != 0;
+        for (int64_t r = r_lo + tid; r < r_hi; r += K7_BLOCK) {
+            const uint32_t a = (uint32_t)(row_off[r] - b_lo), b = (uint32_t)(row_off[r + 1] - b_lo);
+            const bool host = (width[r] == 0.0) || (height[r] == 0.0) || (class_id[r] < 0) || (bad && s_ex[b] > s_ex[a]);
+            text_off[r] = base + s_pos[a];
+            flag_out[r] = host ? 2 : ((s_cnt[b] > s_cnt[a]) ? 0 : 1);
+        }
+        if (tile == n_tiles - 1 && tid == 0) text_off[n_rows] = base + tile_bytes;
+        if (!text || tile_bytes == 0 || !fits) return;
+        unsigned char *dst = text + base;
+        if (staged) {   // LDS -> memory in 16-byte stores; the words are realigned to the destination's phase
+            const uint32_t phase = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+            const uint32_t end = phase + tile_bytes;
+            const uint32_t n_chunks = (end + 15u) >> 4;
+            unsigned char *aligned = dst - phase;
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s_text);
+            const uint32_t sh = (0u - phase) & 3u;
+            for (uint32_t c = tid; c < n_chunks; c += K7_BLOCK) {
+                const uint32_t lo = c << 4, hi = lo + 16u;
+                if (lo >= phase && hi <= end) {
+                    const uint32_t m = (lo - phase) >> 2;
+                    const uint32_t d0 = s32[m], d1 = s32[m + 1], d2 = s32[m + 2], d3 = s32[m + 3], d4 = s32[m + 4];
+                    uint4 v;
+                    v.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                    v.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    v.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                    v.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                    *reinterpret_cast<uint4 *>(aligned + lo) = v;
+                } else {
+                    const uint32_t a = lo < phase ? phase : lo, b = hi > end ? end : hi;
+                    for (uint32_t i = a; i < b; ++i) aligned[i] = s_text[i - phase];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K7B_PER; ++k) {
+                const int64_t j = (int64_t)k * K7_BLOCK + tid;
+                if (line[k]) print_box(k, j, dst + s_pos[j]);
+            }
+        }
+        return;
+    }
+    for (int64_t r = r_lo + tid; r < r_hi; r += K7_BLOCK) {   // each lane wrote these entries itself
+        const int64_t at = base + text_off[r];
+        text_off[r] = at;
+        if (text && fits && flag_out[r] == 0) {
+            RowIn ri;
+            ri.b0 = row_off[r];
+            ri.b1 = row_off[r + 1];
+            ri.w = width[r];
+            ri.h = height[r];
+            ri.cid = class_id[r];
+            ri.host = false;
+            unsigned char *mine = text + at;
+            row_print(ri, box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
+        }
+    }
+    if (tile == n_tiles - 1 && tid == 0) text_off[n_rows] = base + tile_bytes;
+}
+
+// dyd_set_option("k7_variant"): -1 = by the table's shape (default: 22 for one box per row, 30 from 1.25 boxes per row on),
+// 2 = one 512-row tile per ticket, 22 = two, pipelined, 30 = tiles of 448 boxes, a lane per box
+static int g_k7_variant = -1;
 static unsigned long long *g_k7_trace = nullptr;   // tuning hook (single-tile kernel): 8 timestamps per tile
 void set_k7_trace(void *p) { g_k7_trace = static_cast<unsigned long long *>(p); }
-void set_k7_variant(int v) { g_k7_variant = (v == 2) ? 2 : 22; }
+void set_k7_variant(int v) { g_k7_variant = (v == 2 || v == 22 || v == 30) ? v : -1; }
 
 static int yolo_launch(const double *box4, const int32_t *row_off, const uint8_t *sel, const double *width,
-                       const double *height, const int32_t *class_id, int64_t n_rows, int64_t *text_off,
-                       uint8_t *flag, uint8_t *text, int64_t text_cap, int64_t *total_out, hipStream_t st) {
-    const int64_t n_tiles = ceil_div(n_rows, (int64_t)K7_BLOCK * 2);
+                       const double *height, const int32_t *class_id, int64_t n_rows, int64_t n_boxes,
+                       int64_t *text_off, uint8_t *flag, uint8_t *text, int64_t text_cap, int64_t *total_out, hipStream_t st) {
+    // rows of several boxes go to the box-tiled kernel (a lane per box); it needs the box count, the last row offset
+    bool by_box = g_k7_variant == 30;
+    if (n_boxes < 0 && g_k7_variant != 2 && g_k7_variant != 22) {   // device-resident caller: fetch the last offset
+        int32_t last = 0;
+        DYD_HIP(hipMemcpyAsync(&last, row_off + n_rows, 4, hipMemcpyDeviceToHost, st));
+        DYD_HIP(hipStreamSynchronize(st));
+        n_boxes = last;
+    }
+    if (g_k7_variant != 2 && g_k7_variant != 22 && !by_box) by_box = n_boxes > n_rows + n_rows / 4;   // -1: by the table's shape
+    const int64_t n_tiles = by_box ? (n_boxes > 0 ? ceil_div(n_boxes, (int64_t)K7B_WINDOW) : 1) : ceil_div(n_rows, (int64_t)K7_BLOCK * 2);
     void *scr = nullptr;
     const size_t state_bytes = (size_t)(n_tiles + 2) * 8;
-    int rc = get_scratch(state_bytes, &scr, st);
+    int rc = get_scratch(state_bytes + (by_box ? (size_t)(n_tiles + 1) * 8 : 0), &scr, st);
     if (rc) return rc;
     DYD_HIP(hipMemsetAsync(scr, 0, state_bytes, st));
     unsigned long long *state = static_cast<unsigned long long *>(scr);
-    if (g_k7_variant == 22)
+    if (by_box) {   // (the first tile's search for box 0 gives row 0: leading empty rows are its own)
+        int64_t *tile_row = reinterpret_cast<int64_t *>(state + n_tiles + 2);
+        hipLaunchKernelGGL(k7_tile_rows_kernel, dim3((unsigned)ceil_div(n_tiles + 1, (int64_t)K7_BLOCK)), dim3(K7_BLOCK), 0, st, row_off,
+                           n_rows, n_tiles, tile_row);
+        hipLaunchKernelGGL(k7_yolo_box_kernel, dim3((unsigned)n_tiles), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
+                           class_id, n_rows, n_tiles, tile_row, text_off, flag, text, text_cap, state);
+    }
+    else if (g_k7_variant != 2)
         hipLaunchKernelGGL((k7_yolo_pair_kernel<2>), dim3((unsigned)ceil_div(n_tiles, 2)), dim3(K7_BLOCK), 0, st, box4, row_off, sel,
                            width, height, class_id, n_rows, text_off, flag, text, text_cap, state);
     else
@@ -893,7 +1263,7 @@ int dyd_yolo_lines_dev(const double *box4, const int32_t *row_off, const uint8_t
     }
     DYD_REQUIRE(row_off && width && height && class_id && out_flag, "null pointer");
     DYD_REQUIRE(n_rows < (1LL << 40), "n_rows too large");
-    return yolo_launch(box4, row_off, sel_or_null, width, height, class_id, n_rows, out_text_off, out_flag,
+    return yolo_launch(box4, row_off, sel_or_null, width, height, class_id, n_rows, -1, out_text_off, out_flag,
                        out_text_or_null, text_cap, out_total, st);
 }
 
@@ -930,7 +1300,7 @@ int dyd_yolo_lines(const double *box4, const int32_t *row_off, const uint8_t *se
     // first launch measures (no text buffer), second prints into a buffer of exactly that size
     int64_t total = 0;
     rc = yolo_launch(d_box.as<double>(), d_off.as<int32_t>(), sel, d_w.as<double>(), d_h.as<double>(),
-                     d_cid.as<int32_t>(), n_rows, d_toff.as<int64_t>(), d_flag.as<uint8_t>(), nullptr, 0, &total, st);
+                     d_cid.as<int32_t>(), n_rows, n_boxes, d_toff.as<int64_t>(), d_flag.as<uint8_t>(), nullptr, 0, &total, st);
     if (rc) return rc;
     uint8_t *host_text = static_cast<uint8_t *>(malloc((size_t)(total > 0 ? total : 1)));
     if (!host_text) {
@@ -944,7 +1314,7 @@ int dyd_yolo_lines(const double *box4, const int32_t *row_off, const uint8_t *se
         }
         KernelTimer t(st);
         rc = yolo_launch(d_box.as<double>(), d_off.as<int32_t>(), sel, d_w.as<double>(), d_h.as<double>(),
-                         d_cid.as<int32_t>(), n_rows, d_toff.as<int64_t>(), d_flag.as<uint8_t>(),
+                         d_cid.as<int32_t>(), n_rows, n_boxes, d_toff.as<int64_t>(), d_flag.as<uint8_t>(),
                          d_text.as<uint8_t>(), total, &total, st);
         if (rc) {
             free(host_text);

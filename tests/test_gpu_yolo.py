@@ -65,12 +65,13 @@ def _random_case(rng, n_rows, max_boxes, with_sel, special=True):
     return box, row_off, sel, w, h, cid
 
 
-@pytest.fixture(params=[22, 2], ids=["paired", "single"])
+@pytest.fixture(params=[-1, 22, 2, 30], ids=["auto", "paired", "single", "by_box"])
 def k7_variant(request, native):
-    """22 = two tiles per ticket, software-pipelined (default); 2 = one tile per ticket"""
+    """22 = two 512-row tiles per ticket, software-pipelined; 2 = one tile per ticket; 30 = tiles of 448 boxes, a lane per
+    box; -1 (default) = 22 for tables of one box per row, 30 from 1.25 boxes per row on"""
     native.check(native.lib().dyd_set_option(b"k7_variant", request.param), "opt")
     yield request.param
-    native.check(native.lib().dyd_set_option(b"k7_variant", 22), "opt")
+    native.check(native.lib().dyd_set_option(b"k7_variant", -1), "opt")
 
 
 @pytest.mark.parametrize("n_rows,max_boxes,with_sel", [(1, 1, False), (255, 3, True), (256, 1, False), (257, 2, True), (512, 1, False),
@@ -170,6 +171,52 @@ def test_k7_long_rows_bypass_lds(native, k7_variant):
     c = np.round(rng.random((nb, 2)) * 1000, 1)
     box = np.concatenate([c, c + np.round(rng.random((nb, 2)) * 90 + 1, 1)], axis=1)
     _check_against_oracle(native, box, row_off, None, np.full(n_rows, 1920.0), np.full(n_rows, 1080.0), np.arange(n_rows, dtype=np.int32))
+
+
+def _boxes(rng, nb, scale=1000.0):
+    c = np.round(rng.random((nb, 2)) * scale, 1)
+    return np.concatenate([c, c + np.round(rng.random((nb, 2)) * scale * 0.09 + 1, 1)], axis=1)
+
+
+@pytest.mark.parametrize("shape", ["window_multiple", "empty_runs", "row_over_windows", "text_over_lds", "host_lines", "one_row",
+                                   "rows_over_cap"])
+def test_k7_box_tiles(native, k7_variant, shape):
+    """shapes that sit on the edges of the box-tiled kernel: tiles that end exactly on a window, runs of empty rows (more rows
+    than the LDS offset table holds), a row that covers several windows, text beyond the LDS staging area, host lines in the
+    middle of a row, everything in one row"""
+    rng = np.random.default_rng(len(shape))
+    if shape == "window_multiple":
+        counts = np.full(448 * 3 // 4, 4)
+    elif shape == "empty_runs":
+        counts = np.zeros(9000, np.int64)
+        counts[[0, 700, 701, 5000, 8999]] = [3, 500, 1, 460, 2]
+    elif shape == "row_over_windows":
+        counts = np.array([5, 0, 448 * 3 + 17, 0, 0, 2, 448, 1, 447, 1])
+    elif shape == "text_over_lds":
+        counts = rng.integers(1, 9, 400)
+    elif shape == "host_lines":
+        counts = rng.integers(0, 12, 1500)
+    elif shape == "one_row":
+        counts = np.array([2000])
+    else:
+        counts = np.where(np.arange(4000) % 9 == 0, 1, 0)        # 448 boxes spread over 4000 rows per tile
+    n_rows = len(counts)
+    row_off = np.zeros(n_rows + 1, np.int32)
+    np.cumsum(counts, out=row_off[1:])
+    nb = int(row_off[-1])
+    box = _boxes(rng, nb, 1e12 if shape == "text_over_lds" else 1000.0)
+    w, h = np.full(n_rows, 1920.0), np.full(n_rows, 1080.0)
+    if shape == "text_over_lds":
+        w[:], h[:] = 1.0, -1.0
+    if shape == "host_lines":
+        k = rng.integers(0, nb, nb // 40)
+        box[k, 2] = 1e18                                            # value >= 2^43: the whole row is the host's
+        w[rng.integers(0, n_rows, 20)] = 0.0
+    cid = rng.choice([0, 5, 17, 99, 100, 4321], n_rows).astype(np.int32)
+    sel = (rng.random(nb) < 0.8).astype(np.uint8) if shape in ("host_lines", "empty_runs") else None
+    flag = _check_against_oracle(native, box, row_off, sel, w, h, cid)
+    if shape == "host_lines":
+        assert (flag == 2).sum() > 20 and (flag == 0).sum() > 100
 
 
 def test_k7_golden_cases_through_the_step(native):

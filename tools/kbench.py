@@ -200,7 +200,7 @@ def main():
         text = torch.empty(T, dtype=torch.uint8, device=dev)
         import os
         modes = os.environ.get("K7MODE", "full,measure").split(",")
-        for variant in [int(v) for v in os.environ.get("K7V", "2,22").split(",")]:
+        for variant in [int(v) for v in os.environ.get("K7V", "2,22,30,-1").split(",")]:
             ck(L.dyd_set_option(b"k7_variant", variant), "opt")
             if "full" in modes:
               med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
@@ -214,8 +214,22 @@ def main():
                                                               cid.data_ptr(), E, toff.data_ptr(), flag.data_ptr(), None, 0,
                                                               C.byref(total), sp), "k7"))
             report(f"k7_measure_only_rpt{variant}", 32 * E + 4 * (E + 1) + 20 * E + 8 * (E + 1) + E, med, mn, rows=E)
-        ck(L.dyd_set_option(b"k7_variant", 22), "opt")
-
+        # rows of many boxes (unsplit sheets: 1..32 lines per row): the generic path of the kernel
+        wr = torch.full((N,), 1920.0, dtype=torch.float64, device=dev); hr = torch.full((N,), 1080.0, dtype=torch.float64, device=dev)
+        cidr = (torch.arange(N, device=dev, dtype=torch.int32) % 20).contiguous()
+        toffr = torch.empty(N + 1, dtype=torch.int64, device=dev); flagr = torch.empty(N, dtype=torch.uint8, device=dev)
+        ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), box_off.data_ptr(), None, wr.data_ptr(), hr.data_ptr(), cidr.data_ptr(), N,
+                                toffr.data_ptr(), flagr.data_ptr(), None, 0, C.byref(total), sp), "k7 measure")
+        Tr = total.value
+        textr = torch.empty(Tr, dtype=torch.uint8, device=dev)
+        for variant in [int(v) for v in os.environ.get("K7VM", "30,-1").split(",")]:   # 22: 330 ms per launch
+            ck(L.dyd_set_option(b"k7_variant", variant), "opt")
+            med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), box_off.data_ptr(), None, wr.data_ptr(), hr.data_ptr(),
+                                                              cidr.data_ptr(), N, toffr.data_ptr(), flagr.data_ptr(), textr.data_ptr(), Tr,
+                                                              C.byref(total), sp), "k7"))
+            report(f"k7_yolo_lines_multi_box_rows_v{variant}", 32 * B + 4 * (N + 1) + 20 * N + 8 * (N + 1) + N + Tr, med, mn, rows=N, lines=B,
+                   text_bytes=Tr, lines_per_s=round(B / med * 1e3))
+        ck(L.dyd_set_option(b"k7_variant", -1), "opt")
 
 if __name__ == "__main__":
     main()
