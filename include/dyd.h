@@ -283,7 +283,8 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
 void dyd_host_free(void *p);
 
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
- * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging. */
+ * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging; "k7_variant": -1 by the table's shape (default),
+ * 2 / 22 row tiles (one / two per ticket), 30 box tiles (rows of many boxes). */
 int dyd_set_option(const char *key, int64_t value);
 /* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 16 B per
  * lane) used to record the box's HBM ceiling next to the kernels' achieved GB/s. */
