@@ -132,14 +132,14 @@ def main():
                                                                       N, B, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
                                                                       out_high.data_ptr(), sp), "k12"))
                 res.setdefault(variant, []).append((med, mn))
-        b2b = {}
-        for variant in (4, 8, 7):
+        b2b = []
+        names = {4: "4 waves/wg (default)", 8: "2 waves/wg", 7: "1 wave/wg"}
+        for variant in (4, 8, 7, 4):   # interleaved, in one process: box-to-box variance is larger than the differences
             ck(L.dyd_set_option(b"fused_variant", variant), "opt")
-            b2b[variant] = timeit_b2b(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2,
-                                                                          0.98, out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(),
-                                                                          sp), "k12"))
-        print(json.dumps({"k12_wave_back_to_back_ms": {"4 waves/wg (default)": round(b2b[4], 4), "2 waves/wg": round(b2b[8], 4),
-                                                        "1 wave/wg": round(b2b[7], 4)}}), flush=True)
+            ms = timeit_b2b(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98,
+                                                                out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"))
+            b2b.append([names[variant], round(ms, 4)])
+        print(json.dumps({"k12_wave_back_to_back_ms": b2b}), flush=True)
         ck(L.dyd_set_option(b"fused_variant", -1), "opt")
         for variant, name in ((0, "k12_fused<2048,16,256>"), (2, "k12_fused<1024,8,128>"), (3, "k12_fused<1024,16,256>"),
                               (4, "k12_wave_kernel"), (8, "k12_wave_kernel, 2 waves per workgroup"), (7, "k12_wave_kernel, 1 wave per workgroup"), (5, "k12_fused<2048,16,256,filter>"), (6, "k12_fused<1024,8,128,filter>"),
