@@ -25,6 +25,7 @@ from __future__ import annotations
 import io
 import json
 import os
+import re
 from pathlib import Path
 from typing import Optional
 
@@ -1267,3 +1268,299 @@ def generate_yolo_datasets_from_excels(
         progress_callback(processed_rows, *last[1:])
     return {"datasets": datasets, "skipped": skipped_path, "stats": dataset_stats, "total": total_rows,
             "processed": processed_rows, "downloaded": downloaded_images, "dataset_name_map": dataset_name_map}
+
+
+# =============================================================================== label_replace (pipeline step between a4 and a5)
+def mapping_to_label_map(mapping_df: pd.DataFrame, old_col: Optional[str] = None, new_col: Optional[str] = None) -> dict:
+    """old label -> new label from the mapping sheet (reference processor.py:532-545): the first two columns unless
+    named; a pair with a blank or a "nan" spelling on either side is dropped; later rows overwrite earlier ones."""
+    if not old_col or not new_col:
+        cols = list(mapping_df.columns)
+        if len(cols) < 2:
+            raise ValueError("标签对照表至少需要两列")
+        old_col, new_col = old_col or cols[0], new_col or cols[1]
+
+    names = list(mapping_df.columns)
+    values = mapping_df.values            # what iterrows walks: one common dtype for the row (ints next to floats print as floats)
+
+    def texts(col):   # str(row.get(col, "")).strip() for every row
+        if col not in names:
+            return [""] * len(mapping_df)
+        return [str(v).strip() for v in values[:, names.index(col)]]
+
+    def usable(t):
+        return bool(t) and t.lower() != "nan"
+
+    return {o: n for o, n in zip(texts(old_col), texts(new_col)) if usable(o) and usable(n)}
+
+
+def _relabel_name(raw_name, label_map):
+    """reference utils.py:664-679: (new name, labels replaced, labels seen); the new name is the SET of the
+    replaced labels, sorted, joined with ',' — also when nothing was replaced"""
+    if not raw_name:
+        return raw_name, 0, 0
+    tokens = _split_object_labels(raw_name)
+    hits = sum(1 for t in tokens if t in label_map)
+    return ",".join(sorted({label_map.get(t, t) for t in tokens})), hits, len(tokens)
+
+
+class _RelabelTotals:
+    __slots__ = ("total_objects", "total_labels", "replaced_labels", "replaced_objects", "invalid_json_rows",
+                 "missing_name_objects", "unmatched")
+
+    def __init__(self):
+        self.total_objects = self.total_labels = self.replaced_labels = self.replaced_objects = 0
+        self.invalid_json_rows = self.missing_name_objects = 0
+        self.unmatched = {}            # label -> occurrences, in first-seen order (the unmatched sheet keeps it among ties)
+
+
+def _relabel_cell(cell: str, label_map: dict, tot: _RelabelTotals):
+    """One annotation cell (reference processor.py:572-609) -> (rewritten text or None when the cell stays as it is,
+    [(old name, new name)] of the objects whose name would change, any object renamed?).  Every cell whose document
+    has a list under "objects" is re-serialised (``json.dumps(..., ensure_ascii=False)``), renamed or not; a document
+    that is not an object, or a name that is neither text nor empty, ends the step with the reference's exception."""
+    try:
+        doc = json.loads(cell)
+    except json.JSONDecodeError:
+        tot.invalid_json_rows += 1
+        return None, (), False
+    objects = doc.get("objects")
+    if not isinstance(objects, list):
+        return None, (), False
+    changes, renamed = [], False
+    unmatched = tot.unmatched
+    for obj in objects:
+        if not isinstance(obj, dict):
+            continue
+        tot.total_objects += 1
+        raw = obj.get("name")
+        if raw is None:
+            tot.missing_name_objects += 1
+            continue
+        for lbl in _split_object_labels(raw):
+            if lbl not in label_map:
+                unmatched[lbl] = unmatched.get(lbl, 0) + 1
+        new_name, hits, seen = _relabel_name(raw, label_map)
+        tot.total_labels += seen
+        if hits:
+            obj["name"] = new_name
+            tot.replaced_labels += hits
+            tot.replaced_objects += 1
+            renamed = True
+        if raw != new_name:
+            changes.append((raw, new_name))
+    return json.dumps(doc, ensure_ascii=False), changes, renamed
+
+
+def replace_labels_frame(df: pd.DataFrame, label_map: dict, json_columns: Optional[list] = None):
+    """DataFrame twin of replace_labels_by_mapping: (frame with the rewritten cells, summary counters, diff rows,
+    unmatched label counts).  Rows are visited in order, and within a row the columns in ``json_columns`` order —
+    the order of the diff rows and of first-seen unmatched labels."""
+    if json_columns is None:
+        json_columns = [c for c in (BBOX_COL, ANNOTATION_COL) if c in df.columns]
+    present = [c for c in json_columns if c in df.columns]
+    tot = _RelabelTotals()
+    columns = {c: df[c].tolist() for c in present}
+    sources = df["source"].tolist() if "source" in df.columns else None
+    diff_rows, replaced_rows = [], 0
+    for i in range(len(df)):
+        row_renamed = False
+        for c in present:
+            cell = columns[c][i]
+            if not isinstance(cell, str) or not cell:          # NaN, numbers, ""
+                continue
+            text, changes, renamed = _relabel_cell(cell, label_map, tot)
+            if text is None:
+                continue
+            columns[c][i] = text
+            row_renamed |= renamed
+            if changes:
+                diff_rows.append({"source": sources[i] if sources is not None else None, "column": c,
+                                  "before": "；".join([a for a, _ in changes]), "after": "；".join([b for _, b in changes])})
+        replaced_rows += row_renamed
+    out = df.copy()
+    for c in present:
+        if out[c].dtype != object:
+            continue                                           # a numeric column holds no cell to rewrite
+        out[c] = pd.Series(columns[c], index=out.index, dtype=object)
+    counters = {"replaced_rows": int(replaced_rows), "total_objects": tot.total_objects, "replaced_objects": tot.replaced_objects,
+                "total_labels": tot.total_labels, "replaced_labels": tot.replaced_labels,
+                "invalid_json_rows": tot.invalid_json_rows, "missing_name_objects": tot.missing_name_objects}
+    return out, counters, diff_rows, tot.unmatched
+
+
+def replace_labels_by_mapping(
+        input_csv_path: str,
+        mapping_excel_path: str,
+        output_csv_path: str,
+        sheet_name: Optional[str] = None,
+        old_col: Optional[str] = None,
+        new_col: Optional[str] = None,
+        json_columns: Optional[list] = None,
+        diff_excel_path: Optional[str] = None,
+        unmatched_excel_path: Optional[str] = None,
+        sample_size: int = 30,
+):
+    """Drop-in for reference processor.py:516-652 (pipeline step ``label_replace``, between the IoU filter and the
+    split): object names rewritten through the mapping sheet, every parsed cell re-serialised, a diff sheet and an
+    unmatched-label sheet on request.  Host-only step: there is no arithmetic for the device in it."""
+    df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    mapping_df = pd.read_excel(mapping_excel_path, sheet_name=sheet_name) if sheet_name else pd.read_excel(mapping_excel_path)
+    label_map = mapping_to_label_map(mapping_df, old_col, new_col)
+    out, counters, diff_rows, unmatched = replace_labels_frame(df, label_map, json_columns)
+
+    output_csv_path = Path(output_csv_path)
+    output_csv_path.parent.mkdir(parents=True, exist_ok=True)
+    out.to_csv(output_csv_path, index=False, encoding="utf-8-sig")
+
+    diff_path = None
+    if diff_excel_path:
+        diff_path = Path(diff_excel_path)
+        diff_path.parent.mkdir(parents=True, exist_ok=True)
+        pd.DataFrame(diff_rows).to_excel(diff_path, index=False)
+    unmatched_path = None
+    if unmatched_excel_path:
+        unmatched_path = Path(unmatched_excel_path)
+        unmatched_path.parent.mkdir(parents=True, exist_ok=True)
+        if unmatched:
+            sheet = pd.DataFrame([{"标签": k, "数量": v} for k, v in unmatched.items()]).sort_values("数量", ascending=False)
+        else:
+            sheet = pd.DataFrame(columns=["标签", "数量"])
+        sheet.to_excel(unmatched_path, index=False)
+
+    summary = {"total_rows": len(df), "replaced_rows": counters["replaced_rows"], "total_objects": counters["total_objects"],
+               "replaced_objects": counters["replaced_objects"], "total_labels": counters["total_labels"],
+               "replaced_labels": counters["replaced_labels"], "invalid_json_rows": counters["invalid_json_rows"],
+               "missing_name_objects": counters["missing_name_objects"], "mapping_size": len(label_map),
+               "unmatched_labels": len(unmatched)}
+    return {"output_csv": output_csv_path, "summary": summary, "diff": diff_path, "unmatched": unmatched_path,
+            "sample_diff": diff_rows[:sample_size]}
+
+
+def overwrite_reference_with_result(result_csv: str, ref_csv: str):
+    """Drop-in for reference processor.py:221-227: the filtered result becomes the next run's reference table."""
+    import shutil
+
+    if not os.path.exists(result_csv):
+        raise FileNotFoundError(f"结果文件不存在：{result_csv}")
+    shutil.copy2(result_csv, ref_csv)
+
+
+# =============================================================================== summaries either side of a5 / f4
+_UNDEFINED_LABEL_REASON = re.compile(r"^标签(.+?)(未在规则中定义)$")          # reference processor.py:860
+
+
+def unclassified_summary_frames(df: pd.DataFrame) -> dict:
+    """The three sheets of unclassified_summary.xlsx (reference processor.py:852-885): rows per reason (NaN counted as
+    未知原因), rows per label, rows per (label, reason).  The labels of a row come from its 无法分类标签 cell, else from a
+    reason of the form 标签<label>未在规则中定义, else the row counts under 无标签.  Ties keep pandas' own order."""
+    reason_col, label_col = "无法分类原因", "无法分类标签"
+    n = len(df)
+    reasons = df[reason_col].tolist() if reason_col in df.columns else ["未知原因"] * n
+    reason_series = df[reason_col] if reason_col in df.columns else pd.Series(reasons, index=df.index, name=reason_col)
+    reason_counts = reason_series.fillna("未知原因").value_counts().reset_index()
+    reason_counts.columns = ["原因", "数量"]
+    label_cells = df[label_col].tolist() if label_col in df.columns else [None] * n
+
+    by_label, by_pair = {}, {}
+
+    def count(label, reason):
+        by_label[label] = by_label.get(label, 0) + 1
+        by_pair[(label, reason)] = by_pair.get((label, reason), 0) + 1
+
+    for reason, cell in zip(reasons, label_cells):
+        labels = _split_object_labels(cell)
+        if not labels:
+            m = _UNDEFINED_LABEL_REASON.match(str(reason))
+            labels = [m.group(1)] if m else ["无标签"]
+        for label in labels:
+            count(label, reason)
+    label_summary = pd.DataFrame([{"标签": k, "数量": v} for k, v in by_label.items()]).sort_values("数量", ascending=False)
+    pair_summary = pd.DataFrame([{"标签": k[0], "原因": k[1], "数量": v} for k, v in by_pair.items()]).sort_values("数量", ascending=False)
+    return {"reason_summary": reason_counts, "label_summary": label_summary, "reason_label": pair_summary}
+
+
+def summarize_unclassified(unclassified_excel_path: str, output_dir: str, json_columns: Optional[list] = None):
+    """Drop-in for reference processor.py:833-891 (``json_columns`` is accepted and, as there, never used)."""
+    if not os.path.exists(unclassified_excel_path):
+        raise FileNotFoundError(f"无法分类文件不存在：{unclassified_excel_path}")
+    df = pd.read_excel(unclassified_excel_path)
+    output_dir = Path(output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    sheets = unclassified_summary_frames(df)
+    out_path = output_dir / "unclassified_summary.xlsx"
+    with pd.ExcelWriter(out_path) as writer:
+        for name in ("reason_summary", "label_summary", "reason_label"):
+            sheets[name].to_excel(writer, sheet_name=name, index=False)
+    return out_path
+
+
+def _label_file_counts(text: str, names) -> dict:
+    """label -> boxes for one label file (reference processor.py:1123-1133): the first field of a line is the class id
+    (``int(float(...))``; a line whose id does not parse, or whose lookup fails, is skipped); ids the names list does
+    not reach are shown as the number itself.  Negative ids index the list from its end, as there."""
+    boxes = {}
+    for line in text.splitlines():
+        fields = line.strip().split()
+        if not fields:
+            continue
+        try:
+            cid = int(float(fields[0]))
+            name = names[cid] if cid < len(names) else str(cid)
+            boxes[name] = boxes.get(name, 0) + 1
+        except Exception:  # noqa: BLE001
+            continue
+    return boxes
+
+
+def summarize_yolo_label_counts(dataset_dirs):
+    """Drop-in for reference processor.py:1089-1162: for every dataset directory and split, images and boxes per label
+    read back from labels/<split>/*.txt (what K7 wrote), with data.yaml's names -> (stats dict, flat DataFrame)."""
+    import yaml
+
+    def pct(part, whole):
+        return f"{(part / whole * 100):.1f}%" if whole else "0.0%"
+
+    def add(into, counts):
+        for k, v in counts.items():
+            into[k] = into.get(k, 0) + v
+
+    stats, rows = {}, []
+    for entry in dataset_dirs or []:
+        if not entry:
+            continue
+        root = Path(entry)
+        if not root.exists():
+            continue
+        names = []
+        yaml_path = root / "data.yaml"
+        if yaml_path.exists():
+            try:
+                names = yaml.safe_load(yaml_path.read_text(encoding="utf-8")).get("names") or []
+            except Exception:  # noqa: BLE001
+                pass
+        splits, all_images, all_img, all_box = {}, 0, {}, {}
+        for split in ("train", "val", "test"):
+            img_counts, box_counts, images = {}, {}, 0
+            folder = root / "labels" / split
+            if folder.exists():
+                for path in folder.glob("*.txt"):
+                    images += 1
+                    try:
+                        text = path.read_text(encoding="utf-8", errors="ignore")
+                    except Exception:  # noqa: BLE001
+                        continue
+                    in_file = _label_file_counts(text, names)
+                    add(box_counts, in_file)
+                    add(img_counts, dict.fromkeys(in_file, 1))
+            splits[split] = {"total_images": images, "label_counts": img_counts, "box_counts": box_counts}
+            all_images += images
+            add(all_img, img_counts)
+            add(all_box, box_counts)
+            rows += [{"数据集": root.name, "split": split, "标签": k, "图片数量": img_counts.get(k, 0), "标注框数量": box_counts.get(k, 0),
+                      "占比%": pct(img_counts.get(k, 0), images), "split总图片数": images} for k in set(img_counts) | set(box_counts)]
+        splits["all"] = {"total_images": all_images, "label_counts": all_img, "box_counts": all_box}
+        stats[root.name] = splits
+        rows += [{"数据集": root.name, "split": "all", "标签": k, "图片数量": all_img.get(k, 0), "标注框数量": all_box.get(k, 0),
+                  "占比%": pct(all_img.get(k, 0), all_images), "split总图片数": all_images} for k in set(all_img) | set(all_box)]
+    return stats, pd.DataFrame(rows)

@@ -460,3 +460,208 @@ def merge_folder(folder_path, output_file="merged_csv.csv", encoding="utf-8-sig"
     print(f"\n合并完成！共 {total} 行数据")
     print(f"输出文件：{os.path.abspath(output_file)}")
     return total
+
+
+# --------------------------------------------------------------------------- label_replace :516-652 (between a4 and a5)
+def mapping_to_label_map(mapping_df: pd.DataFrame, old_col=None, new_col=None) -> dict:
+    """:532-545  first two columns unless named; blanks and "nan" spellings on either side drop the pair"""
+    if not old_col or not new_col:
+        cols = list(mapping_df.columns)
+        if len(cols) < 2:
+            raise ValueError("标签对照表至少需要两列")
+        old_col = old_col or cols[0]
+        new_col = new_col or cols[1]
+    out = {}
+    for _, row in mapping_df.iterrows():
+        old = str(row.get(old_col, "")).strip()
+        new = str(row.get(new_col, "")).strip()
+        if old and old.lower() != "nan" and new and new.lower() != "nan":
+            out[old] = new
+    return out
+
+
+def replace_label_tokens(raw_name, label_map):
+    """utils.py:664-679  tokens replaced one by one, then de-duplicated, sorted and joined with ','"""
+    if not raw_name:
+        return raw_name, 0, 0
+    tokens = split_object_labels(raw_name)
+    swapped, hits = [], 0
+    for t in tokens:
+        if t in label_map:
+            swapped.append(label_map[t])
+            hits += 1
+        else:
+            swapped.append(t)
+    return ",".join(sorted(set(swapped))), hits, len(tokens)
+
+
+def label_replace_frame(df: pd.DataFrame, label_map: dict, json_columns=None):
+    """:547-609  -> (frame with rewritten cells, counters, diff rows, unmatched label counts)"""
+    df = df.copy()
+    if json_columns is None:
+        json_columns = [c for c in (NEW_COL, ANN_COL) if c in df.columns]
+    n = {"total_objects": 0, "total_labels": 0, "replaced_labels": 0, "replaced_objects": 0, "replaced_rows": 0,
+         "invalid_json_rows": 0, "missing_name_objects": 0}
+    unmatched, diff_rows = {}, []
+    for idx, row in df.iterrows():
+        touched = False
+        for col in json_columns:
+            if col not in df.columns:
+                continue
+            cell = row.get(col)
+            if pd.isna(cell) or not isinstance(cell, str) or not cell:
+                continue
+            try:
+                doc = json.loads(cell)
+            except json.JSONDecodeError:
+                n["invalid_json_rows"] += 1
+                continue
+            objs = doc.get("objects")
+            if not isinstance(objs, list):
+                continue
+            changes = []
+            for obj in objs:
+                if not isinstance(obj, dict):
+                    continue
+                n["total_objects"] += 1
+                raw = obj.get("name")
+                if raw is None:
+                    n["missing_name_objects"] += 1
+                    continue
+                for lbl in split_object_labels(raw):
+                    if lbl not in label_map:
+                        unmatched[lbl] = unmatched.get(lbl, 0) + 1
+                new_name, hits, count = replace_label_tokens(raw, label_map)
+                n["total_labels"] += count
+                if hits > 0:
+                    obj["name"] = new_name
+                    n["replaced_labels"] += hits
+                    n["replaced_objects"] += 1
+                    touched = True
+                if raw != new_name:
+                    changes.append((raw, new_name))
+            doc["objects"] = objs
+            df.at[idx, col] = json.dumps(doc, ensure_ascii=False)
+            if changes:
+                diff_rows.append({"source": row.get("source"), "column": col, "before": "；".join([c[0] for c in changes]),
+                                  "after": "；".join([c[1] for c in changes])})
+        if touched:
+            n["replaced_rows"] += 1
+    return df, n, diff_rows, unmatched
+
+
+def label_replace_csv(input_csv_path, mapping_df, output_csv_path, old_col=None, new_col=None, json_columns=None,
+                      diff_excel_path=None, unmatched_excel_path=None, sample_size=30):
+    """:516-652 with the mapping sheet handed over as a frame (the Excel layer is pandas' own)"""
+    df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    label_map = mapping_to_label_map(mapping_df, old_col, new_col)
+    out, n, diff_rows, unmatched = label_replace_frame(df, label_map, json_columns)
+    output_csv_path = Path(output_csv_path)
+    output_csv_path.parent.mkdir(parents=True, exist_ok=True)
+    out.to_csv(output_csv_path, index=False, encoding="utf-8-sig")
+    sheets = {}
+    if diff_excel_path:
+        sheets["diff"] = pd.DataFrame(diff_rows)
+    if unmatched_excel_path:
+        sheets["unmatched"] = (pd.DataFrame([{"标签": k, "数量": v} for k, v in unmatched.items()]).sort_values("数量", ascending=False)
+                               if unmatched else pd.DataFrame(columns=["标签", "数量"]))
+    summary = {"total_rows": len(df), "replaced_rows": n["replaced_rows"], "total_objects": n["total_objects"],
+               "replaced_objects": n["replaced_objects"], "total_labels": n["total_labels"], "replaced_labels": n["replaced_labels"],
+               "invalid_json_rows": n["invalid_json_rows"], "missing_name_objects": n["missing_name_objects"],
+               "mapping_size": len(label_map), "unmatched_labels": len(unmatched)}
+    return {"output_csv": output_csv_path, "summary": summary, "sheets": sheets, "sample_diff": diff_rows[:sample_size]}
+
+
+# --------------------------------------------------------------------------- summaries :833-891, :1089-1162
+_UNDEFINED_LABEL = re.compile(r"^标签(.+?)(未在规则中定义)$")      # :860
+
+
+def unclassified_sheets(df: pd.DataFrame) -> dict:
+    """:852-885  the three sheets of unclassified_summary.xlsx"""
+    df = df.copy()
+    reason_col = "无法分类原因"
+    if reason_col not in df.columns:
+        df[reason_col] = "未知原因"
+    reasons = df[reason_col].fillna("未知原因").value_counts().reset_index()
+    reasons.columns = ["原因", "数量"]
+    per_label, per_pair = {}, {}
+    for _, row in df.iterrows():
+        reason = row.get(reason_col, "未知原因")
+        labels = split_object_labels(row.get("无法分类标签")) if "无法分类标签" in df.columns else []
+        if not labels:
+            m = _UNDEFINED_LABEL.match(str(reason))
+            if m:
+                labels = [m.group(1)]
+            else:
+                per_label["无标签"] = per_label.get("无标签", 0) + 1
+                per_pair[("无标签", reason)] = per_pair.get(("无标签", reason), 0) + 1
+                continue
+        for lbl in labels:
+            per_label[lbl] = per_label.get(lbl, 0) + 1
+            per_pair[(lbl, reason)] = per_pair.get((lbl, reason), 0) + 1
+    label_summary = pd.DataFrame([{"标签": k, "数量": v} for k, v in per_label.items()]).sort_values("数量", ascending=False)
+    pair_summary = pd.DataFrame([{"标签": k[0], "原因": k[1], "数量": v} for k, v in per_pair.items()]).sort_values("数量", ascending=False)
+    return {"reason_summary": reasons, "label_summary": label_summary, "reason_label": pair_summary}
+
+
+def yolo_label_counts(dataset_dirs):
+    """:1089-1162  per dataset and split: images per label, boxes per label -> (stats, flat frame)"""
+    import yaml
+
+    stats, flat = {}, []
+
+    def share(part, whole):
+        return f"{(part / whole * 100):.1f}%" if whole else "0.0%"
+
+    for d in dataset_dirs or []:
+        if not d:
+            continue
+        root = Path(d)
+        if not root.exists():
+            continue
+        names = []
+        if (root / "data.yaml").exists():
+            try:
+                names = yaml.safe_load((root / "data.yaml").read_text(encoding="utf-8")).get("names") or []
+            except Exception:
+                pass
+        per_split, images_all, img_all, box_all = {}, 0, {}, {}
+        for split in ["train", "val", "test"]:
+            img_counts, box_counts, images = {}, {}, 0
+            folder = root / "labels" / split
+            if folder.exists():
+                for txt in folder.glob("*.txt"):
+                    images += 1
+                    try:
+                        lines = txt.read_text(encoding="utf-8", errors="ignore").splitlines()
+                    except Exception:
+                        continue
+                    seen = set()
+                    for line in lines:
+                        parts = line.strip().split()
+                        if not parts:
+                            continue
+                        try:
+                            cid = int(float(parts[0]))
+                            name = names[cid] if cid < len(names) else str(cid)
+                            seen.add(name)
+                            box_counts[name] = box_counts.get(name, 0) + 1
+                        except Exception:
+                            continue
+                    for name in seen:
+                        img_counts[name] = img_counts.get(name, 0) + 1
+            per_split[split] = {"total_images": images, "label_counts": img_counts, "box_counts": box_counts}
+            images_all += images
+            for k, v in img_counts.items():
+                img_all[k] = img_all.get(k, 0) + v
+            for k, v in box_counts.items():
+                box_all[k] = box_all.get(k, 0) + v
+            for name in set(img_counts) | set(box_counts):
+                flat.append({"数据集": root.name, "split": split, "标签": name, "图片数量": img_counts.get(name, 0),
+                             "标注框数量": box_counts.get(name, 0), "占比%": share(img_counts.get(name, 0), images), "split总图片数": images})
+        per_split["all"] = {"total_images": images_all, "label_counts": img_all, "box_counts": box_all}
+        stats[root.name] = per_split
+        for name in set(img_all) | set(box_all):
+            flat.append({"数据集": root.name, "split": "all", "标签": name, "图片数量": img_all.get(name, 0), "标注框数量": box_all.get(name, 0),
+                         "占比%": share(img_all.get(name, 0), images_all), "split总图片数": images_all})
+    return stats, pd.DataFrame(flat)

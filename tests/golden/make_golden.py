@@ -14,8 +14,10 @@ tests or vectors of its own, so these outputs are what pins oracle/ and the HIP 
     e2e_*.csv.gz         one seeded table through all five steps (inputs and every output)
     yolo_cases.json      f4 _extract_boxes_with_labels + the label files generate_yolo_datasets_from_excels writes
     merge_case.json      f3 merge_all_csv_in_folder: input files, merged bytes, progress-callback arguments, printed lines
+    label_replace_case.json  replace_labels_by_mapping (the step between a4 and a5): output CSV, summary, diff / unmatched sheets, raising cells
+    summaries_case.json  summarize_unclassified (three sheets) and summarize_yolo_label_counts (stats + flat rows) on small inputs
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [name ...]      (no names: everything)
 """
 import gzip
 import io
@@ -641,13 +643,170 @@ def make_merge():
     _dump("merge_case.json", {"files": files, "runs": [run_reference_merge(files, 7), run_reference_merge(files, 100000)]})
 
 
+# ------------------------------------------------------------------------------- label_replace (between a4 and a5)
+def run_reference_label_replace(df, mapping_df, **kwargs):
+    """replace_labels_by_mapping with the Excel layer captured in memory; returns what it wrote and returned"""
+    sheets = {}
+    orig = (ref.pd.read_excel, pd.DataFrame.to_excel)
+
+    def to_excel(self, target, *a, **k):
+        sheets[os.path.basename(str(target))] = self.copy()
+
+    ref.pd.read_excel = lambda *a, **k: mapping_df
+    pd.DataFrame.to_excel = to_excel
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            inp, outp = os.path.join(d, "in.csv"), os.path.join(d, "o", "out.csv")
+            df.to_csv(inp, index=False, encoding="utf-8-sig")
+            try:
+                res = ref.replace_labels_by_mapping(inp, os.path.join(d, "map.xlsx"), outp, diff_excel_path=os.path.join(d, "x", "diff.xlsx"),
+                                                    unmatched_excel_path=os.path.join(d, "x", "unmatched.xlsx"), **kwargs)
+            except Exception as e:  # noqa: BLE001
+                return {"raises": type(e).__name__, "message": str(e)}
+            return {"csv": _read_text(outp), "summary": res["summary"], "sample_diff": res["sample_diff"],
+                    "diff_name": os.path.basename(str(res["diff"])), "unmatched_name": os.path.basename(str(res["unmatched"])),
+                    "sheets": {k: _frame_records(v) for k, v in sheets.items()}}
+    finally:
+        ref.pd.read_excel, pd.DataFrame.to_excel = orig
+
+
+LABEL_CELLS = [
+    '{"width": 640, "height": 480, "objects": [{"name": "cat", "polygon": {"ptList": [{"x": 1, "y": 2}, {"x": 3.50, "y": 4e0}]}}, {"name": "dog,cat", "k": [1, 2.0, 1e22, 1e-7, -0.0]}]}',
+    '{"objects":[{"name":"b,a"},{"name":" dog ； bird|dog "},{"name":"猫"},{"name":"\\u732b,wolf"}],"extra":{"a":null,"b":true,"c":"x\\ty\\"z\\\\"}}',
+    '{"objects": [{"name": null}, {"polygon": {}}, {"name": ""}, 7, "s", [1], {"name": "kitty"}, {"name": "lion"}]}',
+    '{"objects": {"name": "cat"}}',
+    '{"objects": []}',
+    '{"width": 3}',
+    '{"objects": [',
+    '',
+    '{"objects": [{"name": "cat", "v": NaN, "w": Infinity, "u": -Infinity, "big": 123456789012345678901234567890, "f": 0.1, "g": 100.0, "h": 1E+2, "i": 1.5e300}]}',
+    '  {"objects" : [ {"name" : "cat;cat;CAT"} ] , "objects2": 1, "name": "cat"}  ',
+    '{"objects": [{"name": "5"}, {"name": "5.0"}, {"name": "nan"}, {"name": "x,y，z;w；v|u"}]}',
+    '{"a": 1, "objects": [{"name": "dog"}], "a": 2}',
+    '{"objects": [{"name": "tab\\there,cat", "s": "\\u0001\\u001f\\u007f\\u00e9\\ud83d\\ude00/\\/"}]}',
+]
+
+
+def make_label_replace():
+    n = len(LABEL_CELLS)
+    df = pd.DataFrame({"source": [f"s{i}" for i in range(n)], ANN: LABEL_CELLS, "other": list(range(n))})
+    df.loc[n] = ["s_nan", np.nan, 99]
+    both = df.copy()
+    both[NEW] = list(reversed(LABEL_CELLS)) + ['{"objects": [{"name": "wolf"}]}']
+    mapping = pd.DataFrame({"旧标签": ["cat", " dog ", "kitty", "bird", None, "nan", "ghost", "5", 5.0, "CAT", "猫", "lion", ""],
+                            "新标签": ["feline", "canine", "feline", " avian ", "x", "y", None, "five", "five-float", "nan", "feline", " ", "z"],
+                            "备注": list("abcdefghijklm")})
+    out = {"mapping": _frame_records(mapping), "cases": {}}
+    out["cases"]["one_column"] = {"input": _frame_records(df), "kwargs": {}, "result": run_reference_label_replace(df, mapping)}
+    out["cases"]["both_columns_sample2"] = {"input": _frame_records(both), "kwargs": {"sample_size": 2},
+                                            "result": run_reference_label_replace(both, mapping, sample_size=2)}
+    out["cases"]["explicit_columns"] = {"input": _frame_records(df), "kwargs": {"old_col": "新标签", "new_col": "备注", "json_columns": [ANN, "missing"]},
+                                        "result": run_reference_label_replace(df, mapping, old_col="新标签", new_col="备注", json_columns=[ANN, "missing"])}
+    empty_map = pd.DataFrame({"a": [None], "b": ["x"]})
+    out["cases"]["nothing_mapped"] = {"input": _frame_records(df.head(3)), "mapping": _frame_records(empty_map), "kwargs": {},
+                                      "result": run_reference_label_replace(df.head(3), empty_map)}
+    one_col = pd.DataFrame({"a": ["x"]})
+    out["cases"]["mapping_one_column"] = {"input": _frame_records(df.head(2)), "mapping": _frame_records(one_col), "kwargs": {},
+                                          "result": run_reference_label_replace(df.head(2), one_col)}
+    # cells the reference does not survive (only JSONDecodeError is caught, :573-577)
+    raising = {"list_document": "[1, 2]", "null_document": "null", "number_document": "12", "string_document": '"abc"',
+               "int_name_changes": '{"objects": [{"name": 7}]}', "true_name": '{"objects": [{"name": true}]}',
+               "list_name": '{"objects": [{"name": ["cat"]}]}', "float_name": '{"objects": [{"name": 2.5}]}',
+               "zero_name_is_quiet": '{"objects": [{"name": 0}, {"name": false}, {"name": []}, {"name": {}}]}',
+               "dict_name": '{"objects": [{"name": {"a": 1}}]}'}
+    out["single_cells"] = {}
+    for k, cell in raising.items():
+        f = pd.DataFrame({"source": ["r0", "r1"], ANN: ['{"objects": [{"name": "cat"}]}', cell]})
+        out["single_cells"][k] = {"cell": cell, "result": run_reference_label_replace(f, mapping)}
+    nosrc = pd.DataFrame({ANN: ['{"objects": [{"name": "cat"}]}'], "n": [1]})
+    out["cases"]["no_source_column"] = {"input": _frame_records(nosrc), "kwargs": {}, "result": run_reference_label_replace(nosrc, mapping)}
+    numeric = pd.DataFrame({"source": ["a", "b"], ANN: [1.5, 2.5]})
+    out["cases"]["numeric_annotation_column"] = {"input": _frame_records(numeric), "kwargs": {}, "result": run_reference_label_replace(numeric, mapping)}
+    _dump("label_replace_case.json", out)
+
+
+# ------------------------------------------------------------------------------- the two summaries either side of a5 / f4
+def run_reference_unclassified(df, **kwargs):
+    cap = _Capture()
+    orig = (ref.pd.read_excel, ref.pd.ExcelWriter, pd.DataFrame.to_excel)
+
+    def to_excel(self, target, sheet_name="Sheet1", index=True, **k):
+        cap.sheets.setdefault(cap.current, {})[sheet_name] = self.copy()
+
+    ref.pd.read_excel = lambda *a, **k: df.copy()
+    ref.pd.ExcelWriter = cap.writer
+    pd.DataFrame.to_excel = to_excel
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "unclassified.xlsx")
+            open(src, "wb").close()
+            try:
+                out_path = ref.summarize_unclassified(src, os.path.join(d, "sum", "dir"), **kwargs)
+            except Exception as e:  # noqa: BLE001
+                return {"raises": type(e).__name__, "message": str(e)}
+            return {"name": os.path.basename(str(out_path)), "parent_exists": os.path.isdir(os.path.dirname(str(out_path))),
+                    "sheets": {s: _frame_records(f) for s, f in cap.sheets[os.path.basename(str(out_path))].items()}}
+    finally:
+        ref.pd.read_excel, ref.pd.ExcelWriter, pd.DataFrame.to_excel = orig
+
+
+def make_summaries():
+    out = {"unclassified": {}, "label_counts": {}}
+    full = pd.DataFrame({"source": [f"u{i}" for i in range(12)],
+                         "无法分类原因": ["标签foo未在规则中定义", "标签bar未在规则中定义", "标签foo未在规则中定义", "空数据", None, "JSON解析失败",
+                                    "标签a,b未在规则中定义", "标签未在规则中定义", "没有可用标签", "标签foo未在规则中定义", "空数据", "x"],
+                         "无法分类标签": ["foo", None, "foo, baz；foo", None, None, "", "a|b", None, " ", "qux", None, "foo"]})
+    out["unclassified"]["full"] = {"input": _frame_records(full), "result": run_reference_unclassified(full)}
+    no_labels = full.drop(columns=["无法分类标签"])
+    out["unclassified"]["no_label_column"] = {"input": _frame_records(no_labels), "result": run_reference_unclassified(no_labels)}
+    no_reason = pd.DataFrame({"source": ["a", "b"], "无法分类标签": ["k", None]})
+    out["unclassified"]["no_reason_column"] = {"input": _frame_records(no_reason), "result": run_reference_unclassified(no_reason)}
+    empty = pd.DataFrame({"source": [], "无法分类原因": []})
+    out["unclassified"]["empty"] = {"input": _frame_records(empty), "result": run_reference_unclassified(empty)}
+    try:
+        ref.summarize_unclassified("/nonexistent/x.xlsx", "/tmp/never")
+    except Exception as e:  # noqa: BLE001
+        out["unclassified"]["missing_file"] = {"raises": type(e).__name__, "message": str(e)}
+
+    # label files as generate_yolo_datasets_from_excels leaves them, plus the things the counter shrugs off
+    tree = {
+        "ds_a/data.yaml": "path: .\nnames:\n- cat\n- dog\n- bird\n",
+        "ds_a/labels/train/i1.txt": "0 0.5 0.5 0.1 0.1\n1 0.2 0.2 0.1 0.1\n0 0.7 0.7 0.1 0.1",
+        "ds_a/labels/train/i2.txt": "2 0.1 0.1 0.1 0.1\n\n   \n7 0.1 0.1 0.1 0.1\nx y z\n1.0 0.3 0.3 0.1 0.1\n-1 0.1 0.1 0.1 0.1\n",
+        "ds_a/labels/train/empty.txt": "",
+        "ds_a/labels/train/notes.md": "0 1 1 1 1",
+        "ds_a/labels/val/v1.txt": "1 0.5 0.5 0.2 0.2",
+        "ds_b/labels/test/t1.txt": "3 0.5 0.5 0.2 0.2\n3 0.1 0.1 0.1 0.1\n0 0.1 0.1 0.1 0.1",
+        "ds_c/data.yaml": "names: [only\n",
+        "ds_c/labels/train/c1.txt": "0 0.5 0.5 0.2 0.2",
+        "ds_d/data.yaml": "names:\n  0: zero\n  1: one\n",
+        "ds_d/labels/train/d1.txt": "1 0.5 0.5 0.2 0.2\n5 0.5 0.5 0.2 0.2",
+        "ds_e/data.yaml": "nc: 2\n",
+        "ds_e/labels/val/e1.txt": "1e0 0.5 0.5 0.2 0.2\nnan 0 0 0 0\ninf 0 0 0 0",
+    }
+    with tempfile.TemporaryDirectory() as d:
+        for rel, text in tree.items():
+            p = os.path.join(d, rel)
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            with open(p, "w", encoding="utf-8") as f:
+                f.write(text)
+        os.makedirs(os.path.join(d, "ds_empty"))
+        dirs = [os.path.join(d, n) if n else n for n in ("ds_a", "ds_b", "", "ds_missing", "ds_c", "ds_d", "ds_e", "ds_empty")]
+        calls = {}
+        for name, arg in (("all", dirs), ("none", None), ("empty_list", []), ("only_missing", [os.path.join(d, "nope")])):
+            try:
+                stats, flat = ref.summarize_yolo_label_counts(arg)
+                calls[name] = {"dirs": [os.path.basename(x) if x else x for x in (arg or [])], "arg_is_none": arg is None, "stats": stats,
+                               "flat_columns": list(flat.columns), "flat_rows": json.loads(flat.to_json(orient="records", force_ascii=False))}
+            except Exception as e:  # noqa: BLE001
+                calls[name] = {"dirs": [os.path.basename(x) if x else x for x in (arg or [])], "raises": type(e).__name__, "message": str(e)}
+    out["label_counts"] = {"tree": tree, "extra_dirs": ["ds_empty"], "calls": calls}
+    _dump("summaries_case.json", out)
+
+
 if __name__ == "__main__":
-    make_replace()
-    make_iou()
-    make_dedup()
-    make_ref_filter()
-    make_perm()
-    make_split()
-    make_e2e()
-    make_yolo()
-    make_merge()
+    makers = {"replace": make_replace, "iou": make_iou, "dedup": make_dedup, "ref_filter": make_ref_filter, "perm": make_perm,
+              "split": make_split, "e2e": make_e2e, "yolo": make_yolo, "merge": make_merge, "label_replace": make_label_replace,
+              "summaries": make_summaries}
+    for name in (sys.argv[1:] or list(makers)):
+        makers[name]()
