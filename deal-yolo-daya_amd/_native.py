@@ -107,6 +107,15 @@ SIGNATURES = {
     "dyd_split_event_kind": (C.c_void_p, [C.c_void_p]),
     "dyd_split_strings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "dyd_split_free": (None, [C.c_void_p]),
+    "dyd_json_relabel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_int, C.POINTER(C.c_void_p)]),
+    "dyd_relabel_status": (C.c_void_p, [C.c_void_p]),
+    "dyd_relabel_has_diff": (C.c_void_p, [C.c_void_p]),
+    "dyd_relabel_counts": (C.c_void_p, [C.c_void_p]),
+    "dyd_relabel_tokens": (C.c_int64, [C.c_void_p]),
+    "dyd_relabel_token_cell": (C.c_void_p, [C.c_void_p]),
+    "dyd_relabel_strings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dyd_relabel_free": (None, [C.c_void_p]),
     "dyd_csv_index": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "dyd_csv_rows": (C.c_int64, [C.c_void_p]),
     "dyd_csv_cols": (C.c_int32, [C.c_void_p]),

@@ -1352,38 +1352,99 @@ def _relabel_cell(cell: str, label_map: dict, tot: _RelabelTotals):
     return json.dumps(doc, ensure_ascii=False), changes, renamed
 
 
+def _relabel_cells_python(cells, label_map, tot: _RelabelTotals):
+    """every cell through CPython json, in order -> (new text or None, joined old names or None, joined new names, renamed?) per cell"""
+    out = []
+    for cell in cells:
+        if not isinstance(cell, str) or not cell:          # NaN, numbers, ""
+            out.append((None, None, None, False))
+            continue
+        text, changes, renamed = _relabel_cell(cell, label_map, tot)
+        if changes:
+            out.append((text, "；".join([a for a, _ in changes]), "；".join([b for _, b in changes]), renamed))
+        else:
+            out.append((text, None, None, renamed))
+    return out
+
+
+def _relabel_cells_native(cells, label_map, tot: _RelabelTotals):
+    """the same through the native relabeller (csrc/host_json.cpp); the cells it calls irregular go through CPython
+    in their turn, so counters, first-seen order of the unmatched labels and the first exception are the reference's"""
+    try:
+        r = _nj.relabel(cells, label_map)
+    except UnicodeEncodeError:                             # a lone surrogate somewhere: CPython path for the batch
+        return _relabel_cells_python(cells, label_map, tot)
+    done = r.status == _nj.RL_REWRITTEN
+    irregular = np.flatnonzero(r.status == _nj.RL_IRREGULAR)
+    sums = r.counts[done].sum(axis=0, dtype=np.int64) if done.any() else np.zeros(5, np.int64)
+    tot.total_objects += int(sums[0]); tot.missing_name_objects += int(sums[1]); tot.total_labels += int(sums[2])
+    tot.replaced_labels += int(sums[3]); tot.replaced_objects += int(sums[4])
+    tot.invalid_json_rows += int(np.count_nonzero(r.status == _nj.RL_UNDECODABLE))
+    texts = np.where(done, r.text, None)
+    before = np.where(r.has_diff != 0, r.before, None)
+    after = np.where(r.has_diff != 0, r.after, None)
+    renamed = r.counts[:, 4] > 0
+    out = list(zip(texts.tolist(), before.tolist(), after.tolist(), renamed.tolist()))
+    token, token_cell = r.token, r.token_cell
+    if len(irregular):
+        extra_tok, extra_cell = [], []
+        for i in irregular.tolist():
+            side = _RelabelTotals()
+            res = _relabel_cells_python([cells[i]], label_map, side)[0]          # may raise, like the reference
+            out[i] = res
+            for k in ("total_objects", "total_labels", "replaced_labels", "replaced_objects", "invalid_json_rows", "missing_name_objects"):
+                setattr(tot, k, getattr(tot, k) + getattr(side, k))
+            for lbl, cnt in side.unmatched.items():      # first-seen order within the cell; the counts are merged below
+                extra_tok += [lbl] * cnt
+                extra_cell += [i] * cnt
+        if extra_tok:
+            token = np.concatenate([token, np.array(extra_tok, dtype=object)])
+            token_cell = np.concatenate([token_cell, np.array(extra_cell, dtype=np.int64)])
+            order = np.argsort(token_cell, kind="stable")
+            token = token[order]
+    if len(token):
+        codes, uniques = pd.factorize(token)               # uniques in order of first appearance
+        counts = np.bincount(codes, minlength=len(uniques))
+        for lbl, cnt in zip(uniques.tolist(), counts.tolist()):
+            tot.unmatched[lbl] = tot.unmatched.get(lbl, 0) + cnt
+    return out
+
+
 def replace_labels_frame(df: pd.DataFrame, label_map: dict, json_columns: Optional[list] = None):
     """DataFrame twin of replace_labels_by_mapping: (frame with the rewritten cells, summary counters, diff rows,
-    unmatched label counts).  Rows are visited in order, and within a row the columns in ``json_columns`` order —
-    the order of the diff rows and of first-seen unmatched labels."""
+    unmatched label counts).  Cells are visited row by row, and within a row in ``json_columns`` order — the order
+    of the diff rows and of first-seen unmatched labels."""
     if json_columns is None:
         json_columns = [c for c in (BBOX_COL, ANNOTATION_COL) if c in df.columns]
     present = [c for c in json_columns if c in df.columns]
     tot = _RelabelTotals()
-    columns = {c: df[c].tolist() for c in present}
+    n, k = len(df), len(present)
+    columns = [df[c].tolist() for c in present]
+    cells = [None] * (n * k)                               # row-major: the order the reference walks them in
+    for j, col in enumerate(columns):
+        cells[j::k] = col
+    relabel = _relabel_cells_native if _nj.enabled() else _relabel_cells_python
+    res = []
+    for start in range(0, len(cells), _NATIVE_CHUNK_CELLS):
+        res += relabel(cells[start:start + _NATIVE_CHUNK_CELLS], label_map, tot)
     sources = df["source"].tolist() if "source" in df.columns else None
-    diff_rows, replaced_rows = [], 0
-    for i in range(len(df)):
-        row_renamed = False
-        for c in present:
-            cell = columns[c][i]
-            if not isinstance(cell, str) or not cell:          # NaN, numbers, ""
-                continue
-            text, changes, renamed = _relabel_cell(cell, label_map, tot)
-            if text is None:
-                continue
-            columns[c][i] = text
-            row_renamed |= renamed
-            if changes:
-                diff_rows.append({"source": sources[i] if sources is not None else None, "column": c,
-                                  "before": "；".join([a for a, _ in changes]), "after": "；".join([b for _, b in changes])})
-        replaced_rows += row_renamed
+    diff_rows = []
+    row_renamed = np.zeros(n, bool)
+    for idx, (text, before, after, renamed) in enumerate(res):
+        if text is None:
+            continue
+        i, j = divmod(idx, k)
+        columns[j][i] = text
+        if renamed:
+            row_renamed[i] = True
+        if before is not None:
+            diff_rows.append({"source": sources[i] if sources is not None else None, "column": present[j], "before": before, "after": after})
     out = df.copy()
-    for c in present:
+    for j, c in enumerate(present):
         if out[c].dtype != object:
             continue                                           # a numeric column holds no cell to rewrite
-        out[c] = pd.Series(columns[c], index=out.index, dtype=object)
-    counters = {"replaced_rows": int(replaced_rows), "total_objects": tot.total_objects, "replaced_objects": tot.replaced_objects,
+        out[c] = pd.Series(columns[j], index=out.index, dtype=object)
+    counters = {"replaced_rows": int(row_renamed.sum()), "total_objects": tot.total_objects, "replaced_objects": tot.replaced_objects,
                 "total_labels": tot.total_labels, "replaced_labels": tot.replaced_labels,
                 "invalid_json_rows": tot.invalid_json_rows, "missing_name_objects": tot.missing_name_objects}
     return out, counters, diff_rows, tot.unmatched

@@ -438,6 +438,7 @@ struct Parser {
             if (end - p >= 3 && !memcmp(p, "NaN", 3)) { p += 3; if (out) *out += "NaN"; } else bad();
         } else if (c == '-' || c == 'I' || (c >= '0' && c <= '9')) {
             Span t = number_token();
+            if (t.e - t.b > 4000) irregular();   // int() refuses more than 4300 digits (ValueError, not a decode error)
             if (out) append_number(*out, t);
         } else {
             bad();
@@ -1527,6 +1528,308 @@ int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const
     }
 }
 void dyd_split_free(dyd_split *h) { delete h; }
+
+}  // extern "C"
+
+// ===================================================================================================
+// label_replace step: object names rewritten through a mapping, the document re-serialised
+// (reference core/processor.py:565-609; helpers utils.py:659-679)
+// ===================================================================================================
+namespace {
+
+enum RelabelStatus : uint8_t {
+    RL_REWRITTEN = 0,     // the document is an object whose "objects" is a list: text re-serialised, names replaced
+    RL_EMPTY = 1,         // NaN / non-str / "" cell (decided by the caller through `missing`)
+    RL_UNDECODABLE = 2,   // json.JSONDecodeError: counted, the cell stays
+    RL_UNCHANGED = 3,     // no "objects", or not a list: the cell stays as it is
+    RL_IRREGULAR = 5      // the Python path decides (non-dict document, odd "name" values, duplicate keys ...)
+};
+
+using NameMap = std::unordered_map<std::string_view, std::string_view>;
+
+struct RelabelPart {      // per-thread outputs, concatenated in cell order afterwards
+    int64_t lo = 0, hi = 0;
+    std::string text, before, after, tokens;
+    std::vector<int64_t> tok_end, tok_cell;
+};
+
+struct RelabelCounts {
+    int32_t objects = 0, missing_name = 0, labels = 0, replaced_labels = 0, replaced_objects = 0;
+};
+
+// one dict element of "objects" (p at '{'): canonical text into `out`, its name replaced when a label is mapped
+void relabel_object(Parser &ps, std::string &out, const NameMap &map, int64_t ci, RelabelPart &pt, RelabelCounts &n, bool &any_change,
+                    std::string &name, std::vector<std::string> &labels) {
+    ++n.objects;
+    ++ps.p;
+    out += '{';
+    KeySet ks;
+    bool first = true, has_name = false, name_is_null = false;
+    if (ps.peek() == '}') { ++ps.p; out += '}'; ++n.missing_name; return; }
+    while (true) {
+        ps.ws();
+        const Span k = ps.string_token();
+        ks.add(ps, k);
+        if (!first) out += ", ";
+        first = false;
+        ps.emit_string(out, k);
+        out += ": ";
+        ps.ws();
+        if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+        ++ps.p;
+        if (Parser::span_is(k, "name")) {
+            has_name = true;
+            const Kind kd = kind_of(ps.peek());
+            if (kd == K_STRING) {
+                ps.ws();
+                const Span v = ps.string_token();
+                decode_string(ps, v, name);
+                if (name.empty()) {                         // falsy: no labels, nothing changes (utils.py:665-666)
+                    out += "\"\"";
+                } else {
+                    split_labels(name, labels);
+                    int hits = 0;
+                    for (std::string &l : labels) {
+                        const auto it = map.find(std::string_view(l));
+                        if (it == map.end()) {                  // :593-595
+                            pt.tokens += l;
+                            pt.tok_end.push_back((int64_t)pt.tokens.size());
+                            pt.tok_cell.push_back(ci);
+                        } else {
+                            l.assign(it->second);
+                            ++hits;
+                        }
+                    }
+                    n.labels += (int32_t)labels.size();
+                    std::sort(labels.begin(), labels.end());    // sorted(set(...)): code point order == UTF-8 byte order
+                    labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+                    std::string fresh;
+                    for (size_t i = 0; i < labels.size(); ++i) {
+                        if (i) fresh += ',';
+                        fresh += labels[i];
+                    }
+                    if (hits) {                                 // :598-602
+                        n.replaced_labels += hits;
+                        ++n.replaced_objects;
+                    }
+                    if (fresh != name) {                        // :603-604 (also when nothing was replaced: the diff shows it,
+                        if (any_change) {                       //           the cell keeps the old name)
+                            pt.before += "\xef\xbc\x9b";
+                            pt.after += "\xef\xbc\x9b";
+                        }
+                        pt.before += name;
+                        pt.after += fresh;
+                        any_change = true;
+                    }
+                    quote_utf8(out, hits ? fresh : name);
+                }
+            } else if (kd == K_NULL) {
+                ps.value(&out);
+                name_is_null = true;
+            } else if (kd == K_FALSE) {
+                ps.value(&out);                                 // falsy and not None: nothing to do
+            } else if (kd == K_ARRAY || kd == K_OBJECT) {
+                const char open = *ps.p;
+                ++ps.p;
+                if (ps.peek() != (open == '[' ? ']' : '}')) ps.irregular();   // str(list / dict) as a label: Python path
+                ++ps.p;
+                out += (open == '[') ? "[]" : "{}";
+            } else {
+                ps.irregular();                                 // numbers (0 is falsy, 7 -> "7") and true: Python path
+            }
+        } else {
+            ps.value(&out);
+        }
+        const char d = ps.peek();
+        if (d == ',') { ++ps.p; continue; }
+        if (d == '}') { ++ps.p; break; }
+        ps.bad();
+    }
+    out += '}';
+    if (!has_name || name_is_null) ++n.missing_name;
+}
+
+// whole cell.  Throws Fail.  On RL_REWRITTEN the part holds the new text, the joined diff and the unmatched labels.
+RelabelStatus relabel_cell(Span cell, int64_t ci, const NameMap &map, RelabelPart &pt, RelabelCounts &n, bool &any_change) {
+    Parser ps{cell.b, cell.e};
+    ps.ws();
+    if (ps.p >= ps.end) ps.bad();
+    if (*ps.p != '{') {   // list / scalar document: data.get raises AttributeError and ends the step: Python path
+        ps.value(nullptr);
+        ps.ws();
+        if (ps.p != ps.end) ps.bad();
+        ps.irregular();
+    }
+    ++ps.p;
+    std::string &out = pt.text;
+    out += '{';
+    int objects_kind = -1;   // -1 absent, 0 array, 1 something else
+    KeySet ks;
+    std::string name;
+    std::vector<std::string> labels;
+    if (ps.peek() == '}') {
+        ++ps.p;
+    } else {
+        bool first = true;
+        while (true) {
+            ps.ws();
+            const Span k = ps.string_token();
+            ks.add(ps, k);
+            if (!first) out += ", ";
+            first = false;
+            ps.emit_string(out, k);
+            out += ": ";
+            ps.ws();
+            if (ps.p >= ps.end || *ps.p != ':') ps.bad();
+            ++ps.p;
+            if (Parser::span_is(k, "objects")) {
+                if (kind_of(ps.peek()) != K_ARRAY) {
+                    objects_kind = 1;
+                    ps.value(nullptr);
+                } else {
+                    objects_kind = 0;
+                    ++ps.p;
+                    out += '[';
+                    if (ps.peek() == ']') {
+                        ++ps.p;
+                    } else {
+                        bool first_el = true;
+                        while (true) {
+                            if (!first_el) out += ", ";
+                            first_el = false;
+                            if (ps.peek() == '{') relabel_object(ps, out, map, ci, pt, n, any_change, name, labels);
+                            else ps.value(&out);     // non-dict elements are kept and not counted (:583-584)
+                            const char d = ps.peek();
+                            if (d == ',') { ++ps.p; continue; }
+                            if (d == ']') { ++ps.p; break; }
+                            ps.bad();
+                        }
+                    }
+                    out += ']';
+                }
+            } else {
+                ps.value(&out);
+            }
+            const char d = ps.peek();
+            if (d == ',') { ++ps.p; continue; }
+            if (d == '}') { ++ps.p; break; }
+            ps.bad();
+        }
+    }
+    ps.ws();
+    if (ps.p != ps.end) ps.bad();
+    out += '}';
+    return objects_kind == 0 ? RL_REWRITTEN : RL_UNCHANGED;
+}
+
+}  // namespace
+
+struct dyd_relabel {
+    int64_t n_cells = 0;
+    std::vector<uint8_t> status, has_diff;
+    std::vector<int32_t> counts;          // 5 per cell: objects, missing names, labels, replaced labels, replaced objects
+    std::string text, before, after, tokens;
+    std::vector<int64_t> text_off, before_off, after_off, tok_off, tok_cell;
+};
+
+extern "C" {
+
+// map_keys / map_vals: the old -> new label pairs, concatenated UTF-8 with offsets.  `missing[i]` != 0 marks a cell the
+// step skips (NaN / not text / "").  Cells are independent; the caller walks the results in its own (row-major) order.
+int dyd_json_relabel(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                     const uint8_t *key_text, const int64_t *key_off, const uint8_t *val_text, const int64_t *val_off,
+                     int32_t n_pairs, int n_threads, dyd_relabel **out) {
+    if (!out || n_cells < 0 || n_pairs < 0 || (n_cells > 0 && !cell_off) || (n_pairs > 0 && (!key_text || !key_off || !val_text || !val_off)))
+        return DYD_ERR_INVALID;
+    dyd_relabel *h = new (std::nothrow) dyd_relabel();
+    if (!h) return DYD_ERR_OOM;
+    try {
+        h->n_cells = n_cells;
+        h->status.assign((size_t)n_cells, RL_EMPTY);
+        h->has_diff.assign((size_t)n_cells, 0);
+        h->counts.assign((size_t)n_cells * 5, 0);
+        NameMap map;
+        map.reserve((size_t)n_pairs * 2 + 1);
+        for (int32_t i = 0; i < n_pairs; ++i)   // later pairs overwrite earlier ones, as the dict does
+            map[std::string_view((const char *)key_text + key_off[i], (size_t)(key_off[i + 1] - key_off[i]))] =
+                std::string_view((const char *)val_text + val_off[i], (size_t)(val_off[i + 1] - val_off[i]));
+        std::vector<RelabelPart> parts(64);
+        std::vector<int64_t> text_len((size_t)n_cells, 0), before_len((size_t)n_cells, 0), after_len((size_t)n_cells, 0);
+        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            RelabelPart &pt = parts[(size_t)t];
+            pt.lo = lo; pt.hi = hi;
+            for (int64_t i = lo; i < hi; ++i) {
+                if (missing && missing[i]) continue;
+                const size_t m_text = pt.text.size(), m_before = pt.before.size(), m_after = pt.after.size(), m_tok = pt.tokens.size(),
+                             m_te = pt.tok_end.size();
+                RelabelCounts n;
+                bool any_change = false;
+                RelabelStatus st;
+                try {
+                    st = relabel_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, i, map, pt, n, any_change);
+                } catch (Fail f) {
+                    st = (f.code == 1) ? RL_UNDECODABLE : RL_IRREGULAR;
+                }
+                if (st != RL_REWRITTEN) {   // nothing of this cell is kept
+                    pt.text.resize(m_text); pt.before.resize(m_before); pt.after.resize(m_after); pt.tokens.resize(m_tok);
+                    pt.tok_end.resize(m_te); pt.tok_cell.resize(m_te);
+                } else {
+                    int32_t *c = &h->counts[(size_t)i * 5];
+                    c[0] = n.objects; c[1] = n.missing_name; c[2] = n.labels; c[3] = n.replaced_labels; c[4] = n.replaced_objects;
+                    h->has_diff[(size_t)i] = any_change ? 1 : 0;
+                }
+                h->status[(size_t)i] = st;
+                text_len[(size_t)i] = (int64_t)(pt.text.size() - m_text);
+                before_len[(size_t)i] = (int64_t)(pt.before.size() - m_before);
+                after_len[(size_t)i] = (int64_t)(pt.after.size() - m_after);
+            }
+        });
+        std::sort(parts.begin(), parts.end(), [](const RelabelPart &a, const RelabelPart &b) { return a.lo < b.lo; });
+        h->tok_off.push_back(0);
+        for (auto &pt : parts) {
+            const int64_t tb = (int64_t)h->tokens.size();
+            h->text += pt.text;
+            h->before += pt.before;
+            h->after += pt.after;
+            h->tokens += pt.tokens;
+            for (int64_t e : pt.tok_end) h->tok_off.push_back(tb + e);
+            h->tok_cell.insert(h->tok_cell.end(), pt.tok_cell.begin(), pt.tok_cell.end());
+        }
+        h->text_off.resize((size_t)n_cells + 1);
+        h->before_off.resize((size_t)n_cells + 1);
+        h->after_off.resize((size_t)n_cells + 1);
+        h->text_off[0] = h->before_off[0] = h->after_off[0] = 0;
+        for (int64_t i = 0; i < n_cells; ++i) {
+            h->text_off[(size_t)i + 1] = h->text_off[(size_t)i] + text_len[(size_t)i];
+            h->before_off[(size_t)i + 1] = h->before_off[(size_t)i] + before_len[(size_t)i];
+            h->after_off[(size_t)i + 1] = h->after_off[(size_t)i] + after_len[(size_t)i];
+        }
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    *out = h;
+    return DYD_OK;
+}
+
+const uint8_t *dyd_relabel_status(const dyd_relabel *h) { return h->status.data(); }
+const uint8_t *dyd_relabel_has_diff(const dyd_relabel *h) { return h->has_diff.data(); }
+const int32_t *dyd_relabel_counts(const dyd_relabel *h) { return h->counts.data(); }
+int64_t dyd_relabel_tokens(const dyd_relabel *h) { return (int64_t)h->tok_cell.size(); }
+const int64_t *dyd_relabel_token_cell(const dyd_relabel *h) { return h->tok_cell.data(); }
+// which: 0 new text per cell [n_cells], 1 joined old names per cell [n_cells], 2 joined new names per cell [n_cells],
+// 3 unmatched labels in order of appearance [tokens]
+int dyd_relabel_strings(const dyd_relabel *h, int which, const uint8_t **data, const int64_t **off) {
+    if (!h || !data || !off) return DYD_ERR_INVALID;
+    switch (which) {
+        case 0: *data = (const uint8_t *)h->text.data(); *off = h->text_off.data(); return DYD_OK;
+        case 1: *data = (const uint8_t *)h->before.data(); *off = h->before_off.data(); return DYD_OK;
+        case 2: *data = (const uint8_t *)h->after.data(); *off = h->after_off.data(); return DYD_OK;
+        case 3: *data = (const uint8_t *)h->tokens.data(); *off = h->tok_off.data(); return DYD_OK;
+        default: return DYD_ERR_INVALID;
+    }
+}
+void dyd_relabel_free(dyd_relabel *h) { delete h; }
 
 }  // extern "C"
 

@@ -244,6 +244,55 @@ def split_expand(cells, labels: list, n_threads: int = 0) -> SplitExpansion:
     return SplitExpansion(h, len(cells))
 
 
+# ------------------------------------------------------------------------------------------ label_replace step
+RL_REWRITTEN, RL_EMPTY, RL_UNDECODABLE, RL_UNCHANGED, RL_IRREGULAR = 0, 1, 2, 3, 5
+
+
+def _packed(strings):
+    raw = [s.encode("utf-8") for s in strings]
+    off = np.zeros(len(raw) + 1, np.int64)
+    np.cumsum(np.fromiter(map(len, raw), dtype=np.int64, count=len(raw)), out=off[1:])
+    return np.frombuffer(b"".join(raw) or b"\0", dtype=np.uint8), off
+
+
+class Relabelling:
+    """Result of relabel, copied out of the native handle: per cell status, counts[n, 5] (objects, names missing,
+    labels, labels replaced, objects renamed), has_diff, text / before / after (object arrays of str; "" where the
+    cell was not rewritten), and the unmatched labels in order of appearance (token, token_cell)."""
+
+    def __init__(self, handle, n_cells):
+        L = _native.load_library()
+        try:
+            self.status = _view(L.dyd_relabel_status(handle), np.uint8, n_cells).copy()
+            self.has_diff = _view(L.dyd_relabel_has_diff(handle), np.uint8, n_cells).copy()
+            self.counts = _view(L.dyd_relabel_counts(handle), np.int32, 5 * n_cells).reshape(-1, 5).copy()
+            tokens = int(L.dyd_relabel_tokens(handle))
+            self.token_cell = _view(L.dyd_relabel_token_cell(handle), np.int64, tokens).copy()
+            d, o = C.c_void_p(), C.c_void_p()
+            out = []
+            for which, count in ((0, n_cells), (1, n_cells), (2, n_cells), (3, tokens)):
+                _native.check(L.dyd_relabel_strings(handle, which, C.byref(d), C.byref(o)), "dyd_relabel_strings")
+                out.append(_strings(d.value, o.value, count))
+            self.text, self.before, self.after, self.token = out
+        finally:
+            L.dyd_relabel_free(handle)
+
+
+def relabel(cells, label_map: dict, n_threads: int = 0) -> Relabelling:
+    """cells: JSON cells (str) or anything else for a cell the step skips; label_map: old label -> new label"""
+    L = _native.load_library()
+    buf, off, missing, keep = cells_to_buffers(cells)
+    for i, c in enumerate(cells):                       # "" is skipped too (reference processor.py:571)
+        if c == "":
+            missing[i] = 1
+    kbuf, koff = _packed(list(label_map.keys()))
+    vbuf, voff = _packed(list(label_map.values()))
+    h = C.c_void_p()
+    _native.check(L.dyd_json_relabel(buf.ctypes.data, off.ctypes.data, missing.ctypes.data, len(cells), kbuf.ctypes.data, koff.ctypes.data,
+                                     vbuf.ctypes.data, voff.ctypes.data, len(label_map), n_threads, C.byref(h)), "dyd_json_relabel")
+    return Relabelling(h, len(cells))
+
+
 # ------------------------------------------------------------------------------------------ YOLO step
 class LabelledScan(_Scan):
     """labelled boxes per cell: box4 (min x, min y, max x, max y), cell_box_off, sel (name == the row's label)"""

@@ -249,6 +249,28 @@ const uint8_t *dyd_split_event_kind(const dyd_split *h);      /* [events] */
 int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const int64_t **off);
 void dyd_split_free(dyd_split *h);
 
+/* ---- native relabelling of the label_replace step (HOST code, multithreaded) ------------------------------
+ * Replaces the per-row Python of replace_labels_by_mapping (processor.py:565-609; utils.py:659-679): in every
+ * document whose "objects" is a list, the name of each dict element is split into labels, the labels found among
+ * the keys are replaced, the result de-duplicated, sorted and joined with ","; the whole document is re-serialised
+ * as json.dumps(..., ensure_ascii=False) does.  key_text/key_off, val_text/val_off: the old -> new label pairs.
+ * Per cell: status (0 rewritten, 1 skipped: no usable cell, 2 JSON decode error, 3 left as it is: "objects" absent
+ * or not a list, 5 irregular: the Python path decides), five counters (objects, names missing, labels seen, labels
+ * replaced, objects renamed), whether some name would change, and for those the old / new names joined with "；"
+ * (:605-609).  The labels that are not keys of the mapping, in order of appearance, with their cell. */
+typedef struct dyd_relabel dyd_relabel;
+int dyd_json_relabel(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                     const uint8_t *key_text, const int64_t *key_off, const uint8_t *val_text, const int64_t *val_off,
+                     int32_t n_pairs, int n_threads, dyd_relabel **out);
+const uint8_t *dyd_relabel_status(const dyd_relabel *h);        /* [n_cells] */
+const uint8_t *dyd_relabel_has_diff(const dyd_relabel *h);      /* [n_cells] */
+const int32_t *dyd_relabel_counts(const dyd_relabel *h);        /* [n_cells][5] */
+int64_t dyd_relabel_tokens(const dyd_relabel *h);
+const int64_t *dyd_relabel_token_cell(const dyd_relabel *h);    /* [tokens] */
+/* which: 0 new text [n_cells], 1 joined old names [n_cells], 2 joined new names [n_cells], 3 unmatched label [tokens] */
+int dyd_relabel_strings(const dyd_relabel *h, int which, const uint8_t **data, const int64_t **off);
+void dyd_relabel_free(dyd_relabel *h);
+
 /* ---- native CSV hand-off (HOST code) ------------------------------------------------
  * Replaces pandas read_csv / to_csv around the two heavy JSON columns (processor.py:235, :309, :379,
  * :404, :407).  dyd_csv_index tokenises a utf-8 buffer with pandas' C-parser conventions and FAILS on

@@ -373,3 +373,51 @@ def test_yolo_texts_odd_sizes_take_the_python_path(oracle_backend):
     texts, reasons = P.yolo_label_texts([cell] * 4, ["a"] * 4, [1, 2, 3, 4], [10, None, "", True], [10, 10, 10, 10], oracle_backend)
     assert texts[0] == "1 0.200000 0.300000 0.200000 0.200000" and texts[3] == "4 2.000000 0.300000 2.000000 0.200000"
     assert reasons[1] == reasons[2] == "缺少图像尺寸"
+
+
+# ------------------------------------------------------------------------------------------ label_replace step
+RELABEL_MAP = {"c1": "g1", "c2": "g1", "c3": "中", "中文": "c1", 'a"b': "q,r", "😀": "z"}
+
+
+def _relabel_one_by_one(cells, fn):
+    """every cell alone, so that a cell that ends the step (exception) does not hide the ones after it"""
+    out = []
+    for c in cells:
+        tot = P._RelabelTotals()
+        try:
+            res = fn([c], RELABEL_MAP, tot)
+            out.append((res, {k: getattr(tot, k) for k in tot.__slots__ if k != "unmatched"}, list(tot.unmatched.items())))
+        except Exception as e:  # noqa: BLE001
+            out.append((type(e).__name__, str(e)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_relabel_fuzz_matches_cpython(seed):
+    from deal_yolo_daya_amd import native_json
+    g = SplitGen(5000 + seed)
+    cells = [g.cell() for _ in range(500)] + [None, "", float("nan"), 7, '{"objects": [{"name": "c1;c2 , c1"}, {"name": " ， "}], "k": 1e5}']
+    st = native_json.relabel(cells, RELABEL_MAP).status
+    assert (st == native_json.RL_REWRITTEN).sum() > 90 and (st == native_json.RL_IRREGULAR).sum() > 5
+    native = _relabel_one_by_one(cells, P._relabel_cells_native)
+    plain = _relabel_one_by_one(cells, P._relabel_cells_python)
+    for i, (a, b) in enumerate(zip(native, plain)):
+        assert a == b, (i, cells[i], a, b)
+    assert sum(1 for b in plain if not isinstance(b[0], str) and b[0][0][1] is not None) > 20        # cells with a diff
+    # and as one batch (counters summed, unmatched labels in first-seen order) over the cells that do not raise
+    quiet = [c for c, b in zip(cells, plain) if not isinstance(b[0], str)]
+    ta, tb = P._RelabelTotals(), P._RelabelTotals()
+    assert P._relabel_cells_native(quiet, RELABEL_MAP, ta) == P._relabel_cells_python(quiet, RELABEL_MAP, tb)
+    assert list(ta.unmatched.items()) == list(tb.unmatched.items()) and len(tb.unmatched) >= 3
+    assert all(getattr(ta, k) == getattr(tb, k) for k in ta.__slots__)
+
+
+def test_relabel_rules():
+    """separators, Unicode whitespace, replaced labels merged and sorted, names that only change their spelling"""
+    cells = ['{"a": 1, "objects": [{"name": "\\u3000c2 ,\\u00a0c1；zz|c1", "id": 1}, 5, {"id": 2}, {"name": "b,a"}, {"name": "c3"}], "b": [1.0, "x"]}']
+    tot = P._RelabelTotals()
+    (text, before, after, renamed), = P._relabel_cells_native(cells, RELABEL_MAP, tot)
+    assert text == '{"a": 1, "objects": [{"name": "g1,zz", "id": 1}, 5, {"id": 2}, {"name": "b,a"}, {"name": "中"}], "b": [1.0, "x"]}'
+    assert before == "　c2 , c1；zz|c1；b,a；c3" and after == "g1,zz；a,b；中" and renamed
+    assert (tot.total_objects, tot.missing_name_objects, tot.total_labels, tot.replaced_labels, tot.replaced_objects) == (4, 1, 7, 4, 2)
+    assert list(tot.unmatched.items()) == [("zz", 1), ("b", 1), ("a", 1)]
