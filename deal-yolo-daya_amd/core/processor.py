@@ -1367,6 +1367,23 @@ def _relabel_cells_python(cells, label_map, tot: _RelabelTotals):
     return out
 
 
+def _relabel_add_counts(tot: _RelabelTotals, r):
+    done = r.status == _nj.RL_REWRITTEN
+    sums = r.counts[done].sum(axis=0, dtype=np.int64) if done.any() else np.zeros(5, np.int64)
+    tot.total_objects += int(sums[0]); tot.missing_name_objects += int(sums[1]); tot.total_labels += int(sums[2])
+    tot.replaced_labels += int(sums[3]); tot.replaced_objects += int(sums[4])
+    tot.invalid_json_rows += int(np.count_nonzero(r.status == _nj.RL_UNDECODABLE))
+
+
+def _relabel_add_unmatched(tot: _RelabelTotals, token):
+    """labels in order of appearance -> counts in first-seen order"""
+    if len(token):
+        codes, uniques = pd.factorize(token)               # uniques in order of first appearance
+        counts = np.bincount(codes, minlength=len(uniques))
+        for lbl, cnt in zip(uniques.tolist(), counts.tolist()):
+            tot.unmatched[lbl] = tot.unmatched.get(lbl, 0) + cnt
+
+
 def _relabel_cells_native(cells, label_map, tot: _RelabelTotals):
     """the same through the native relabeller (csrc/host_json.cpp); the cells it calls irregular go through CPython
     in their turn, so counters, first-seen order of the unmatched labels and the first exception are the reference's"""
@@ -1376,14 +1393,12 @@ def _relabel_cells_native(cells, label_map, tot: _RelabelTotals):
         return _relabel_cells_python(cells, label_map, tot)
     done = r.status == _nj.RL_REWRITTEN
     irregular = np.flatnonzero(r.status == _nj.RL_IRREGULAR)
-    sums = r.counts[done].sum(axis=0, dtype=np.int64) if done.any() else np.zeros(5, np.int64)
-    tot.total_objects += int(sums[0]); tot.missing_name_objects += int(sums[1]); tot.total_labels += int(sums[2])
-    tot.replaced_labels += int(sums[3]); tot.replaced_objects += int(sums[4])
-    tot.invalid_json_rows += int(np.count_nonzero(r.status == _nj.RL_UNDECODABLE))
-    texts = np.where(done, r.text, None)
-    before = np.where(r.has_diff != 0, r.before, None)
-    after = np.where(r.has_diff != 0, r.after, None)
+    _relabel_add_counts(tot, r)
+    texts = np.where(done, r.text(), None)
+    before = np.where(r.has_diff != 0, r.before(), None)
+    after = np.where(r.has_diff != 0, r.after(), None)
     renamed = r.counts[:, 4] > 0
+    r.close()
     out = list(zip(texts.tolist(), before.tolist(), after.tolist(), renamed.tolist()))
     token, token_cell = r.token, r.token_cell
     if len(irregular):
@@ -1402,11 +1417,7 @@ def _relabel_cells_native(cells, label_map, tot: _RelabelTotals):
             token_cell = np.concatenate([token_cell, np.array(extra_cell, dtype=np.int64)])
             order = np.argsort(token_cell, kind="stable")
             token = token[order]
-    if len(token):
-        codes, uniques = pd.factorize(token)               # uniques in order of first appearance
-        counts = np.bincount(codes, minlength=len(uniques))
-        for lbl, cnt in zip(uniques.tolist(), counts.tolist()):
-            tot.unmatched[lbl] = tot.unmatched.get(lbl, 0) + cnt
+    _relabel_add_unmatched(tot, token)
     return out
 
 
@@ -1450,6 +1461,84 @@ def replace_labels_frame(df: pd.DataFrame, label_map: dict, json_columns: Option
     return out, counters, diff_rows, tot.unmatched
 
 
+def _relabel_csv_fast(input_csv_path, label_map, output_csv_path, json_columns):
+    """CSV -> CSV label replacement without pandas touching the JSON columns (fastcsv + native relabeller).
+    Returns NotImplemented when the fast path does not apply (nothing has been written then), else
+    (n_rows, counters, diff_rows, unmatched)."""
+    try:
+        table = _fc.read_split(str(input_csv_path), [BBOX_COL, ANNOTATION_COL] if json_columns is None else list(json_columns))
+    except (OSError, ValueError, pd.errors.ParserError, UnicodeDecodeError):
+        return NotImplemented
+    if table is None:
+        return NotImplemented
+    if json_columns is None:
+        json_columns = [c for c in (BBOX_COL, ANNOTATION_COL) if c in table.names]
+    present = [c for c in json_columns if c in table.names]
+    if not present or len(set(present)) != len(present) or any(c not in table.heavy for c in present):
+        return NotImplemented                              # short or numeric JSON columns: pandas types them, pandas reads them
+    label_map = label_map()
+    k = len(present)
+    tot = _RelabelTotals()
+    new_cols, tokens, token_keys, diffs, runs = {}, [], [], [], []
+    row_renamed = np.zeros(table.n_rows, bool)
+    for j, c in enumerate(present):
+        col = table.heavy[c]
+        r = _nj.relabel_buffers(col.data, col.off, col.na, label_map, keep=col)
+        runs.append(r)
+        _relabel_add_counts(tot, r)
+        row_renamed |= r.counts[:, 4] > 0
+        tokens.append(r.token)
+        token_keys.append(r.token_cell * k + j)
+        diff_cells = np.flatnonzero(r.has_diff)
+        if len(diff_cells):
+            before, after = r.before(), r.after()
+            diffs += [(int(i) * k + j, before[i], after[i]) for i in diff_cells.tolist()]
+        irregular = np.flatnonzero(r.status == _nj.RL_IRREGULAR)
+        spliced = None
+        for i in irregular.tolist():                        # CPython decides, in its turn; may raise, like the reference
+            side = _RelabelTotals()
+            text, before, after, renamed = _relabel_cells_python([col.cell(i)], label_map, side)[0]
+            for name in ("total_objects", "total_labels", "replaced_labels", "replaced_objects", "invalid_json_rows", "missing_name_objects"):
+                setattr(tot, name, getattr(tot, name) + getattr(side, name))
+            for lbl, cnt in side.unmatched.items():
+                tokens.append(np.array([lbl] * cnt, dtype=object))
+                token_keys.append(np.full(cnt, i * k + j, np.int64))
+            row_renamed[i] |= renamed
+            if before is not None:
+                diffs.append((i * k + j, before, after))
+            if text is not None:
+                if spliced is None:
+                    spliced = r.text().tolist()
+                spliced[i] = text
+        if spliced is None:
+            data, off = r.text_buffers()
+            new_cols[c] = _fc.Utf8Column(data, off, col.na, r)
+        else:
+            for i in np.flatnonzero(col.na).tolist():
+                spliced[i] = None
+            spec = _fc._series_column(pd.Series(spliced, dtype=object))
+            new_cols[c] = _fc.Utf8Column(spec[1], spec[2], spec[3])
+    if tokens:
+        token = np.concatenate(tokens)
+        key = np.concatenate(token_keys)
+        _relabel_add_unmatched(tot, token[np.argsort(key, kind="stable")])
+    diffs.sort(key=lambda d: d[0])
+    sources = table.light["source"].tolist() if "source" in table.light.columns else None
+    diff_rows = [{"source": sources[key // k] if sources is not None else None, "column": present[key % k], "before": b, "after": a}
+                 for key, b, a in diffs]
+    columns = [new_cols[nm] if nm in new_cols else (table.heavy[nm] if nm in table.heavy else table.light[nm]) for nm in table.names]
+    Path(output_csv_path).parent.mkdir(parents=True, exist_ok=True)
+    ok = _fc.write_table(str(output_csv_path), table.names, columns, table.n_rows)
+    for r in runs:
+        r.close()
+    if not ok:
+        return NotImplemented
+    counters = {"replaced_rows": int(row_renamed.sum()), "total_objects": tot.total_objects, "replaced_objects": tot.replaced_objects,
+                "total_labels": tot.total_labels, "replaced_labels": tot.replaced_labels,
+                "invalid_json_rows": tot.invalid_json_rows, "missing_name_objects": tot.missing_name_objects}
+    return table.n_rows, counters, diff_rows, tot.unmatched
+
+
 def replace_labels_by_mapping(
         input_csv_path: str,
         mapping_excel_path: str,
@@ -1465,14 +1554,29 @@ def replace_labels_by_mapping(
     """Drop-in for reference processor.py:516-652 (pipeline step ``label_replace``, between the IoU filter and the
     split): object names rewritten through the mapping sheet, every parsed cell re-serialised, a diff sheet and an
     unmatched-label sheet on request.  Host-only step: there is no arithmetic for the device in it."""
-    df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
-    mapping_df = pd.read_excel(mapping_excel_path, sheet_name=sheet_name) if sheet_name else pd.read_excel(mapping_excel_path)
-    label_map = mapping_to_label_map(mapping_df, old_col, new_col)
-    out, counters, diff_rows, unmatched = replace_labels_frame(df, label_map, json_columns)
-
     output_csv_path = Path(output_csv_path)
-    output_csv_path.parent.mkdir(parents=True, exist_ok=True)
-    out.to_csv(output_csv_path, index=False, encoding="utf-8-sig")
+    made = {}
+
+    def label_map():                                       # the mapping sheet is read after the CSV, as in the reference
+        if "map" not in made:
+            mapping_df = pd.read_excel(mapping_excel_path, sheet_name=sheet_name) if sheet_name else pd.read_excel(mapping_excel_path)
+            made["map"] = mapping_to_label_map(mapping_df, old_col, new_col)
+        return made["map"]
+
+    fast = NotImplemented
+    if _fc.enabled() and _nj.enabled() and os.path.isfile(str(input_csv_path)):
+        fast = _relabel_csv_fast(input_csv_path, label_map, output_csv_path, json_columns)
+    if fast is not NotImplemented:
+        LAST_IO_PATH["label_replace"] = "native"
+        total_rows, counters, diff_rows, unmatched = fast
+    else:
+        LAST_IO_PATH["label_replace"] = "pandas"
+        df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+        out, counters, diff_rows, unmatched = replace_labels_frame(df, label_map(), json_columns)
+        total_rows = len(df)
+        output_csv_path.parent.mkdir(parents=True, exist_ok=True)
+        out.to_csv(output_csv_path, index=False, encoding="utf-8-sig")
+    label_map = label_map()
 
     diff_path = None
     if diff_excel_path:
@@ -1489,7 +1593,7 @@ def replace_labels_by_mapping(
             sheet = pd.DataFrame(columns=["标签", "数量"])
         sheet.to_excel(unmatched_path, index=False)
 
-    summary = {"total_rows": len(df), "replaced_rows": counters["replaced_rows"], "total_objects": counters["total_objects"],
+    summary = {"total_rows": total_rows, "replaced_rows": counters["replaced_rows"], "total_objects": counters["total_objects"],
                "replaced_objects": counters["replaced_objects"], "total_labels": counters["total_labels"],
                "replaced_labels": counters["replaced_labels"], "invalid_json_rows": counters["invalid_json_rows"],
                "missing_name_objects": counters["missing_name_objects"], "mapping_size": len(label_map),

@@ -1770,9 +1770,10 @@ int dyd_json_relabel(const uint8_t *text, const int64_t *cell_off, const uint8_t
                 } catch (Fail f) {
                     st = (f.code == 1) ? RL_UNDECODABLE : RL_IRREGULAR;
                 }
-                if (st != RL_REWRITTEN) {   // nothing of this cell is kept
+                if (st != RL_REWRITTEN) {   // nothing of this cell is kept: its text stays what it was
                     pt.text.resize(m_text); pt.before.resize(m_before); pt.after.resize(m_after); pt.tokens.resize(m_tok);
                     pt.tok_end.resize(m_te); pt.tok_cell.resize(m_te);
+                    pt.text.append((const char *)text + cell_off[i], (size_t)(cell_off[i + 1] - cell_off[i]));
                 } else {
                     int32_t *c = &h->counts[(size_t)i * 5];
                     c[0] = n.objects; c[1] = n.missing_name; c[2] = n.labels; c[3] = n.replaced_labels; c[4] = n.replaced_objects;

@@ -256,41 +256,77 @@ def _packed(strings):
 
 
 class Relabelling:
-    """Result of relabel, copied out of the native handle: per cell status, counts[n, 5] (objects, names missing,
-    labels, labels replaced, objects renamed), has_diff, text / before / after (object arrays of str; "" where the
-    cell was not rewritten), and the unmatched labels in order of appearance (token, token_cell)."""
+    """Result of relabel: per cell status, counts[n, 5] (objects, names missing, labels, labels replaced, objects
+    renamed), has_diff, the unmatched labels in order of appearance (token, token_cell); the text after the step (the
+    cell itself unless it was rewritten, empty for skipped cells) and the joined old / new names as flat buffers
+    (text_data / text_off ...) or, through text() / before() / after(), as object arrays of str."""
 
-    def __init__(self, handle, n_cells):
+    def __init__(self, handle, n_cells, keep=None):
         L = _native.load_library()
+        self._h, self._keep, self.n_cells = handle, keep, n_cells
+        self.status = _view(L.dyd_relabel_status(handle), np.uint8, n_cells).copy()
+        self.has_diff = _view(L.dyd_relabel_has_diff(handle), np.uint8, n_cells).copy()
+        self.counts = _view(L.dyd_relabel_counts(handle), np.int32, 5 * n_cells).reshape(-1, 5).copy()
+        tokens = int(L.dyd_relabel_tokens(handle))
+        self.token_cell = _view(L.dyd_relabel_token_cell(handle), np.int64, tokens).copy()
+        self.token = self._strings(3, tokens)
+
+    def _buffers(self, which, count):
+        d, o = C.c_void_p(), C.c_void_p()
+        _native.check(_native.load_library().dyd_relabel_strings(self._h, which, C.byref(d), C.byref(o)), "dyd_relabel_strings")
+        off = _view(o.value, np.int64, count + 1)
+        return _view(d.value, np.uint8, max(int(off[-1]), 1) if count else 0), off, d.value, o.value
+
+    def _strings(self, which, count):
+        _, _, d, o = self._buffers(which, count)
+        return _strings(d, o, count)
+
+    def text(self):
+        return self._strings(0, self.n_cells)
+
+    def before(self):
+        return self._strings(1, self.n_cells)
+
+    def after(self):
+        return self._strings(2, self.n_cells)
+
+    def text_buffers(self):
+        """(data u8, off i64) views into the handle: valid until close()"""
+        data, off, _, _ = self._buffers(0, self.n_cells)
+        return data, off
+
+    def close(self):
+        if self._h is not None:
+            _native.load_library().dyd_relabel_free(self._h)
+            self._h = None
+
+    def __del__(self):
         try:
-            self.status = _view(L.dyd_relabel_status(handle), np.uint8, n_cells).copy()
-            self.has_diff = _view(L.dyd_relabel_has_diff(handle), np.uint8, n_cells).copy()
-            self.counts = _view(L.dyd_relabel_counts(handle), np.int32, 5 * n_cells).reshape(-1, 5).copy()
-            tokens = int(L.dyd_relabel_tokens(handle))
-            self.token_cell = _view(L.dyd_relabel_token_cell(handle), np.int64, tokens).copy()
-            d, o = C.c_void_p(), C.c_void_p()
-            out = []
-            for which, count in ((0, n_cells), (1, n_cells), (2, n_cells), (3, tokens)):
-                _native.check(L.dyd_relabel_strings(handle, which, C.byref(d), C.byref(o)), "dyd_relabel_strings")
-                out.append(_strings(d.value, o.value, count))
-            self.text, self.before, self.after, self.token = out
-        finally:
-            L.dyd_relabel_free(handle)
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def relabel_buffers(data, off, missing, label_map: dict, n_threads: int = 0, keep=None) -> Relabelling:
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    missing = np.ascontiguousarray(missing, dtype=np.uint8)
+    L = _native.load_library()
+    kbuf, koff = _packed(list(label_map.keys()))
+    vbuf, voff = _packed(list(label_map.values()))
+    h = C.c_void_p()
+    _native.check(L.dyd_json_relabel(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1, kbuf.ctypes.data, koff.ctypes.data,
+                                     vbuf.ctypes.data, voff.ctypes.data, len(label_map), n_threads, C.byref(h)), "dyd_json_relabel")
+    return Relabelling(h, len(off) - 1, (keep, data, off, missing))
 
 
 def relabel(cells, label_map: dict, n_threads: int = 0) -> Relabelling:
     """cells: JSON cells (str) or anything else for a cell the step skips; label_map: old label -> new label"""
-    L = _native.load_library()
     buf, off, missing, keep = cells_to_buffers(cells)
     for i, c in enumerate(cells):                       # "" is skipped too (reference processor.py:571)
         if c == "":
             missing[i] = 1
-    kbuf, koff = _packed(list(label_map.keys()))
-    vbuf, voff = _packed(list(label_map.values()))
-    h = C.c_void_p()
-    _native.check(L.dyd_json_relabel(buf.ctypes.data, off.ctypes.data, missing.ctypes.data, len(cells), kbuf.ctypes.data, koff.ctypes.data,
-                                     vbuf.ctypes.data, voff.ctypes.data, len(label_map), n_threads, C.byref(h)), "dyd_json_relabel")
-    return Relabelling(h, len(cells))
+    return relabel_buffers(buf, off, missing, label_map, n_threads, keep)
 
 
 # ------------------------------------------------------------------------------------------ YOLO step

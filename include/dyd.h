@@ -267,7 +267,7 @@ const uint8_t *dyd_relabel_has_diff(const dyd_relabel *h);      /* [n_cells] */
 const int32_t *dyd_relabel_counts(const dyd_relabel *h);        /* [n_cells][5] */
 int64_t dyd_relabel_tokens(const dyd_relabel *h);
 const int64_t *dyd_relabel_token_cell(const dyd_relabel *h);    /* [tokens] */
-/* which: 0 new text [n_cells], 1 joined old names [n_cells], 2 joined new names [n_cells], 3 unmatched label [tokens] */
+/* which: 0 text after the step [n_cells] (the cell itself unless status 0; empty for status 1), 1 joined old names [n_cells], 2 joined new names [n_cells], 3 unmatched label [tokens] */
 int dyd_relabel_strings(const dyd_relabel *h, int which, const uint8_t **data, const int64_t **off);
 void dyd_relabel_free(dyd_relabel *h);
 

@@ -220,3 +220,51 @@ def test_processing_page_imports_resolve():
                  "process_csv_replace_ptlist", "filter_by_box_count_and_iou", "replace_labels_by_mapping", "split_dataset_by_rules",
                  "summarize_unclassified", "generate_yolo_datasets_from_excels", "summarize_yolo_label_counts"):
         assert callable(getattr(P, name)), name
+
+
+def _synthetic_two_column_table(n=400):
+    from deal_yolo_daya_amd import synth
+    df = synth.to_frame(synth.generate(n, seed=21, max_boxes=5))
+    df[P.BBOX_COL] = df[P.ANNOTATION_COL].iloc[::-1].to_numpy()
+    df.loc[3, P.BBOX_COL] = np.nan
+    df.loc[5, P.ANNOTATION_COL] = '{"objects": ['                                           # decode error
+    df.loc[7, P.ANNOTATION_COL] = '{"objects": [{"name": "c1", "name": "c2"}], "pad": "' + "x" * 80 + '"}'   # repeated key: CPython decides
+    df.loc[9, P.BBOX_COL] = '{"objects": [{"na\\u006de": "c3,c4"}, {"name": "c4；c2"}], "pad": "' + "y" * 80 + '"}'
+    df.loc[11, P.ANNOTATION_COL] = '{"objects": {"name": "c1"}, "pad": "' + "z" * 80 + '"}'
+    df["n"] = np.arange(len(df))
+    return df
+
+
+@pytest.mark.parametrize("json_columns", [None, [P.ANNOTATION_COL], [P.ANNOTATION_COL, P.BBOX_COL, "absent"]])
+def test_label_replace_csv_paths_agree(tmp_path, monkeypatch, json_columns):
+    """native CSV + native relabeller, native relabeller behind pandas I/O, and CPython alone write the same bytes"""
+    df = _synthetic_two_column_table()
+    mapping = pd.DataFrame({"old": [f"c{i}" for i in range(0, 20, 3)], "new": ["g1", "g2", "g1", "c1", "g3", "g2", "g1"]})
+    kwargs = {} if json_columns is None else {"json_columns": json_columns}
+    runs = {}
+    for mode, env in (("native", {}), ("native_json_only", {"DYD_NATIVE_CSV": "0"}), ("cpython", {"DYD_NATIVE_CSV": "0", "DYD_NATIVE_JSON": "0"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            d = tmp_path / mode
+            d.mkdir()
+            res, text, sheets = _run_product(d, m, df, mapping, kwargs)
+            runs[mode] = (text, res["summary"], res["sample_diff"], {k: _records(v) for k, v in sheets.items()}, P.LAST_IO_PATH["label_replace"])
+    assert runs["native"][4] == "native" and runs["native_json_only"][4] == "pandas" and runs["cpython"][4] == "pandas"
+    assert runs["native"][:4] == runs["cpython"][:4] and runs["native_json_only"][:4] == runs["cpython"][:4]
+    summary = runs["cpython"][1]
+    assert summary["replaced_rows"] > 100 and summary["invalid_json_rows"] == 1 and summary["unmatched_labels"] > 5
+    inp = tmp_path / "in.csv"
+    df.to_csv(inp, index=False, encoding="utf-8-sig")
+    want = osteps.label_replace_csv(str(inp), mapping, str(tmp_path / "oracle.csv"), diff_excel_path="d", unmatched_excel_path="u", **kwargs)
+    assert (tmp_path / "oracle.csv").read_bytes().decode("utf-8-sig") == runs["native"][0] and want["summary"] == summary
+
+
+def test_label_replace_csv_fast_path_raises_like_the_reference(tmp_path, monkeypatch):
+    df = _synthetic_two_column_table(60)
+    df.loc[20, P.ANNOTATION_COL] = '{"objects": [{"name": 7}], "pad": "' + "x" * 80 + '"}'
+    mapping = pd.DataFrame({"old": ["c1"], "new": ["g1"]})
+    with pytest.raises(TypeError) as ei:
+        _run_product(tmp_path, monkeypatch, df, mapping, {})
+    assert str(ei.value) == "sequence item 0: expected str instance, int found"
+    assert not (tmp_path / "o" / "out.csv").exists()
