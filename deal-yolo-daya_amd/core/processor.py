@@ -13,7 +13,10 @@ positionally through ``run_step`` (:548, :566, :584, :598, :630):
 
 and, either side of them, ``merge_all_csv_in_folder`` (reference processor.py:26-109, native
 CSV hand-off) and the label-line arithmetic of generate_yolo_datasets_from_excels
-(reference processor.py:1001-1060) as ``yolo_label_texts`` -> K7.
+(reference processor.py:1001-1060) as ``yolo_label_texts`` -> K7.  The rest of what the processing page imports from this
+module is here as host-only steps: ``replace_labels_by_mapping`` (pipeline step label_replace, reference :516-652, native
+relabeller), ``summarize_unclassified`` (:833-891), ``summarize_yolo_label_counts`` (:1089-1162) and
+``overwrite_reference_with_result`` (:221-227); only the drawing helper is left out.
 
 Each step is  flatten (cells -> SoA numpy buffers)  ->  device stage (HIP kernels behind
 include/dyd.h)  ->  emit (masks / indices back into pandas).  Every step also has a

@@ -15,4 +15,4 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address,undefined
 ASAN=$($HIPCC -print-file-name=libclang_rt.asan-x86_64.so)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   DYD_LIB_PATH=$PWD/build_exp/libdyd_asan.so python -m pytest tests/test_native_json_cpu.py tests/test_fastcsv_cpu.py \
-  tests/test_merge_cpu.py tests/test_host_steps_cpu.py tests/test_yolo_host_cpu.py -x -q
+  tests/test_merge_cpu.py tests/test_host_steps_cpu.py tests/test_yolo_host_cpu.py tests/test_label_replace_cpu.py -x -q

@@ -101,6 +101,24 @@ def main():
             P.merge_all_csv_in_folder(Q("parts"), Q("merged_warm.csv"))
             s_m, n_m = clock(lambda: P.merge_all_csv_in_folder(Q("parts"), Q("merged_prod.csv")))
         out["product_merge"] = {"s": round(s_m, 3), "rows_per_s": round(n_m / s_m), "io_paths": dict(P.LAST_IO_PATH["merge"])}
+        # ---- label_replace step (between IoU filter and split): CSV -> CSV over the IoU step's "other" table ------------
+        mapping = pd.DataFrame({"old": [f"c{i}" for i in range(0, 20, 2)], "new": [f"g{i % 4}" for i in range(10)]})
+        real_read_excel, real_to_excel = pd.read_excel, pd.DataFrame.to_excel
+        pd.read_excel = lambda *a, **k: mapping.copy()                       # openpyxl is not installed: the Excel layer is stubbed
+        pd.DataFrame.to_excel = lambda self, *a, **k: None
+        try:
+            P.replace_labels_by_mapping(Q("c4o_prod.csv"), "map.xlsx", Q("lr_warm.csv"))
+            s_lr, res_lr = clock(lambda: P.replace_labels_by_mapping(Q("c4o_prod.csv"), "map.xlsx", Q("lr_prod.csv"), diff_excel_path=Q("d.xlsx"),
+                                                                    unmatched_excel_path=Q("u.xlsx")))
+            out["product_label_replace"] = {"s": round(s_lr, 3), "rows": res_lr["summary"]["total_rows"], "rows_per_s": round(res_lr["summary"]["total_rows"] / s_lr),
+                                            "replaced_labels": res_lr["summary"]["replaced_labels"], "io_path": P.LAST_IO_PATH["label_replace"]}
+            if not args.skip_cpu:
+                s_lr, ores = clock(lambda: osteps.label_replace_csv(Q("c4o_prod.csv"), mapping, Q("lr_cpu.csv"), diff_excel_path="d", unmatched_excel_path="u"))
+                out["cpu_port_label_replace"] = {"s": round(s_lr, 3), "rows_per_s": round(ores["summary"]["total_rows"] / s_lr)}
+                out["label_replace_identical"] = open(Q("lr_prod.csv"), "rb").read() == open(Q("lr_cpu.csv"), "rb").read() \
+                    and ores["summary"] == res_lr["summary"] and ores["sample_diff"] == res_lr["sample_diff"]
+        finally:
+            pd.read_excel, pd.DataFrame.to_excel = real_read_excel, real_to_excel
         # ---- split + YOLO label texts (a5 in memory, f4) ----------------------------------------------------
         rules = pd.DataFrame({"catA": [f"c{i}" for i in range(10)], "catB": [f"c{i}" for i in range(10, 18)] + [None, None]})
         lmap = P.rules_to_label_map(rules)
