@@ -255,9 +255,12 @@ struct RowState {   // what the measuring pass keeps for the printing pass
 // plain row keep the four rounded values (bit 31 = sign) and print them straight; the other lanes go through
 // row_measure / row_print below.
 // one box of a row of width w, height h: true when its line is plain; q = the four values as round(|v| * 10^6), bit 31 = sign
+__device__ __forceinline__ bool plain_corners(double ax, double ay, double bx, double by, double w, double h, uint32_t q[4]);
 __device__ __forceinline__ bool plain_box(const double *__restrict__ b, double w, double h, uint32_t q[4]) {
     const double2 lo2 = *reinterpret_cast<const double2 *>(b), hi2 = *reinterpret_cast<const double2 *>(b + 2);
-    const double ax = lo2.x, ay = lo2.y, bx = hi2.x, by = hi2.y;
+    return plain_corners(lo2.x, lo2.y, hi2.x, hi2.y, w, h, q);
+}
+__device__ __forceinline__ bool plain_corners(double ax, double ay, double bx, double by, double w, double h, uint32_t q[4]) {
     const double x1 = (bx < ax) ? bx : ax, x2 = (bx > ax) ? bx : ax;
     const double y1 = (by < ay) ? by : ay, y2 = (by > ay) ? by : ay;
     const double bw = x2 - x1, bh = y2 - y1;            // max(d, 0.0) == d for the d > 0 accepted here
@@ -846,9 +849,10 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_pair_kernel(const double *__
 // host must print (a value of 2^43 or more) makes the whole row the host's, so when a tile has such a line a third scan
 // tells every box whether its row holds one.  Tiles of more than K7B_CAP boxes (a row of hundreds of boxes) take
 // the row-per-lane route in chunks of 256 rows.
-constexpr int K7B_WINDOW = 448;
+constexpr int K7B_WINDOW = 480;
 constexpr int K7B_CAP = 512;                 // boxes the LDS arrays of a tile hold: two per lane
 constexpr int K7B_PER = K7B_CAP / K7_BLOCK;
+constexpr int K7B_LDS_TEXT = 22 * 1024;      // text staged per tile (480..511 lines of ~38 B); with the row table 5 workgroups fit a CU
 
 // first i in [0, n] with off[i] >= x
 __device__ __forceinline__ int64_t lower_bound_off(const int32_t *__restrict__ off, int64_t n, int64_t x) {
@@ -863,10 +867,12 @@ __device__ __forceinline__ int64_t lower_bound_off(const int32_t *__restrict__ o
 // tile t owns the rows [tile_row[t], tile_row[t + 1]): one binary search per tile, all tiles at once (inside the tile
 // kernel the 20 dependent loads of a search cost more than the rest of the tile)
 __global__ __launch_bounds__(K7_BLOCK) void k7_tile_rows_kernel(const int32_t *__restrict__ row_off, int64_t n_rows, int64_t n_tiles,
-                                                                int64_t *__restrict__ tile_row) {
+                                                                int64_t *__restrict__ tile_row, int64_t *__restrict__ tile_box) {
     const int64_t t = (int64_t)blockIdx.x * K7_BLOCK + threadIdx.x;
     if (t > n_tiles) return;
-    tile_row[t] = (t == n_tiles) ? n_rows : lower_bound_off(row_off, n_rows, t * K7B_WINDOW);
+    const int64_t r = (t == n_tiles) ? n_rows : lower_bound_off(row_off, n_rows, t * K7B_WINDOW);
+    tile_row[t] = r;
+    tile_box[t] = row_off[r];   // the tile kernel then needs no dependent load to know its boxes
 }
 
 __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__restrict__ box4,
@@ -876,11 +882,15 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
                                                                const double *__restrict__ height,
                                                                const int32_t *__restrict__ class_id, int64_t n_rows,
                                                                int64_t n_tiles, const int64_t *__restrict__ tile_row,
+                                                               const int64_t *__restrict__ tile_box,
                                                                int64_t *__restrict__ text_off,
                                                                uint8_t *__restrict__ flag_out, uint8_t *text,
-                                                               int64_t text_cap, unsigned long long *state) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_text[K7_LDS_TEXT + 32];
+                                                               int64_t text_cap, unsigned long long *state,
+                                                               unsigned long long *trace) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_text[K7B_LDS_TEXT + 32];
     __shared__ uint32_t s_cnt[K7B_CAP + 1], s_pos[K7B_CAP + 1], s_ex[K7B_CAP + 1];   // exclusive scans over the boxes: lines / bytes / host lines
+    __shared__ uint32_t s_off[K7B_CAP + 1];     // the tile's row offsets, relative to its first box (when it has at most K7B_CAP rows)
+    __shared__ uint8_t s_host[K7B_CAP];         // row is the host's by its sizes / class id
     __shared__ uint32_t s_wave[K7B_PER][K7_WAVES];
     __shared__ unsigned long long s_bcast[2];
     __shared__ uint32_t s_bad;           // the tile holds a line only the host can print
@@ -891,8 +901,10 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
     unsigned long long *words = state + 2;
     if (tile >= n_tiles) return;
     if (tid == 0) s_bad = 0;
+#define K7B_STAMP(i) do { if (trace && tid == 0) trace[tile * 8 + (i)] = wall_clock64(); } while (0)
+    K7B_STAMP(0);
     const int64_t r_lo = tile_row[tile], r_hi = tile_row[tile + 1];           // rows [r_lo, r_hi), possibly none
-    const int64_t b_lo = row_off[r_lo], nb = (int64_t)row_off[r_hi] - b_lo;
+    const int64_t b_lo = tile_box[tile], nb = tile_box[tile + 1] - b_lo;
     const int64_t nr = r_hi - r_lo;
     const bool small = nb <= K7B_CAP;
 
@@ -933,12 +945,38 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
     uint32_t q[K7B_PER][4], len[K7B_PER], line[K7B_PER];
     bool plain[K7B_PER];
     if (small) {
-        // the tile's row offsets, relative, in LDS (the text area is free until the printing) when they fit
-        uint32_t *s_off = reinterpret_cast<uint32_t *>(s_text);
-        const bool offs_in_lds = nr <= K7B_CAP;
-        if (offs_in_lds)
+        // the lane's boxes are requested first; meanwhile the tile's rows (offsets relative to the tile, sizes, class ids)
+        // go to LDS with coalesced loads (the text area is free until the printing), so that a box finds its row and
+        // the row's numbers without another trip to memory
+        double2 c_lo[K7B_PER], c_hi[K7B_PER];
+#pragma unroll
+        for (int k = 0; k < K7B_PER; ++k) {
+            const int64_t j = (int64_t)k * K7_BLOCK + tid;
+            c_lo[k] = c_hi[k] = make_double2(0.0, 0.0);
+            if (j < nb) {
+                const double2 *b = reinterpret_cast<const double2 *>(box4 + 4 * (b_lo + j));
+                c_lo[k] = b[0];
+                c_hi[k] = b[1];
+            }
+        }
+        double *s_w = reinterpret_cast<double *>(s_text);                                    // [K7B_CAP]
+        double *s_h = s_w + K7B_CAP;                                                         // [K7B_CAP]
+        int32_t *s_cid = reinterpret_cast<int32_t *>(s_h + K7B_CAP);                         // [K7B_CAP]
+        static_assert(20 * K7B_CAP <= K7B_LDS_TEXT, "the rows of a tile fit the text area");
+        const bool rows_in_lds = nr <= K7B_CAP;
+        if (rows_in_lds) {
             for (int64_t i = tid; i <= nr; i += K7_BLOCK) s_off[i] = (uint32_t)(row_off[r_lo + i] - b_lo);
+            for (int64_t i = tid; i < nr; i += K7_BLOCK) {
+                const double w = width[r_lo + i], h = height[r_lo + i];
+                const int32_t c = class_id[r_lo + i];
+                s_w[i] = w;
+                s_h[i] = h;
+                s_cid[i] = c;
+                s_host[i] = (w == 0.0) || (h == 0.0) || (c < 0);
+            }
+        }
         __syncthreads();
+        K7B_STAMP(1);
         uint32_t host_line[K7B_PER];
 #pragma unroll
         for (int k = 0; k < K7B_PER; ++k) {
@@ -951,34 +989,35 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
             in[k].host = true;
             if (j < nb) {
                 int64_t lo = 0, hi = nr;   // the last row of the tile that starts at or before box j
-                if (offs_in_lds) {
+                if (rows_in_lds) {
                     while (hi - lo > 1) {
                         const int64_t mid = (lo + hi) >> 1;
                         if (s_off[mid] <= (uint32_t)j) lo = mid; else hi = mid;
                     }
                     in[k].b0 = (int32_t)s_off[lo];
                     in[k].b1 = (int32_t)s_off[lo + 1];
-                } else {
+                    in[k].w = s_w[lo];
+                    in[k].h = s_h[lo];
+                    in[k].cid = s_cid[lo];
+                } else {   // a run of empty rows longer than the table: searched and read in memory
                     while (hi - lo > 1) {
                         const int64_t mid = (lo + hi) >> 1;
                         if (row_off[r_lo + mid] - b_lo <= j) lo = mid; else hi = mid;
                     }
                     in[k].b0 = (int32_t)(row_off[r_lo + lo] - b_lo);
                     in[k].b1 = (int32_t)(row_off[r_lo + lo + 1] - b_lo);
+                    in[k].w = width[r_lo + lo];
+                    in[k].h = height[r_lo + lo];
+                    in[k].cid = class_id[r_lo + lo];
                 }
-                const int64_t row = r_lo + lo;
-                in[k].w = width[row];
-                in[k].h = height[row];
-                in[k].cid = class_id[row];
                 in[k].host = (in[k].w == 0.0) || (in[k].h == 0.0) || (in[k].cid < 0);
                 if (!in[k].host && (!sel || sel[b_lo + j])) {
-                    const double *b = box4 + 4 * (b_lo + j);
-                    if ((uint32_t)in[k].cid < 100u && plain_box(b, in[k].w, in[k].h, q[k])) {
+                    if ((uint32_t)in[k].cid < 100u && plain_corners(c_lo[k].x, c_lo[k].y, c_hi[k].x, c_hi[k].y, in[k].w, in[k].h, q[k])) {
                         plain[k] = true;
                         line[k] = 1;
                         len[k] = plain_len(in[k], q[k]);
                     } else {
-                        const Line l = box_line(b, in[k].w, in[k].h);
+                        const Line l = box_line(box4 + 4 * (b_lo + j), in[k].w, in[k].h);
                         if (l.valid) {
                             line[k] = 1;
                             if (l.exotic) host_line[k] = 1;
@@ -989,6 +1028,7 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
             }
             if (host_line[k]) atomicOr(&s_bad, 1u);
         }
+        K7B_STAMP(2);
         __syncthreads();
         const bool bad = s_bad != 0;
         if (bad) {   // rare: rows holding a host line give no text at all
@@ -1048,11 +1088,12 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
         tile_bytes = carry;
     }
 
+    K7B_STAMP(3);
     // ---- publish; print into LDS while the tiles before publish theirs; look back (wave 0) ---------------------------------
     if (tid == 0)
         __hip_atomic_store(&words[tile], (tile == 0 ? K7_FLAG_PFX : K7_FLAG_AGG) | (unsigned long long)tile_bytes, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-    const bool staged = small && text && tile_bytes && tile_bytes <= (uint32_t)K7_LDS_TEXT;
+    const bool staged = small && text && tile_bytes && tile_bytes <= (uint32_t)K7B_LDS_TEXT;
     auto print_box = [&](int k, int64_t j, unsigned char *where) {
         auto put = [&](int p, char c) { where[p] = (unsigned char)c; };
         int pos = 0;
@@ -1073,6 +1114,7 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
             if (small && line[k]) print_box(k, j, s_text + s_pos[j]);
         }
     }
+    K7B_STAMP(4);
     if (wave == 0) {
         unsigned long long base = 0;
         int64_t look = tile - 1;
@@ -1118,6 +1160,7 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
         }
     }
     __syncthreads();
+    K7B_STAMP(5);
     const int64_t base = (int64_t)s_bcast[1];
     const bool fits = base + (int64_t)tile_bytes <= text_cap;
     if (text && tile_bytes && !fits && tid == 0) atomicExch(&state[1], 2ull);   // the host reads the size needed in text_off[n_rows]
@@ -1125,13 +1168,23 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
     if (small) {
         // ---- the rows' offsets and verdicts from the scans --------------------------------------------------------------
         const bool bad = s_bad != 0;
-        for (int64_t r = r_lo + tid; r < r_hi; r += K7_BLOCK) {
-            const uint32_t a = (uint32_t)(row_off[r] - b_lo), b = (uint32_t)(row_off[r + 1] - b_lo);
-            const bool host = (width[r] == 0.0) || (height[r] == 0.0) || (class_id[r] < 0) || (bad && s_ex[b] > s_ex[a]);
-            text_off[r] = base + s_pos[a];
-            flag_out[r] = host ? 2 : ((s_cnt[b] > s_cnt[a]) ? 0 : 1);
+        if (nr <= K7B_CAP) {   // everything a row needs is in LDS
+            for (int64_t i = tid; i < nr; i += K7_BLOCK) {
+                const uint32_t a = s_off[i], b = s_off[i + 1];
+                const bool host = s_host[i] || (bad && s_ex[b] > s_ex[a]);
+                text_off[r_lo + i] = base + s_pos[a];
+                flag_out[r_lo + i] = host ? 2 : ((s_cnt[b] > s_cnt[a]) ? 0 : 1);
+            }
+        } else {
+            for (int64_t r = r_lo + tid; r < r_hi; r += K7_BLOCK) {
+                const uint32_t a = (uint32_t)(row_off[r] - b_lo), b = (uint32_t)(row_off[r + 1] - b_lo);
+                const bool host = (width[r] == 0.0) || (height[r] == 0.0) || (class_id[r] < 0) || (bad && s_ex[b] > s_ex[a]);
+                text_off[r] = base + s_pos[a];
+                flag_out[r] = host ? 2 : ((s_cnt[b] > s_cnt[a]) ? 0 : 1);
+            }
         }
         if (tile == n_tiles - 1 && tid == 0) text_off[n_rows] = base + tile_bytes;
+        K7B_STAMP(6);
         if (!text || tile_bytes == 0 || !fits) return;
         unsigned char *dst = text + base;
         if (staged) {   // LDS -> memory in 16-byte stores; the words are realigned to the destination's phase
@@ -1164,6 +1217,7 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
                 if (line[k]) print_box(k, j, dst + s_pos[j]);
             }
         }
+        K7B_STAMP(7);
         return;
     }
     for (int64_t r = r_lo + tid; r < r_hi; r += K7_BLOCK) {   // each lane wrote these entries itself
@@ -1185,7 +1239,7 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
 }
 
 // dyd_set_option("k7_variant"): -1 = by the table's shape (default: 22 for one box per row, 30 from 1.25 boxes per row on),
-// 2 = one 512-row tile per ticket, 22 = two, pipelined, 30 = tiles of 448 boxes, a lane per box
+// 2 = one 512-row tile per ticket, 22 = two, pipelined, 30 = tiles of 480 boxes, a lane per box
 static int g_k7_variant = -1;
 static unsigned long long *g_k7_trace = nullptr;   // tuning hook (single-tile kernel): 8 timestamps per tile
 void set_k7_trace(void *p) { g_k7_trace = static_cast<unsigned long long *>(p); }
@@ -1206,16 +1260,16 @@ static int yolo_launch(const double *box4, const int32_t *row_off, const uint8_t
     const int64_t n_tiles = by_box ? (n_boxes > 0 ? ceil_div(n_boxes, (int64_t)K7B_WINDOW) : 1) : ceil_div(n_rows, (int64_t)K7_BLOCK * 2);
     void *scr = nullptr;
     const size_t state_bytes = (size_t)(n_tiles + 2) * 8;
-    int rc = get_scratch(state_bytes + (by_box ? (size_t)(n_tiles + 1) * 8 : 0), &scr, st);
+    int rc = get_scratch(state_bytes + (by_box ? (size_t)(n_tiles + 1) * 16 : 0), &scr, st);
     if (rc) return rc;
     DYD_HIP(hipMemsetAsync(scr, 0, state_bytes, st));
     unsigned long long *state = static_cast<unsigned long long *>(scr);
     if (by_box) {   // (the first tile's search for box 0 gives row 0: leading empty rows are its own)
-        int64_t *tile_row = reinterpret_cast<int64_t *>(state + n_tiles + 2);
+        int64_t *tile_row = reinterpret_cast<int64_t *>(state + n_tiles + 2), *tile_box = tile_row + n_tiles + 1;
         hipLaunchKernelGGL(k7_tile_rows_kernel, dim3((unsigned)ceil_div(n_tiles + 1, (int64_t)K7_BLOCK)), dim3(K7_BLOCK), 0, st, row_off,
-                           n_rows, n_tiles, tile_row);
+                           n_rows, n_tiles, tile_row, tile_box);
         hipLaunchKernelGGL(k7_yolo_box_kernel, dim3((unsigned)n_tiles), dim3(K7_BLOCK), 0, st, box4, row_off, sel, width, height,
-                           class_id, n_rows, n_tiles, tile_row, text_off, flag, text, text_cap, state);
+                           class_id, n_rows, n_tiles, tile_row, tile_box, text_off, flag, text, text_cap, state, g_k7_trace);
     }
     else if (g_k7_variant != 2)
         hipLaunchKernelGGL((k7_yolo_pair_kernel<2>), dim3((unsigned)ceil_div(n_tiles, 2)), dim3(K7_BLOCK), 0, st, box4, row_off, sel,

@@ -67,7 +67,7 @@ def _random_case(rng, n_rows, max_boxes, with_sel, special=True):
 
 @pytest.fixture(params=[-1, 22, 2, 30], ids=["auto", "paired", "single", "by_box"])
 def k7_variant(request, native):
-    """22 = two 512-row tiles per ticket, software-pipelined; 2 = one tile per ticket; 30 = tiles of 448 boxes, a lane per
+    """22 = two 512-row tiles per ticket, software-pipelined; 2 = one tile per ticket; 30 = tiles of 480 boxes, a lane per
     box; -1 (default) = 22 for tables of one box per row, 30 from 1.25 boxes per row on"""
     native.check(native.lib().dyd_set_option(b"k7_variant", request.param), "opt")
     yield request.param
@@ -186,12 +186,12 @@ def test_k7_box_tiles(native, k7_variant, shape):
     middle of a row, everything in one row"""
     rng = np.random.default_rng(len(shape))
     if shape == "window_multiple":
-        counts = np.full(448 * 3 // 4, 4)
+        counts = np.full(480 * 3 // 4, 4)
     elif shape == "empty_runs":
         counts = np.zeros(9000, np.int64)
         counts[[0, 700, 701, 5000, 8999]] = [3, 500, 1, 460, 2]
     elif shape == "row_over_windows":
-        counts = np.array([5, 0, 448 * 3 + 17, 0, 0, 2, 448, 1, 447, 1])
+        counts = np.array([5, 0, 480 * 3 + 17, 0, 0, 2, 480, 1, 479, 1, 448, 3, 31, 1])
     elif shape == "text_over_lds":
         counts = rng.integers(1, 9, 400)
     elif shape == "host_lines":
@@ -199,7 +199,7 @@ def test_k7_box_tiles(native, k7_variant, shape):
     elif shape == "one_row":
         counts = np.array([2000])
     else:
-        counts = np.where(np.arange(4000) % 9 == 0, 1, 0)        # 448 boxes spread over 4000 rows per tile
+        counts = np.where(np.arange(4000) % 9 == 0, 1, 0)        # a tile's boxes spread over some 4000 rows
     n_rows = len(counts)
     row_off = np.zeros(n_rows + 1, np.int32)
     np.cumsum(counts, out=row_off[1:])
