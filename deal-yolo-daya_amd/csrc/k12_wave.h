@@ -68,7 +68,7 @@ __device__ __forceinline__ BoxAcc k12_wave_boxes(const double2 *__restrict__ xy,
             }
         }
     }
-    if (lane < cnt) acc.store(out_box4, out_arg4, b0 + lane);
+    if (lane < cnt) acc.store<true>(out_box4, out_arg4, b0 + lane);
     return acc;
 }
 

@@ -28,7 +28,21 @@ struct BoxAcc {
         mnx = mny = mxx = mxy = __builtin_nan("");
         imnx = imny = imxx = imxy = -1;
     }
+    // NT: non-temporal stores — for a kernel whose boxes are not read again from memory (the fused K1+K2 hands them to K2
+    // through LDS): 2 % on back-to-back launches (0.624 -> 0.610 ms), the 0.8 GB of output no longer displaces the point stream
+    template <bool NT = false>
     __device__ __forceinline__ void store(double *out_box4, int32_t *out_arg4, int64_t b) const {
+        if (NT) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            v2d *ob = reinterpret_cast<v2d *>(out_box4 + 4 * b);
+            const v2d lo2 = {mnx, mny}, hi2 = {mxx, mxy};
+            const v4i ai = {imnx, imny, imxx, imxy};
+            __builtin_nontemporal_store(lo2, ob);
+            __builtin_nontemporal_store(hi2, ob + 1);
+            __builtin_nontemporal_store(ai, reinterpret_cast<v4i *>(out_arg4 + 4 * b));
+            return;
+        }
         double2 *ob = reinterpret_cast<double2 *>(out_box4 + 4 * b);
         ob[0] = make_double2(mnx, mny);
         ob[1] = make_double2(mxx, mxy);
