@@ -39,13 +39,55 @@ __global__ __launch_bounds__(K0_BLOCK) void k0_stream(const uint4 *__restrict__ 
     if ((MODE == 1 || MODE == 4) && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) dst[0] = acc;
 }
 
+// Random-access ceilings for the hash-table and permutation kernels (K4/K5/K6): every lane touches one 8-byte word at a
+// pseudo-random place of a table of 2^k words (a bijective xorshift-multiply mix of the lane's index: every word is hit
+// exactly once, like a permutation).  mode 6: scatter (store), 7: gather (load), 8: atomicMin on the word (K4's insert).
+__device__ __forceinline__ uint64_t mix_bits(uint64_t x, int k) {
+    const uint64_t mask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+    const int s = (k + 1) / 2;
+    x ^= x >> s;
+    x = (x * 0x9e3779b97f4a7c15ull) & mask;
+    x ^= x >> s;
+    x = (x * 0xd6e8feb86659fd93ull) & mask;
+    x ^= x >> s;
+    return x;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(K0_BLOCK) void k0_random(unsigned long long *__restrict__ table, int k, unsigned long long *__restrict__ sink) {
+    const int64_t n = (int64_t)1 << k;
+    const int64_t stride = (int64_t)gridDim.x * K0_BLOCK;
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * K0_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint64_t j = mix_bits((uint64_t)i, k);
+        if (MODE == 6) table[j] = (unsigned long long)i;
+        else if (MODE == 7) acc ^= table[j];
+        else atomicMin(&table[j], (unsigned long long)i);
+    }
+    if (MODE == 7 && acc == 0x9e3779b97f4a7c15ull) sink[0] = acc;
+}
+
 }  // namespace dyd
 
 using namespace dyd;
 
 extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream) {
     DYD_API_ENTER();
-    DYD_REQUIRE(mode >= 0 && mode <= 5 && bytes >= 0 && dst, "bad membench arguments");
+    DYD_REQUIRE(mode >= 0 && mode <= 8 && bytes >= 0 && dst, "bad membench arguments");
+    if (mode >= 6) {   // random access over the largest power-of-two number of 8-byte words in `bytes` of dst
+        int k = 0;
+        while (((int64_t)8 << (k + 1)) <= bytes) ++k;
+        DYD_REQUIRE(bytes >= 8, "bad membench arguments");
+        if (blocks <= 0) blocks = ctx().num_cu * 8;
+        hipStream_t st = pick_stream(stream);
+        unsigned long long *t = static_cast<unsigned long long *>(dst);
+        unsigned long long *sink = const_cast<unsigned long long *>(static_cast<const unsigned long long *>(src ? src : dst));
+        if (mode == 6) hipLaunchKernelGGL(k0_random<6>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
+        else if (mode == 7) hipLaunchKernelGGL(k0_random<7>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
+        else hipLaunchKernelGGL(k0_random<8>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
+        DYD_HIP(hipGetLastError());
+        return DYD_OK;
+    }
     const int64_t n16 = bytes / 16;
     if (n16 == 0) return DYD_OK;
     if (blocks <= 0) blocks = ctx().num_cu * 8;

@@ -308,8 +308,9 @@ void dyd_host_free(void *p);
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging; "k7_variant": -1 by the table's shape (default),
  * 2 / 22 row tiles (one / two per ticket), 30 box tiles (rows of many boxes). */
 int dyd_set_option(const char *key, int64_t value);
-/* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 16 B per
- * lane) used to record the box's HBM ceiling next to the kernels' achieved GB/s. */
+/* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 3-5 the same non-temporal, 16 B per
+ * lane) used to record the box's HBM ceiling next to the kernels' achieved GB/s; modes 6 / 7 / 8: one 8-byte word per lane
+ * at a pseudo-random place of `dst` (scatter / gather / atomicMin, every word once) — the ceiling K4/K5/K6 are quoted against. */
 int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream);
 
 #ifdef __cplusplus

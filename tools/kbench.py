@@ -103,6 +103,16 @@ def main():
         med, mn = timeit(lambda: dst.copy_(src))
         report("torch_d2d_copy", 2 * nb_, med, mn)
         del src, dst
+    if "rand" in only:
+        # random-access ceilings (one 8-byte word per lane, every word of the table once): what K4/K5/K6 are quoted against
+        for k in (24, 27):                       # 128 MiB (inside the 256 MiB Infinity Cache) and 1 GiB tables
+            words = 1 << k
+            table = torch.zeros(words, dtype=torch.int64, device=dev)
+            for mode, nm in ((6, "scatter"), (7, "gather"), (8, "atomic_min")):
+                med, mn = timeit(lambda: ck(L.dyd_membench_dev(mode, table.data_ptr(), table.data_ptr(), 8 * words, 8192, sp), "mb"))
+                print(json.dumps({"kernel": f"membench_random_{nm}_{8 * words >> 20}MiB", "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                                  "words": words, "G_words_per_s": round(words / med / 1e6, 2), "useful_GBs": round(8 * words / med / 1e6, 1)}), flush=True)
+            del table
 
     if "k2" in only:
         ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
