@@ -62,7 +62,8 @@ __global__ __launch_bounds__(K0_BLOCK) void k0_random(unsigned long long *__rest
         const uint64_t j = mix_bits((uint64_t)i, k);
         if (MODE == 6) table[j] = (unsigned long long)i;
         else if (MODE == 7) acc ^= table[j];
-        else atomicMin(&table[j], (unsigned long long)i);
+        else if (MODE == 8) atomicMin(&table[j], (unsigned long long)i);
+        else reinterpret_cast<unsigned int *>(table)[j] = (unsigned int)i;   // mode 9: 4-byte scatter over 2^k 4-byte words
     }
     if (MODE == 7 && acc == 0x9e3779b97f4a7c15ull) sink[0] = acc;
 }
@@ -73,10 +74,11 @@ using namespace dyd;
 
 extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream) {
     DYD_API_ENTER();
-    DYD_REQUIRE(mode >= 0 && mode <= 8 && bytes >= 0 && dst, "bad membench arguments");
+    DYD_REQUIRE(mode >= 0 && mode <= 9 && bytes >= 0 && dst, "bad membench arguments");
     if (mode >= 6) {   // random access over the largest power-of-two number of 8-byte words in `bytes` of dst
         int k = 0;
-        while (((int64_t)8 << (k + 1)) <= bytes) ++k;
+        const int64_t word = (mode == 9) ? 4 : 8;
+        while ((word << (k + 1)) <= bytes) ++k;
         DYD_REQUIRE(bytes >= 8, "bad membench arguments");
         if (blocks <= 0) blocks = ctx().num_cu * 8;
         hipStream_t st = pick_stream(stream);
@@ -84,7 +86,8 @@ extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t by
         unsigned long long *sink = const_cast<unsigned long long *>(static_cast<const unsigned long long *>(src ? src : dst));
         if (mode == 6) hipLaunchKernelGGL(k0_random<6>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
         else if (mode == 7) hipLaunchKernelGGL(k0_random<7>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
-        else hipLaunchKernelGGL(k0_random<8>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
+        else if (mode == 8) hipLaunchKernelGGL(k0_random<8>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
+        else hipLaunchKernelGGL(k0_random<9>, dim3(blocks), dim3(K0_BLOCK), 0, st, t, k, sink);
         DYD_HIP(hipGetLastError());
         return DYD_OK;
     }

@@ -100,6 +100,7 @@ int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_
 void set_k1_variant(int v);
 void set_k2_variant(int v);
 void set_k7_variant(int v);
+void set_k6_variant(int v);
 void set_k7_trace(void *p);
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
@@ -174,6 +175,10 @@ int dyd_set_option(const char *key, int64_t value) {
     }
     if (!strcmp(key, "k2_variant")) {
         set_k2_variant((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "k6_variant")) {
+        set_k6_variant((int)value);
         return DYD_OK;
     }
     if (!strcmp(key, "k7_variant")) {

@@ -125,16 +125,38 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_invert(const int64_t *__restrict_
     if (p >= 0 && p < size) inv[base + p] = k - base;  // guarded: a malformed perm cannot write out of range
 }
 
+// The same into a table of 32-bit positions (n < 2^32): half the table, half of it again resident in the 256 MiB Infinity
+// Cache — a random scatter runs at 86 G words/s while its target fits that cache and at 27 G words/s into a 1 GiB table,
+// whatever the word size (k0_membench modes 6 / 9).  At 165 M records 4.87 -> 2.77 ms.  (Sweeping the permutation once per
+// 256 MiB window of the table, so that every scatter stays inside the cache, was measured too: the extra sweeps cost
+// more than the scatter gains — 6.4 ms for K6 with 256 MiB windows, 5.2 with 512 MiB, 4.8 with one sweep.)
+__global__ __launch_bounds__(K6_BLOCK) void k6_invert32(const int64_t *__restrict__ perm,
+                                                        const int64_t *__restrict__ cat_off, int32_t n_cat,
+                                                        int64_t total, uint32_t *__restrict__ inv) {
+    const int64_t k = (int64_t)blockIdx.x * K6_BLOCK + threadIdx.x;
+    if (k >= total) return;
+    int lo = 0, hi = n_cat;  // largest c with cat_off[c] <= k
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cat_off[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int64_t base = cat_off[lo];
+    const int64_t size = cat_off[lo + 1] - base;
+    const int64_t p = perm[k];
+    if (p >= 0 && p < size) inv[base + p] = (uint32_t)(k - base);  // guarded as above
+}
+
 // pass C: ranks -> positions -> split ids for the categories of the window
+template <class INV>
 __global__ __launch_bounds__(K6_BLOCK) void k6_assign(const int32_t *__restrict__ cat, int64_t n, int32_t c0,
                                                       int32_t c1, int64_t n_tiles,
                                                       const unsigned int *__restrict__ hist,
                                                       const unsigned long long *__restrict__ chunk_off,
-                                                      int64_t n_chunks, const int64_t *__restrict__ inv,
+                                                      int64_t n_chunks, const INV *__restrict__ inv,
                                                       const int64_t *__restrict__ cat_off,
                                                       const int64_t *__restrict__ n_train,
                                                       const int64_t *__restrict__ n_val,
-                                                      const int64_t *__restrict__ rank_base,
+                                                      const int64_t *__restrict__ rank_base, int32_t n_cat,
                                                       uint8_t *__restrict__ out_split, int64_t *__restrict__ out_pos) {
     __shared__ unsigned int s_cnt[K6_WAVES][K6_CATS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -174,17 +196,20 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_assign(const int32_t *__restrict_
             int64_t pos = -1;
             uint8_t sp = 255;
             if (rank < size) {  // guarded: cat_off must cover the category's rows
-                pos = inv[base + rank];
+                pos = (int64_t)inv[base + rank];
                 const int64_t a = n_train[c], b = n_val[c];
                 sp = pos < a ? 0 : (pos < a + b ? 1 : 2);
             }
             out_pos[r] = pos;
             out_split[r] = sp;
+        } else if (c0 == 0 && r < r1 && (c < 0 || c >= n_cat)) {   // unclassified rows ride along with the first window
+            out_pos[r] = -1;
+            out_split[r] = 255;
         }
     }
 }
 
-// rows whose category is outside [0, n_cat): unclassified
+// rows whose category is outside [0, n_cat): unclassified (own launch only when there is no category at all)
 __global__ __launch_bounds__(K6_BLOCK) void k6_unclassified(const int32_t *__restrict__ cat, int64_t n,
                                                             int32_t n_cat, uint8_t *__restrict__ out_split,
                                                             int64_t *__restrict__ out_pos) {
@@ -197,13 +222,18 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_unclassified(const int32_t *__res
     }
 }
 
+// dyd_set_option("k6_variant"): 1 = 32-bit inverse-permutation table (default), 0 = 64-bit (A/B)
+static int g_k6_variant = 1;
+void set_k6_variant(int v) { g_k6_variant = v ? 1 : 0; }
+
 static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, const int64_t *cat_off,
                         const int64_t *n_train, const int64_t *n_val, int32_t n_cat, int64_t total,
                         const int64_t *rank_base, uint8_t *out_split, int64_t *out_pos, hipStream_t st) {
     const int64_t n_tiles = ceil_div(n, K6_TILE);
     const int64_t blocks = ceil_div(n_tiles, K6_WAVES);
     const int32_t win = n_cat < K6_CATS ? n_cat : K6_CATS;
-    const size_t inv_bytes = (size_t)(total > 0 ? total : 1) * 8;
+    const bool narrow = g_k6_variant != 0;   // 32-bit inverse table (n < 2^32 is required at the entry points)
+    const size_t inv_bytes = (((size_t)(total > 0 ? total : 1) * (narrow ? 4 : 8)) + 15) & ~(size_t)15;
     const size_t hist_bytes = (((size_t)(win > 0 ? win : 1) * (size_t)n_tiles * 4) + 15) & ~(size_t)15;
     const int64_t n_chunks = ceil_div(n_tiles, K6_SCAN_CHUNK);
     const size_t tot_bytes = (size_t)(win > 0 ? win : 1) * (size_t)n_chunks * 8;
@@ -214,13 +244,19 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
     unsigned int *hist = reinterpret_cast<unsigned int *>(static_cast<char *>(scr) + inv_bytes);
     unsigned long long *chunk_tot =
         reinterpret_cast<unsigned long long *>(static_cast<char *>(scr) + inv_bytes + hist_bytes);
-    hipLaunchKernelGGL(k6_unclassified, dim3((unsigned)ceil_div(n, K6_BLOCK)), dim3(K6_BLOCK), 0, st, cat, n, n_cat,
-                       out_split, out_pos);
-    DYD_HIP(hipGetLastError());
+    if (n_cat == 0) {
+        hipLaunchKernelGGL(k6_unclassified, dim3((unsigned)ceil_div(n, K6_BLOCK)), dim3(K6_BLOCK), 0, st, cat, n, n_cat,
+                           out_split, out_pos);
+        DYD_HIP(hipGetLastError());
+    }
     if (total > 0) {
         DYD_HIP(hipMemsetAsync(inv, 0, inv_bytes, st));
-        hipLaunchKernelGGL(k6_invert, dim3((unsigned)ceil_div(total, K6_BLOCK)), dim3(K6_BLOCK), 0, st, perm, cat_off,
-                           n_cat, total, inv);
+        if (narrow)
+            hipLaunchKernelGGL(k6_invert32, dim3((unsigned)ceil_div(total, K6_BLOCK)), dim3(K6_BLOCK), 0, st, perm, cat_off, n_cat,
+                               total, reinterpret_cast<uint32_t *>(inv));
+        else
+            hipLaunchKernelGGL(k6_invert, dim3((unsigned)ceil_div(total, K6_BLOCK)), dim3(K6_BLOCK), 0, st, perm, cat_off,
+                               n_cat, total, inv);
         DYD_HIP(hipGetLastError());
     }
     for (int32_t c0 = 0; c0 < n_cat; c0 += K6_CATS) {
@@ -232,8 +268,13 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
         DYD_HIP(hipGetLastError());
         hipLaunchKernelGGL(k6_scan_totals, dim3((unsigned)(c1 - c0)), dim3(kWave), 0, st, chunk_tot, n_chunks);
         DYD_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k6_assign, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist,
-                           chunk_tot, n_chunks, inv, cat_off, n_train, n_val, rank_base, out_split, out_pos);
+        if (narrow)
+            hipLaunchKernelGGL(k6_assign<uint32_t>, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist,
+                               chunk_tot, n_chunks, reinterpret_cast<const uint32_t *>(inv), cat_off, n_train, n_val, rank_base,
+                               n_cat, out_split, out_pos);
+        else
+            hipLaunchKernelGGL(k6_assign<int64_t>, dim3((unsigned)blocks), dim3(K6_BLOCK), 0, st, cat, n, c0, c1, n_tiles, hist,
+                               chunk_tot, n_chunks, inv, cat_off, n_train, n_val, rank_base, n_cat, out_split, out_pos);
         DYD_HIP(hipGetLastError());
     }
     release_scratch(st);

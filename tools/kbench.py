@@ -105,13 +105,13 @@ def main():
         del src, dst
     if "rand" in only:
         # random-access ceilings (one 8-byte word per lane, every word of the table once): what K4/K5/K6 are quoted against
-        for k in (24, 27):                       # 128 MiB (inside the 256 MiB Infinity Cache) and 1 GiB tables
-            words = 1 << k
-            table = torch.zeros(words, dtype=torch.int64, device=dev)
-            for mode, nm in ((6, "scatter"), (7, "gather"), (8, "atomic_min")):
-                med, mn = timeit(lambda: ck(L.dyd_membench_dev(mode, table.data_ptr(), table.data_ptr(), 8 * words, 8192, sp), "mb"))
-                print(json.dumps({"kernel": f"membench_random_{nm}_{8 * words >> 20}MiB", "ms_median": round(med, 4), "ms_min": round(mn, 4),
-                                  "words": words, "G_words_per_s": round(words / med / 1e6, 2), "useful_GBs": round(8 * words / med / 1e6, 1)}), flush=True)
+        for mib in (32, 64, 128, 256, 512, 1024, 2048):          # around the 256 MiB Infinity Cache
+            table = torch.zeros(mib << 17, dtype=torch.int64, device=dev)
+            for mode, nm, word in ((6, "scatter", 8), (9, "scatter4", 4), (7, "gather", 8), (8, "atomic_min", 8)):
+                words = (mib << 20) // word
+                med, mn = timeit(lambda: ck(L.dyd_membench_dev(mode, table.data_ptr(), table.data_ptr(), mib << 20, 8192, sp), "mb"))
+                print(json.dumps({"kernel": f"membench_random_{nm}_{mib}MiB", "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                                  "words": words, "G_words_per_s": round(words / med / 1e6, 2), "useful_GBs": round(word * words / med / 1e6, 1)}), flush=True)
             del table
 
     if "k2" in only:
@@ -194,6 +194,30 @@ def main():
                                                          pos.data_ptr(), sp), "k6"))
         report("k6_split_ids", 21 * E, med, mn, expanded_rows=E, rows_per_s=round(E / med * 1e3))
 
+    if "k6big" in only:
+        # the 10 M-row pipeline's K6 (165 M expanded rows): the inverse-permutation table no longer fits the Infinity Cache
+        E = int(os.environ.get("K6_ROWS", 165_000_000))
+        g = torch.Generator(device=dev).manual_seed(3)
+        lab = torch.randint(0, 20, (E,), generator=g, device=dev, dtype=torch.int32)
+        cat = torch.where(lab < 10, 0, torch.where(lab < 18, 1, -1)).to(torch.int32).contiguous()
+        del lab
+        sizes = [int((cat == c).sum().item()) for c in (0, 1)]
+        perm = torch.cat([torch.randperm(s, generator=g, device=dev) for s in sizes]).contiguous()
+        cat_off = torch.tensor([0, sizes[0], sizes[0] + sizes[1]], dtype=torch.int64, device=dev)
+        n_train = torch.tensor([int(s * 0.8) for s in sizes], dtype=torch.int64, device=dev)
+        n_val = torch.tensor([int(s * 0.1) for s in sizes], dtype=torch.int64, device=dev)
+        split = torch.empty(E, dtype=torch.uint8, device=dev); pos = torch.empty(E, dtype=torch.int64, device=dev)
+        ref = None
+        for mib in [int(v) for v in os.environ.get("K6V", "0,1,0,1").split(",")]:   # 0 = 64-bit inverse table, 1 = 32-bit (default)
+            ck(L.dyd_set_option(b"k6_variant", mib), "opt")
+            med, mn = timeit(lambda: ck(L.dyd_split_ids_dev(cat.data_ptr(), E, perm.data_ptr(), cat_off.data_ptr(), n_train.data_ptr(),
+                                                             n_val.data_ptr(), 2, split.data_ptr(), pos.data_ptr(), sp), "k6"), iters=10, warm=2)
+            chk = (int(pos.sum().item()), int(split.to(torch.int64).sum().item()))
+            ref = ref or chk
+            report(f"k6_split_ids_165M_{'32' if mib else '64'}bit_inverse", 21 * E, med, mn, expanded_rows=E, same_as_first=(chk == ref))
+        ck(L.dyd_set_option(b"k6_variant", 1), "opt")
+        del cat, perm, split, pos
+
     if "k7" in only:
         import ctypes as C
         # the shape of a split sheet: one labelled box per expanded row; boxes = K1's output for the synthetic polygons
@@ -208,7 +232,6 @@ def main():
                                 toff.data_ptr(), flag.data_ptr(), None, 0, C.byref(total), sp), "k7 measure")
         T = total.value
         text = torch.empty(T, dtype=torch.uint8, device=dev)
-        import os
         modes = os.environ.get("K7MODE", "full,measure").split(",")
         for variant in [int(v) for v in os.environ.get("K7V", "2,22,30,-1").split(",")]:
             ck(L.dyd_set_option(b"k7_variant", variant), "opt")
