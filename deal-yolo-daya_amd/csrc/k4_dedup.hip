@@ -47,8 +47,10 @@ __global__ __launch_bounds__(K4_BLOCK) void k4_insert(const ulonglong2 *__restri
             cur = (long long)prev;
         }
         if (key_eq(keys[cur], k)) {
-            if (mode == DYD_KEEP_FIRST) atomicMin(&tab[slot], (long long)i);
-            else if (mode == DYD_KEEP_LAST) atomicMax(&tab[slot], (long long)i);
+            // the slot only ever moves towards the winner, so a value already at least as good as this row makes the
+            // atomic a no-op: skipped (rows run roughly in index order, so with keep=first most duplicates skip it)
+            if (mode == DYD_KEEP_FIRST) { if (cur > (long long)i) atomicMin(&tab[slot], (long long)i); }
+            else if (mode == DYD_KEEP_LAST) { if (cur < (long long)i) atomicMax(&tab[slot], (long long)i); }
             else atomicAdd(&cnt[slot], 1u);
             return;
         }
