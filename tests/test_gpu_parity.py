@@ -293,3 +293,58 @@ def test_sharded_functions_world1_rccl(native):
         assert gtext == otext and gtotal == len(otext) and np.array_equal(goff, ooff) and np.array_equal(gflag, oflag)
     finally:
         dist.destroy_process_group()
+
+
+def test_whole_chain_with_label_replace_matches_the_cpu_port(native, tmp_path, monkeypatch):
+    """dedup -> ref filter -> replace -> IoU -> label_replace -> split -> label texts, CSV in / CSV out where the
+    reference has files, product (HIP + native host code) against the CPU port step by step on one synthetic table"""
+    from deal_yolo_daya_amd import synth
+    from deal_yolo_daya_amd.core import processor as P
+    from oracle import steps as osteps
+
+    n = 1500
+    df = synth.to_frame(synth.generate(n, seed=77, max_boxes=8))
+    df = pd.concat([df, df.iloc[::7]], ignore_index=True)                      # duplicates for the dedup step
+    mapping = pd.DataFrame({"old": [f"c{i}" for i in range(0, 20, 3)], "new": ["c1", "c2", "c1", "c30", "c4", "c2", "c1"]})
+    monkeypatch.setattr(pd, "read_excel", lambda *a, **k: mapping.copy())
+    monkeypatch.setattr(pd.DataFrame, "to_excel", lambda self, *a, **k: None)
+    Q = lambda name: str(tmp_path / name)  # noqa: E731
+    df.to_csv(Q("in.csv"), index=False, encoding="utf-8-sig")
+    pd.DataFrame({"source": synth.reference_urls(n)}).to_csv(Q("ref.csv"), index=False, encoding="utf-8-sig")
+
+    def same(a, b):
+        return open(Q(a), "rb").read() == open(Q(b), "rb").read()
+
+    P.deduplicate_csv_by_source(Q("in.csv"), Q("p1.csv"), verbose=False)
+    osteps.dedup_csv(Q("in.csv"), Q("o1.csv"))
+    assert same("p1.csv", "o1.csv")
+    P.remove_duplicates_between_csv(Q("p1.csv"), Q("ref.csv"), Q("p2.csv"), verbose=False)
+    osteps.ref_filter_csv(Q("o1.csv"), Q("ref.csv"), Q("o2.csv"))
+    assert same("p2.csv", "o2.csv")
+    P.process_csv_replace_ptlist(Q("p2.csv"), Q("p3.csv"), Q("p3e.csv"))
+    osteps.replace_csv(Q("o2.csv"), Q("o3.csv"), Q("o3e.csv"))
+    assert same("p3.csv", "o3.csv") and same("p3e.csv", "o3e.csv")
+    P.filter_by_box_count_and_iou(Q("p3.csv"), Q("p4h.csv"), Q("p4o.csv"), 2, 0.98)
+    osteps.iou_filter_csv(Q("o3.csv"), Q("o4h.csv"), Q("o4o.csv"), 2, 0.98)
+    assert same("p4h.csv", "o4h.csv") and same("p4o.csv", "o4o.csv")
+    res = P.replace_labels_by_mapping(Q("p4o.csv"), "map.xlsx", Q("p5.csv"), diff_excel_path=Q("d.xlsx"), unmatched_excel_path=Q("u.xlsx"))
+    want = osteps.label_replace_csv(Q("o4o.csv"), mapping, Q("o5.csv"), diff_excel_path="d", unmatched_excel_path="u")
+    assert same("p5.csv", "o5.csv") and res["summary"] == want["summary"] and res["sample_diff"] == want["sample_diff"]
+    assert res["summary"]["replaced_labels"] > 1000 and P.LAST_IO_PATH["label_replace"] == "native"
+
+    table = pd.read_csv(Q("p5.csv"), encoding="utf-8-sig")
+    rules = pd.DataFrame({"catA": [f"c{i}" for i in range(1, 9)], "catB": [f"c{i}" for i in range(10, 18)]})
+    lmap = P.rules_to_label_map(rules)
+    got, exp = P.split_frames(table, lmap), osteps.split_frames(table, osteps.rules_to_map(rules))
+    assert list(got["categories"]) == list(exp["categories"])
+    for cat in exp["categories"]:
+        for a, b in zip(got["categories"][cat], exp["categories"][cat]):
+            assert a.equals(b)
+    assert got["unclassified"].equals(exp["unclassified"]) and got["split_counts"].equals(exp["split_counts"])
+    sheet = got["categories"]["catA"][0]
+    labels = sheet["分类标签"].tolist()
+    classes = sorted(set(labels))
+    cids = [classes.index(v) for v in labels]
+    texts, _ = P.yolo_label_texts(sheet[P.BBOX_COL].tolist(), labels, cids, sheet["width"].tolist(), sheet["height"].tolist())
+    assert texts == [osteps.yolo_row_text(c, lab, k, w, h)[0] for c, lab, k, w, h in
+                     zip(sheet[P.BBOX_COL], labels, cids, sheet["width"], sheet["height"])] and any(texts)
