@@ -158,15 +158,23 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                     const int32_t trips = ((n & 1) == 0 && i >= half) ? half - 1 : half;
                     bool hit = false;
                     if (S.nan[lr] == 0) {
+                        // two partners per turn, each in its own registers: the next partner is loaded while the current one
+                        // is tested, and no register copy is needed to hand it over (one load past the last trip at most; it
+                        // stays inside the row)
                         int32_t j = (i + 1 >= n) ? i + 1 - n : i + 1;
-                        Corners nxt = {S.c.x1[rs + j], S.c.y1[rs + j], S.c.x2[rs + j], S.c.y2[rs + j]};
-                        for (int32_t d = 1; d <= trips; ++d) {
-                            const Corners o = nxt;
+                        Corners a = {S.c.x1[rs + j], S.c.y1[rs + j], S.c.x2[rs + j], S.c.y2[rs + j]};
+                        int32_t d = 1;
+                        for (; d < trips; d += 2) {
                             j = (j + 1 >= n) ? 0 : j + 1;
-                            const int32_t kj = rs + j;
-                            nxt.x1 = S.c.x1[kj]; nxt.y1 = S.c.y1[kj]; nxt.x2 = S.c.x2[kj]; nxt.y2 = S.c.y2[kj];
-                            hit |= pair_hits<false, true>(me, o, me_ar, o, thr, thr_lo, zero_hits, unused_mx);
+                            const int32_t kb = rs + j;
+                            const Corners b = {S.c.x1[kb], S.c.y1[kb], S.c.x2[kb], S.c.y2[kb]};
+                            hit |= pair_hits<false, true>(me, a, me_ar, a, thr, thr_lo, zero_hits, unused_mx);
+                            j = (j + 1 >= n) ? 0 : j + 1;
+                            const int32_t ka = rs + j;
+                            a.x1 = S.c.x1[ka]; a.y1 = S.c.y1[ka]; a.x2 = S.c.x2[ka]; a.y2 = S.c.y2[ka];
+                            hit |= pair_hits<false, true>(me, b, me_ar, b, thr, thr_lo, zero_hits, unused_mx);
                         }
+                        if (d == trips) hit |= pair_hits<false, true>(me, a, me_ar, a, thr, thr_lo, zero_hits, unused_mx);
                     } else {  // a NaN in the row: keep the reference's (i < j) argument order
                         for (int32_t d = 1; d <= trips; ++d) {
                             int32_t j = i + d;
