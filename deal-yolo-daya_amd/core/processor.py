@@ -15,8 +15,8 @@ and, either side of them, ``merge_all_csv_in_folder`` (r
 CSV hand-off) and the label-line arithmetic of generate_yolo_datasets_from_excels
 (reference processor.py:1001-1060) as ``yolo_label_texts`` -> K7.  The rest of what the processing page imports from this
 module is here as host-only steps: ``replace_labels_by_mapping`` (pipeline step label_replace, reference :516-652, native
-relabeller), ``summarize_unclassified`` (:833-891), ``summarize_yolo_label_counts`` (:1089-1162) and
-``overwrite_reference_with_result`` (:221-227); only the drawing helper is left out.
+relabeller), ``summarize_unclassified`` (:833-891), ``summarize_yolo_label_counts`` (:1089-1162),
+``overwrite_reference_with_result`` (:221-227) and ``download_and_draw_annotations`` (:409-514).
 
 Each step is  flatten (cells -> SoA numpy buffers)  ->  device stage (HIP kernels behind
 include/dyd.h)  ->  emit (masks / indices back into pandas).  Every step also has a
@@ -1732,3 +1732,106 @@ def summarize_yolo_label_counts(dataset_dirs):
         rows += [{"数据集": root.name, "split": "all", "标签": k, "图片数量": all_img.get(k, 0), "标注框数量": all_box.get(k, 0),
                   "占比%": pct(all_img.get(k, 0), all_images), "split总图片数": all_images} for k in set(all_img) | set(all_box)]
     return stats, pd.DataFrame(rows)
+
+
+# =============================================================================== step "download": annotated images
+def _annotation_shapes(json_str):
+    """(name, [(x, y), ...]) of every object of an annotation cell that can be drawn (reference processor.py:447-462): dict
+    objects, the points being the dict entries of polygon.ptList whose x and y are both present and not null; fewer than
+    two points: nothing to draw.  Whatever goes wrong while walking the cell ends the walk quietly — the shapes before
+    it are kept, as the reference's try / except around its drawing loop keeps what it has drawn."""
+    if not isinstance(json_str, str):
+        return
+    try:
+        for obj in json.loads(json_str).get("objects", []):
+            if not isinstance(obj, dict):
+                continue
+            name = obj.get("name", "未知类别")
+            points = [(p["x"], p["y"]) for p in obj.get("polygon", {}).get("ptList", [])
+                      if isinstance(p, dict) and p.get("x") is not None and p.get("y") is not None]
+            if len(points) >= 2:
+                yield name, points
+    except Exception:  # noqa: BLE001
+        return
+
+
+def _draw_shapes(draw, shapes, colour, font):
+    """two points: a rectangle; more: the polygon; the name on a white patch 20 px above the first / top-left point"""
+    try:
+        for name, points in shapes:
+            if len(points) == 2:
+                (x1, y1), (x2, y2) = points
+                draw.rectangle([x1, y1, x2, y2], outline=colour, width=2)
+                anchor = (x1, y1 - 20)
+            else:
+                draw.polygon(points, outline=colour, width=2)
+                anchor = (min(p[0] for p in points), min(p[1] for p in points) - 20)
+            draw.rectangle(draw.textbbox(anchor, name, font=font), fill=(255, 255, 255, 180))
+            draw.text(anchor, name, font=font, fill=colour)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def download_and_draw_annotations(
+        input_csv_path,
+        output_dir: Optional[str] = None,
+        download_dir: Optional[str] = None,
+        result_dir: Optional[str] = None,
+        max_images: Optional[int] = None,
+        timeout: int = 15
+):
+    """Drop-in for reference processor.py:409-514 (pipeline step ``download``): every row's image — taken from
+    ``download_dir`` when it is there, fetched otherwise — with the original annotation drawn in red and the replaced one
+    in green, saved under ``result_dir``.  Host-only (Pillow, requests); rows whose image cannot be had or opened count
+    as processed and are skipped; ``max_images`` bounds the rows processed, successful or not."""
+    import requests
+    from PIL import Image, ImageDraw, ImageFont
+
+    base_dir = Path(output_dir) if output_dir else Path(os.getcwd())
+    download_dir = Path(download_dir) if download_dir else base_dir / "downloaded_images"
+    result_dir = Path(result_dir) if result_dir else base_dir / "annotated_images"
+    download_dir.mkdir(parents=True, exist_ok=True)
+    result_dir.mkdir(parents=True, exist_ok=True)
+    try:
+        df = pd.read_csv(input_csv_path, encoding="utf-8-sig")
+    except Exception as e:  # noqa: BLE001
+        print(f"读取CSV失败：{e}")
+        return
+    if not {"source", ANNOTATION_COL, BBOX_COL} <= set(df.columns):
+        print("CSV缺少必要列")
+        return
+
+    font = None
+    for face in ("simhei.ttf", "Arial Unicode.ttf"):                     # :434-441
+        try:
+            font = ImageFont.truetype(face, 48)
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    if font is None:
+        font = ImageFont.load_default()
+
+    processed = 0
+    for idx, source_url, before, after in zip(df.index, df["source"].tolist(), df[ANNOTATION_COL].tolist(), df[BBOX_COL].tolist()):
+        if max_images is not None and processed >= max_images:
+            break
+        processed += 1                                                   # success or failure, the row counts
+        filename = source_url.split("/")[-1] if "/" in source_url else f"image_{idx}.jpg"
+        local = download_dir / filename
+        if not os.path.exists(local):
+            try:
+                response = requests.get(source_url, stream=True, timeout=timeout)
+                response.raise_for_status()
+                with open(local, "wb") as f:
+                    for chunk in response.iter_content(chunk_size=8192):
+                        f.write(chunk)
+            except Exception:  # noqa: BLE001
+                continue
+        try:
+            with Image.open(local) as img:
+                draw = ImageDraw.Draw(img)
+                _draw_shapes(draw, _annotation_shapes(before), (255, 0, 0), font)
+                _draw_shapes(draw, _annotation_shapes(after), (0, 255, 0), font)
+                img.save(result_dir / filename)
+        except Exception:  # noqa: BLE001
+            continue

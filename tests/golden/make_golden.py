@@ -15,6 +15,7 @@ tests or vectors of its own, so these outputs are what pins oracle/ and the HIP 
     yolo_cases.json      f4 _extract_boxes_with_labels + the label files generate_yolo_datasets_from_excels writes
     merge_case.json      f3 merge_all_csv_in_folder: input files, merged bytes, progress-callback arguments, printed lines
     label_replace_case.json  replace_labels_by_mapping (the step between a4 and a5): output CSV, summary, diff / unmatched sheets, raising cells
+    draw_case.json       download_and_draw_annotations (pipeline step "download") on images already on disk: the annotated PNGs
     summaries_case.json  summarize_unclassified (three sheets) and summarize_yolo_label_counts (stats + flat rows) on small inputs
 
 Usage:  python tests/golden/make_golden.py [name ...]      (no names: everything)
@@ -804,9 +805,66 @@ def make_summaries():
     _dump("summaries_case.json", out)
 
 
+# ------------------------------------------------------------------------------- step "download": annotated images
+def make_draw():
+    """download_and_draw_annotations on images that are already in the download directory (no network here): the
+    annotated PNGs it writes, byte for byte, plus the rows it gives up on (a connection refused at once, a broken file)"""
+    import base64
+    from PIL import Image
+
+    def png(w, h, colour):
+        buf = io.BytesIO()
+        Image.new("RGB", (w, h), colour).save(buf, format="PNG")
+        return buf.getvalue()
+
+    images = {"a.png": png(96, 80, (10, 20, 30)), "b.png": png(64, 64, (200, 200, 200)), "image_3.jpg": png(50, 40, (0, 0, 0)),
+              "broken.png": b"not an image", "d.png": png(40, 40, (255, 255, 255)), "e.png": png(32, 32, (1, 2, 3))}
+    rows = [
+        ("http://img.example/a.png", '{"objects": [{"name": "cat", "polygon": {"ptList": [{"x": 5, "y": 30}, {"x": 60, "y": 70}]}}, {"name": "多边形", "polygon": {"ptList": [{"x": 10, "y": 10}, {"x": 40.5, "y": 12}, {"x": 30, "y": 35.25}]}}]}',
+         '{"objects": [{"name": "cat", "polygon": {"ptList": [{"x": 6, "y": 31}, {"x": 59, "y": 69}]}}]}'),
+        ("http://img.example/dir/b.png", '{"objects": [{"polygon": {"ptList": [{"x": 1, "y": 25}, {"x": null, "y": 3}, {"x": 30, "y": 60}]}}, 7, {"name": "one", "polygon": {"ptList": [{"x": 1, "y": 2}]}}, {"name": "nopoly"}]}', np.nan),
+        ("http://127.0.0.1:9/missing.png", '{"objects": []}', '{"objects": []}'),
+        ("local-name-without-slash", '{"objects": [{"name": 5, "polygon": {"ptList": [{"x": 2, "y": 22}, {"x": 20, "y": 38}]}}]}', '{"objects": ['),
+        ("http://img.example/broken.png", '{"objects": []}', '{"objects": []}'),
+        ("http://img.example/d.png", '[1, 2]', '{"objects": [{"name": "late", "polygon": {"ptList": [{"x": 30, "y": 30}, {"x": 10, "y": 25}]}}, {"name": "bad", "polygon": {"ptList": "zz"}}, {"name": "after", "polygon": {"ptList": [{"x": 1, "y": 25}, {"x": 9, "y": 39}]}}]}'),
+        ("http://img.example/e.png", '{"objects": [{"name": "x", "polygon": {"ptList": [{"x": 3, "y": 25}, {"x": 20, "y": 30}]}}]}', '{}'),
+    ]
+    df = pd.DataFrame(rows, columns=["source", ANN, NEW])
+    out = {"input": _frame_records(df), "images": {k: base64.b64encode(v).decode() for k, v in images.items()}, "runs": {}}
+    for name, max_images in (("all", None), ("first_three", 3)):
+        with tempfile.TemporaryDirectory() as d:
+            inp = os.path.join(d, "in.csv")
+            df.to_csv(inp, index=False, encoding="utf-8-sig")
+            os.makedirs(os.path.join(d, "out", "downloaded_images"))
+            for k, v in images.items():
+                with open(os.path.join(d, "out", "downloaded_images", k), "wb") as f:
+                    f.write(v)
+            buf = io.StringIO()
+            import contextlib
+            with contextlib.redirect_stdout(buf):
+                ret = ref.download_and_draw_annotations(inp, os.path.join(d, "out"), None, None, max_images, 2)
+            res_dir = os.path.join(d, "out", "annotated_images")
+            out["runs"][name] = {"max_images": max_images, "returned_none": ret is None, "printed": buf.getvalue(),
+                                 "annotated": {fn: base64.b64encode(open(os.path.join(res_dir, fn), "rb").read()).decode()
+                                               for fn in sorted(os.listdir(res_dir))},
+                                 "downloaded": sorted(os.listdir(os.path.join(d, "out", "downloaded_images")))}
+    with tempfile.TemporaryDirectory() as d:       # the two early returns
+        buf = io.StringIO()
+        import contextlib
+        with contextlib.redirect_stdout(buf):
+            r1 = ref.download_and_draw_annotations(os.path.join(d, "nope.csv"), os.path.join(d, "o1"))
+            pd.DataFrame({"source": ["a"]}).to_csv(os.path.join(d, "few.csv"), index=False, encoding="utf-8-sig")
+            r2 = ref.download_and_draw_annotations(os.path.join(d, "few.csv"), os.path.join(d, "o2"))
+        out["early"] = {"printed": buf.getvalue().replace(d, "<tmp>"), "returned": [r1 is None, r2 is None],
+                        "dirs": sorted(os.listdir(os.path.join(d, "o1"))) + sorted(os.listdir(os.path.join(d, "o2")))}
+    import PIL
+    out["pillow"] = PIL.__version__
+    _dump("draw_case.json", out)
+
+
 if __name__ == "__main__":
     makers = {"replace": make_replace, "iou": make_iou, "dedup": make_dedup, "ref_filter": make_ref_filter, "perm": make_perm,
               "split": make_split, "e2e": make_e2e, "yolo": make_yolo, "merge": make_merge, "label_replace": make_label_replace,
-              "summaries": make_summaries}
+              "summaries": make_summaries, "draw": make_draw}
     for name in (sys.argv[1:] or list(makers)):
         makers[name]()

@@ -214,11 +214,10 @@ def test_overwrite_reference_with_result(tmp_path):
 
 
 def test_processing_page_imports_resolve():
-    """every name the reference's processing page takes from core.processor (ui/pages/processing.py:25-38) but the drawing
-    helper, which is visualisation and stays out of scope"""
+    """every name the reference's processing page takes from core.processor (ui/pages/processing.py:25-38)"""
     for name in ("merge_all_csv_in_folder", "deduplicate_csv_by_source", "remove_duplicates_between_csv", "overwrite_reference_with_result",
                  "process_csv_replace_ptlist", "filter_by_box_count_and_iou", "replace_labels_by_mapping", "split_dataset_by_rules",
-                 "summarize_unclassified", "generate_yolo_datasets_from_excels", "summarize_yolo_label_counts"):
+                 "summarize_unclassified", "generate_yolo_datasets_from_excels", "summarize_yolo_label_counts", "download_and_draw_annotations"):
         assert callable(getattr(P, name)), name
 
 
@@ -268,3 +267,39 @@ def test_label_replace_csv_fast_path_raises_like_the_reference(tmp_path, monkeyp
         _run_product(tmp_path, monkeypatch, df, mapping, {})
     assert str(ei.value) == "sequence item 0: expected str instance, int found"
     assert not (tmp_path / "o" / "out.csv").exists()
+
+
+DRAW = load_golden("draw_case.json")
+
+
+@pytest.mark.parametrize("run", sorted(DRAW["runs"]))
+def test_download_and_draw_annotations(tmp_path, capsys, run):
+    """images already in the download directory (no network): the annotated files are the reference's, byte for byte"""
+    import base64
+    import PIL
+    if PIL.__version__ != DRAW["pillow"]:
+        pytest.skip("the fixture's bytes are Pillow %s's" % DRAW["pillow"])
+    want = DRAW["runs"][run]
+    df = _frame(DRAW["input"])
+    inp = tmp_path / "in.csv"
+    df.to_csv(inp, index=False, encoding="utf-8-sig")
+    dl = tmp_path / "out" / "downloaded_images"
+    dl.mkdir(parents=True)
+    for name, b64 in DRAW["images"].items():
+        (dl / name).write_bytes(base64.b64decode(b64))
+    assert P.download_and_draw_annotations(str(inp), str(tmp_path / "out"), None, None, want["max_images"], 2) is None
+    assert capsys.readouterr().out == want["printed"]
+    res = tmp_path / "out" / "annotated_images"
+    assert sorted(p.name for p in res.iterdir()) == sorted(want["annotated"])
+    for name, b64 in want["annotated"].items():
+        assert (res / name).read_bytes() == base64.b64decode(b64), name
+    assert sorted(p.name for p in dl.iterdir()) == want["downloaded"]
+
+
+def test_download_and_draw_annotations_early_returns(tmp_path, capsys):
+    want = DRAW["early"]
+    assert P.download_and_draw_annotations(str(tmp_path / "nope.csv"), str(tmp_path / "o1")) is None
+    pd.DataFrame({"source": ["a"]}).to_csv(tmp_path / "few.csv", index=False, encoding="utf-8-sig")
+    assert P.download_and_draw_annotations(str(tmp_path / "few.csv"), str(tmp_path / "o2")) is None
+    assert capsys.readouterr().out.replace(str(tmp_path), "<tmp>") == want["printed"]
+    assert sorted(p.name for p in (tmp_path / "o1").iterdir()) + sorted(p.name for p in (tmp_path / "o2").iterdir()) == want["dirs"]
