@@ -194,6 +194,20 @@ def main():
                                                          pos.data_ptr(), sp), "k6"))
         report("k6_split_ids", 21 * E, med, mn, expanded_rows=E, rows_per_s=round(E / med * 1e3))
 
+    if "k5big" in only:
+        # the 10 M-row pipeline's K4 / K5 on random 128-bit keys: 10 M rows (60 % distinct), 1 M reference keys, 10 % hits
+        Nk = 10_000_000
+        g = torch.Generator(device=dev).manual_seed(5)
+        base = torch.randint(-2**62, 2**62, (6_000_000, 2), generator=g, device=dev, dtype=torch.int64)
+        hk = base[torch.randint(0, base.shape[0], (Nk,), generator=g, device=dev)].contiguous()
+        refk = torch.cat([base[:100_000], torch.randint(-2**62, 2**62, (900_000, 2), generator=g, device=dev, dtype=torch.int64)]).contiguous()
+        keepk = torch.empty(Nk, dtype=torch.uint8, device=dev)
+        med, mn = timeit(lambda: ck(L.dyd_dedup_dev(hk.data_ptr(), Nk, 0, keepk.data_ptr(), sp), "k4"))
+        report("k4_dedup_first_10M", 16 * Nk + Nk + 48 * 6_000_000, med, mn, rows_per_s=round(Nk / med * 1e3), kept=int(keepk.sum().item()))
+        med, mn = timeit(lambda: ck(L.dyd_isin_dev(hk.data_ptr(), Nk, refk.data_ptr(), refk.shape[0], keepk.data_ptr(), sp), "k5"))
+        report("k5_isin_10M_vs_1M", 16 * Nk + Nk + 16 * refk.shape[0], med, mn, rows_per_s=round(Nk / med * 1e3), hits=int(keepk.sum().item()))
+        del base, hk, refk, keepk
+
     if "k6big" in only:
         # the 10 M-row pipeline's K6 (165 M expanded rows): the inverse-permutation table no longer fits the Infinity Cache
         E = int(os.environ.get("K6_ROWS", 165_000_000))
