@@ -1303,7 +1303,7 @@ using namespace dyd;
 extern "C" {
 
 int dyd_yolo_lines_dev(const double *box4, const int32_t *row_off, const uint8_t *sel_or_null, const double *width,
-                       const double *height, const int32_t *class_id, int64_t n_rows, int64_t *out_text_off,
+                       const double *height, const int32_t *class_id, int64_t n_rows, int64_t n_boxes, int64_t *out_text_off,
                        uint8_t *out_flag, uint8_t *out_text_or_null, int64_t text_cap, int64_t *out_total,
                        void *stream) {
     DYD_API_ENTER();
@@ -1317,7 +1317,7 @@ int dyd_yolo_lines_dev(const double *box4, const int32_t *row_off, const uint8_t
     }
     DYD_REQUIRE(row_off && width && height && class_id && out_flag, "null pointer");
     DYD_REQUIRE(n_rows < (1LL << 40), "n_rows too large");
-    return yolo_launch(box4, row_off, sel_or_null, width, height, class_id, n_rows, -1, out_text_off, out_flag,
+    return yolo_launch(box4, row_off, sel_or_null, width, height, class_id, n_rows, n_boxes, out_text_off, out_flag,
                        out_text_or_null, text_cap, out_total, st);
 }
 

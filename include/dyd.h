@@ -181,13 +181,14 @@ int dyd_split_ids_sharded_dev(const int32_t *cat, int64_t n, const int64_t *cat_
  * dyd_yolo_lines     : host pointers; *out_text is allocated by the library (release with dyd_host_free).
  * dyd_yolo_lines_dev : device pointers; out_text_or_null == NULL only measures (offsets, flags, total);
  *                      otherwise text_cap bytes are available and DYD_ERR_RANGE is returned, with the needed
- *                      size in *out_total, when that is too little.  *out_total is a HOST int64. */
+ *                      size in *out_total, when that is too little.  *out_total is a HOST int64.  n_boxes = row_off[n_rows]
+ *                      (the table's shape picks the kernel; a negative value makes the entry read it back from the device). */
 int dyd_yolo_lines(const double *box4, const int32_t *row_off, const uint8_t *sel_or_null,
                    const double *width, const double *height, const int32_t *class_id, int64_t n_rows,
                    int64_t *out_text_off, uint8_t *out_flag, uint8_t **out_text, int64_t *out_text_len);
 int dyd_yolo_lines_dev(const double *box4, const int32_t *row_off, const uint8_t *sel_or_null,
                        const double *width, const double *height, const int32_t *class_id, int64_t n_rows,
-                       int64_t *out_text_off, uint8_t *out_flag, uint8_t *out_text_or_null, int64_t text_cap,
+                       int64_t n_boxes, int64_t *out_text_off, uint8_t *out_flag, uint8_t *out_text_or_null, int64_t text_cap,
                        int64_t *out_total, void *stream);
 
 /* ---- native flatten / emit (HOST code, multithreaded) ------------------------------

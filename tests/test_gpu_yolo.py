@@ -247,7 +247,7 @@ def test_k7_dev_capacity_and_measure_mode(native, k7_variant):
     st = torch.cuda.current_stream().cuda_stream
 
     def call(text, cap):
-        return L.dyd_yolo_lines_dev(d_box.data_ptr(), d_off.data_ptr(), None, d_w.data_ptr(), d_h.data_ptr(), d_cid.data_ptr(), n,
+        return L.dyd_yolo_lines_dev(d_box.data_ptr(), d_off.data_ptr(), None, d_w.data_ptr(), d_h.data_ptr(), d_cid.data_ptr(), n, int(d_box.shape[0]),
                                     d_toff.data_ptr(), d_flag.data_ptr(), text.data_ptr() if text is not None else None, cap,
                                     C.byref(total), st)
     assert call(None, 0) == 0 and total.value == len(want_text)              # measure only
@@ -282,7 +282,7 @@ def test_k7_full_size_properties(native, k7_variant):
     cap = 48 * n
     text = torch.zeros(cap, dtype=torch.uint8, device=dev)
     total = C.c_int64()
-    rc = L.dyd_yolo_lines_dev(box.data_ptr(), row_off.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), n, toff.data_ptr(),
+    rc = L.dyd_yolo_lines_dev(box.data_ptr(), row_off.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), n, -1, toff.data_ptr(),
                               flag.data_ptr(), text.data_ptr(), cap, C.byref(total), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, L.dyd_last_error()
     assert int(flag.max()) == 0

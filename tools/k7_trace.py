@@ -42,7 +42,7 @@ def main():
     trace = torch.zeros(n_tiles * 8, dtype=torch.int64, device=dev)
 
     def run():
-        _native.check(L.dyd_yolo_lines_dev(box.data_ptr(), off.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), n, toff.data_ptr(),
+        _native.check(L.dyd_yolo_lines_dev(box.data_ptr(), off.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), n, n * bpr, toff.data_ptr(),
                                            flag.data_ptr(), None if a.measure else text.data_ptr(), text.numel(), C.byref(total), None), "k7")
     run(); run()
     _native.check(L.dyd_set_option(b"k7_trace_ptr", trace.data_ptr()), "opt")

@@ -242,7 +242,7 @@ def main():
         cid = (torch.arange(E, device=dev, dtype=torch.int32) % 20).contiguous()
         toff = torch.empty(E + 1, dtype=torch.int64, device=dev); flag = torch.empty(E, dtype=torch.uint8, device=dev)
         total = C.c_int64()
-        ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), E,
+        ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(), cid.data_ptr(), E, E,
                                 toff.data_ptr(), flag.data_ptr(), None, 0, C.byref(total), sp), "k7 measure")
         T = total.value
         text = torch.empty(T, dtype=torch.uint8, device=dev)
@@ -251,28 +251,28 @@ def main():
             ck(L.dyd_set_option(b"k7_variant", variant), "opt")
             if "full" in modes:
               med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
-                                                              cid.data_ptr(), E, toff.data_ptr(), flag.data_ptr(), text.data_ptr(), T,
+                                                              cid.data_ptr(), E, E, toff.data_ptr(), flag.data_ptr(), text.data_ptr(), T,
                                                               C.byref(total), sp), "k7"))
               report(f"k7_yolo_lines_rpt{variant}", 32 * E + 4 * (E + 1) + 20 * E + 8 * (E + 1) + E + T, med, mn, rows=E, text_bytes=T,
                    rows_per_s=round(E / med * 1e3), no_line_rows=int((flag == 1).sum().item()))
             if "measure" not in modes:
                 continue
             med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), h.data_ptr(),
-                                                              cid.data_ptr(), E, toff.data_ptr(), flag.data_ptr(), None, 0,
+                                                              cid.data_ptr(), E, E, toff.data_ptr(), flag.data_ptr(), None, 0,
                                                               C.byref(total), sp), "k7"))
             report(f"k7_measure_only_rpt{variant}", 32 * E + 4 * (E + 1) + 20 * E + 8 * (E + 1) + E, med, mn, rows=E)
         # rows of many boxes (unsplit sheets: 1..32 lines per row): the generic path of the kernel
         wr = torch.full((N,), 1920.0, dtype=torch.float64, device=dev); hr = torch.full((N,), 1080.0, dtype=torch.float64, device=dev)
         cidr = (torch.arange(N, device=dev, dtype=torch.int32) % 20).contiguous()
         toffr = torch.empty(N + 1, dtype=torch.int64, device=dev); flagr = torch.empty(N, dtype=torch.uint8, device=dev)
-        ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), box_off.data_ptr(), None, wr.data_ptr(), hr.data_ptr(), cidr.data_ptr(), N,
+        ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), box_off.data_ptr(), None, wr.data_ptr(), hr.data_ptr(), cidr.data_ptr(), N, B,
                                 toffr.data_ptr(), flagr.data_ptr(), None, 0, C.byref(total), sp), "k7 measure")
         Tr = total.value
         textr = torch.empty(Tr, dtype=torch.uint8, device=dev)
         for variant in [int(v) for v in os.environ.get("K7VM", "30,-1").split(",")]:   # 22: 330 ms per launch
             ck(L.dyd_set_option(b"k7_variant", variant), "opt")
             med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), box_off.data_ptr(), None, wr.data_ptr(), hr.data_ptr(),
-                                                              cidr.data_ptr(), N, toffr.data_ptr(), flagr.data_ptr(), textr.data_ptr(), Tr,
+                                                              cidr.data_ptr(), N, B, toffr.data_ptr(), flagr.data_ptr(), textr.data_ptr(), Tr,
                                                               C.byref(total), sp), "k7"))
             report(f"k7_yolo_lines_multi_box_rows_v{variant}", 32 * B + 4 * (N + 1) + 20 * N + 8 * (N + 1) + N + Tr, med, mn, rows=N, lines=B,
                    text_bytes=Tr, lines_per_s=round(B / med * 1e3))

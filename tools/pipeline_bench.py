@@ -140,12 +140,12 @@ def main():
     cid = (torch.arange(B, device=dev, dtype=torch.int32) % 20).contiguous()
     toff = torch.empty(B + 1, dtype=torch.int64, device=dev); flag = torch.empty(B, dtype=torch.uint8, device=dev)
     tot = C.c_int64()
-    ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), hh.data_ptr(), cid.data_ptr(), B, toff.data_ptr(),
+    ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), hh.data_ptr(), cid.data_ptr(), B, B, toff.data_ptr(),
                             flag.data_ptr(), None, 0, C.byref(tot), sp), "k7 measure")
     T = tot.value
     text = torch.empty(T, dtype=torch.uint8, device=dev)
     stage("K7 label lines (one per record; after the 5-stage total below)", 32 * B + 4 * (B + 1) + 20 * B + 8 * (B + 1) + B + T,
-          lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), hh.data_ptr(), cid.data_ptr(), B,
+          lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), one.data_ptr(), None, w.data_ptr(), hh.data_ptr(), cid.data_ptr(), B, B,
                                           toff.data_ptr(), flag.data_ptr(), text.data_ptr(), T, C.byref(tot), sp), "k7"),
           records=B, text_GB=round(T / 1e9, 2))
     k7 = stages.pop()
