@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
     if (tile == n_tiles - 1 && tid == 0) text_off[n_rows] = base + tile_bytes;
 }
 
-// dyd_set_option("k7_variant"): -1 = by the table's shape (default: 22 for one box per row, 30 from 1.25 boxes per row on),
+// dyd_set_option("k7_variant"): -1 = by the table's shape (default: 22 for one box per row, 30 from 1.02 boxes per row on),
 // 2 = one 512-row tile per ticket, 22 = two, pipelined, 30 = tiles of 480 boxes, a lane per box
 static int g_k7_variant = -1;
 static unsigned long long *g_k7_trace = nullptr;   // tuning hook (single-tile kernel): 8 timestamps per tile
@@ -1256,7 +1256,7 @@ static int yolo_launch(const double *box4, const int32_t *row_off, const uint8_t
         DYD_HIP(hipStreamSynchronize(st));
         n_boxes = last;
     }
-    if (g_k7_variant != 2 && g_k7_variant != 22 && !by_box) by_box = n_boxes > n_rows + n_rows / 4;   // -1: by the table's shape
+    if (g_k7_variant != 2 && g_k7_variant != 22 && !by_box) by_box = n_boxes > n_rows + n_rows / 50;   // -1: by the table's shape (measured: at 1.05 boxes per row the row kernels already take 1.7x the box kernel's time, at 1.25 60x)
     const int64_t n_tiles = by_box ? (n_boxes > 0 ? ceil_div(n_boxes, (int64_t)K7B_WINDOW) : 1) : ceil_div(n_rows, (int64_t)K7_BLOCK * 2);
     void *scr = nullptr;
     const size_t state_bytes = (size_t)(n_tiles + 2) * 8;

@@ -68,7 +68,7 @@ def _random_case(rng, n_rows, max_boxes, with_sel, special=True):
 @pytest.fixture(params=[-1, 22, 2, 30], ids=["auto", "paired", "single", "by_box"])
 def k7_variant(request, native):
     """22 = two 512-row tiles per ticket, software-pipelined; 2 = one tile per ticket; 30 = tiles of 480 boxes, a lane per
-    box; -1 (default) = 22 for tables of one box per row, 30 from 1.25 boxes per row on"""
+    box; -1 (default) = 22 for tables of one box per row, 30 from 1.02 boxes per row on"""
     native.check(native.lib().dyd_set_option(b"k7_variant", request.param), "opt")
     yield request.param
     native.check(native.lib().dyd_set_option(b"k7_variant", -1), "opt")

@@ -277,6 +277,36 @@ def main():
             report(f"k7_yolo_lines_multi_box_rows_v{variant}", 32 * B + 4 * (N + 1) + 20 * N + 8 * (N + 1) + N + Tr, med, mn, rows=N, lines=B,
                    text_bytes=Tr, lines_per_s=round(B / med * 1e3))
         ck(L.dyd_set_option(b"k7_variant", -1), "opt")
+    if "k7mix" in only:
+        # where the box-tiled kernel overtakes the row kernels: rows of one box with a share of two-box rows mixed in
+        import ctypes as C
+        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
+        g = torch.Generator(device=dev).manual_seed(9)
+        total = C.c_int64()
+        for share in (0.0, 0.05, 0.1, 0.25, 0.5, 1.0):
+            nr = int(B / (1 + share))
+            counts = (torch.rand(nr, generator=g, device=dev) < share).to(torch.int32) + 1
+            ro = torch.zeros(nr + 1, dtype=torch.int32, device=dev)
+            ro[1:] = torch.cumsum(counts, 0, dtype=torch.int64).to(torch.int32)
+            nbx = int(ro[-1].item())
+            w2 = torch.full((nr,), 1920.0, dtype=torch.float64, device=dev); h2 = torch.full((nr,), 1080.0, dtype=torch.float64, device=dev)
+            c2 = (torch.arange(nr, device=dev, dtype=torch.int32) % 20).contiguous()
+            to2 = torch.empty(nr + 1, dtype=torch.int64, device=dev); fl2 = torch.empty(nr, dtype=torch.uint8, device=dev)
+            ck(L.dyd_set_option(b"k7_variant", 22), "opt")
+            ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), ro.data_ptr(), None, w2.data_ptr(), h2.data_ptr(), c2.data_ptr(), nr, nbx,
+                                    to2.data_ptr(), fl2.data_ptr(), None, 0, C.byref(total), sp), "k7 measure")
+            tx = torch.empty(total.value, dtype=torch.uint8, device=dev)
+            res = {}
+            for variant in (22, 30, 22, 30):
+                ck(L.dyd_set_option(b"k7_variant", variant), "opt")
+                med, mn = timeit(lambda: ck(L.dyd_yolo_lines_dev(out_box.data_ptr(), ro.data_ptr(), None, w2.data_ptr(), h2.data_ptr(), c2.data_ptr(),
+                                                                  nr, nbx, to2.data_ptr(), fl2.data_ptr(), tx.data_ptr(), total.value, C.byref(total), sp), "k7"),
+                                 iters=10, warm=2)
+                res.setdefault(variant, []).append(med)
+            print(json.dumps({"k7_boxes_per_row": round(nbx / nr, 3), "rows": nr, "lines": nbx, "pair_rows_ms": round(min(res[22]), 4),
+                              "box_tiles_ms": round(min(res[30]), 4)}), flush=True)
+            del ro, w2, h2, c2, to2, fl2, tx, counts
+        ck(L.dyd_set_option(b"k7_variant", -1), "opt")
 
 if __name__ == "__main__":
     main()
