@@ -206,6 +206,13 @@ def main():
         report("k4_dedup_first_10M", 16 * Nk + Nk + 48 * 6_000_000, med, mn, rows_per_s=round(Nk / med * 1e3), kept=int(keepk.sum().item()))
         med, mn = timeit(lambda: ck(L.dyd_isin_dev(hk.data_ptr(), Nk, refk.data_ptr(), refk.shape[0], keepk.data_ptr(), sp), "k5"))
         report("k5_isin_10M_vs_1M", 16 * Nk + Nk + 16 * refk.shape[0], med, mn, rows_per_s=round(Nk / med * 1e3), hits=int(keepk.sum().item()))
+        # the other extreme: one key (a constant column, or all NaN), and 1000 keys — every row contends for few slots
+        for distinct in (1, 1000):
+            few = base[torch.randint(0, distinct, (Nk,), generator=g, device=dev)].contiguous()
+            for mode, nm in ((0, "first"), (1, "last"), (2, "none")):
+                med, mn = timeit(lambda: ck(L.dyd_dedup_dev(few.data_ptr(), Nk, mode, keepk.data_ptr(), sp), "k4"), iters=5, warm=1)
+                report(f"k4_dedup_{nm}_10M_rows_{distinct}_keys", 16 * Nk + Nk, med, mn, rows_per_s=round(Nk / med * 1e3), kept=int(keepk.sum().item()))
+            del few
         del base, hk, refk, keepk
 
     if "k6big" in only:
