@@ -131,9 +131,9 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st);
     }
     int v = g_fused_variant;
-    // sparse rows (<= 24 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
+    // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
     // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
-    if (v < 0) v = (n_boxes <= 24 * n_rows) ? 4 : 6;
+    if (v < 0) v = (n_boxes <= 32 * n_rows) ? 4 : 6;   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
     if (v == 4 || v == 7 || v == 8) {
         const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
         const int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);
