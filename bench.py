@@ -146,7 +146,7 @@ def main():
     sp = stream.cuda_stream
 
     def k1():
-        _native.check(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(),
+        _native.check(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, P, out_box.data_ptr(),
                                             out_arg.data_ptr(), sp), "dyd_bbox_minmax_dev")
 
     def k2():
@@ -154,7 +154,7 @@ def main():
                                            out_high.data_ptr(), None, sp), "dyd_iou_any_ge_dev")
 
     def fused():
-        _native.check(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B,
+        _native.check(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P,
                                                MIN_BOXES, THR, out_box.data_ptr(), out_arg.data_ptr(),
                                                out_high.data_ptr(), sp), "dyd_bbox_iou_fused_dev")
 

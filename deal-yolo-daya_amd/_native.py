@@ -55,11 +55,11 @@ SIGNATURES = {
     "dyd_sync": (C.c_int, [C.c_void_p]),
     "dyd_last_kernel_ms": (C.c_double, []),
     "dyd_bbox_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "dyd_bbox_minmax_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_bbox_minmax_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_iou_any_ge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "dyd_iou_any_ge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
-    "dyd_bbox_iou_fused_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+    "dyd_bbox_iou_fused_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_hash128": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dyd_hash128_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -93,8 +93,9 @@ static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *
     return DYD_OK;
 }
 
-int launch_k1(const double *xy, const int32_t *pt_off, int64_t n_boxes, double *out_box4, int32_t *out_arg4,
+int launch_k1(const double *xy, const int32_t *pt_off, int64_t n_boxes, int64_t n_points, double *out_box4, int32_t *out_arg4,
               hipStream_t st);
+bool k1_wants_groups(int64_t n_boxes, int64_t n_points);
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
               uint8_t *out_high, double *out_max, hipStream_t st);
 void set_k1_variant(int v);
@@ -115,8 +116,8 @@ using namespace dyd;
 extern "C" {
 
 int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
-                           int64_t n_boxes, int32_t min_boxes, double thr, double *out_box4, int32_t *out_arg4,
-                           uint8_t *out_high, void *stream) {
+                           int64_t n_boxes, int64_t n_points, int32_t min_boxes, double thr, double *out_box4,
+                           int32_t *out_arg4, uint8_t *out_high, void *stream) {
     DYD_API_ENTER();
     DYD_REQUIRE(n_rows >= 0 && n_boxes >= 0, "negative size");
     if (n_rows == 0) return DYD_OK;
@@ -125,15 +126,18 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
                   reinterpret_cast<uintptr_t>(out_arg4)) & 15) == 0,
                 "xy / out_box4 / out_arg4 must be 16-byte aligned");
     hipStream_t st = pick_stream(stream);
-    if (g_fused_variant == 1) {
-        int rc = launch_k1(xy, pt_off, n_boxes, out_box4, out_arg4, st);
+    // long polygons: a lane per box would walk alone (k1_bbox.hip): the group kernel, then K2 (the boxes are 32 of the table's
+    // 400+ bytes per box, so reading them back costs little)
+    if (g_fused_variant == 1 || (g_fused_variant < 0 && k1_wants_groups(n_boxes, n_points))) {
+        int rc = launch_k1(xy, pt_off, n_boxes, n_points, out_box4, out_arg4, st);
         if (rc) return rc;
         return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st);
     }
     int v = g_fused_variant;
     // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
     // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
-    if (v < 0) v = (n_boxes <= 32 * n_rows) ? 4 : 6;   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
+    // (polygons of 20..48 points: the workgroup tiles keep more lanes walking than a wave's 64-box tile does)
+    if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : 6;   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
     if (v == 4 || v == 7 || v == 8) {
         const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
         const int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);

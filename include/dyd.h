@@ -79,7 +79,9 @@ double dyd_last_kernel_ms(void);
  * processor.py:254-255). */
 int dyd_bbox_minmax(const double *xy, const int32_t *pt_off, int64_t n_boxes,
                     double *out_box4, int32_t *out_arg4);
-int dyd_bbox_minmax_dev(const double *xy, const int32_t *pt_off, int64_t n_boxes,
+/* n_points = pt_off[n_boxes] (the table's shape picks the kernel: a lane per polygon for short polygons, sixteen lanes per
+ * polygon from 48 points per polygon on); a negative value means "not known" and selects the short-polygon kernels. */
+int dyd_bbox_minmax_dev(const double *xy, const int32_t *pt_off, int64_t n_boxes, int64_t n_points,
                         double *out_box4, int32_t *out_arg4, void *stream);
 
 /* ---- K2: per-image box-count + all-pairs IoU filter ------------------------------
@@ -102,10 +104,10 @@ int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_row
 /* ---- K1+K2 fused: poly -> bbox -> IoU flag in one pass ---------------------------
  * One launch that produces K1's outputs and K2's flag for rows whose boxes all come
  * from K1 (processing.py:580-598 runs the two steps back to back on the same rows).
- * box_off : box offsets per image row [n_rows+1], n_boxes = box_off[n_rows]; other
- *           arguments as K1 / K2. */
+ * box_off : box offsets per image row [n_rows+1], n_boxes = box_off[n_rows], n_points = pt_off[n_boxes]
+ *           (or negative: not known); other arguments as K1 / K2. */
 int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_t *box_off,
-                           int64_t n_rows, int64_t n_boxes, int32_t min_boxes, double thr,
+                           int64_t n_rows, int64_t n_boxes, int64_t n_points, int32_t min_boxes, double thr,
                            double *out_box4, int32_t *out_arg4, uint8_t *out_high, void *stream);
 
 /* ---- K3: 128-bit hash of a string column -----------------------------------------

@@ -99,7 +99,7 @@ def test_config2_ten_million_rows_pipeline(native):
     out_box = torch.empty((B, 4), dtype=torch.float64, device=dev)
     out_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
     out_high = torch.empty(N, dtype=torch.uint8, device=dev)
-    ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98, out_box.data_ptr(),
+    ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, int(xy.shape[0]), 2, 0.98, out_box.data_ptr(),
                                 out_arg.data_ptr(), out_high.data_ptr(), sp), "k12")
     # bbox: every coordinate is the selected point's coordinate, and no point lies outside its box
     seg = torch.repeat_interleave(torch.arange(B, device=dev), npts.long())

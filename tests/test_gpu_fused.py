@@ -49,7 +49,7 @@ def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, varia
         t_high = torch.full((n_rows,), 9, dtype=torch.uint8, device=dev)
         native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
         try:
-            native.check(L.dyd_bbox_iou_fused_dev(t_xy.data_ptr(), t_po.data_ptr(), t_bo.data_ptr(), n_rows, B, mb, thr,
+            native.check(L.dyd_bbox_iou_fused_dev(t_xy.data_ptr(), t_po.data_ptr(), t_bo.data_ptr(), n_rows, B, int(t_xy.shape[0]), mb, thr,
                                                   t_box.data_ptr(), t_arg.data_ptr(), t_high.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream), "fused")
         finally:
@@ -77,7 +77,7 @@ def test_dev_entry_points_on_a_side_stream(native):
         t_box = torch.empty((B, 4), dtype=torch.float64, device=dev)
         t_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
         t_high = torch.empty(500, dtype=torch.uint8, device=dev)
-        native.check(L.dyd_bbox_minmax_dev(t_xy.data_ptr(), t_po.data_ptr(), B, t_box.data_ptr(), t_arg.data_ptr(),
+        native.check(L.dyd_bbox_minmax_dev(t_xy.data_ptr(), t_po.data_ptr(), B, int(t_xy.shape[0]), t_box.data_ptr(), t_arg.data_ptr(),
                                            s.cuda_stream), "k1")
         native.check(L.dyd_iou_any_ge_dev(t_box.data_ptr(), t_bo.data_ptr(), 500, 2, 0.9, t_high.data_ptr(), None,
                                           s.cuda_stream), "k2")

@@ -29,8 +29,18 @@ def test_device_is_gfx950(native):
 
 
 # ------------------------------------------------------------------------------------- K1
-@pytest.mark.parametrize("n_boxes,max_pts", [(1, 5), (63, 12), (256, 12), (257, 12), (5000, 12), (70000, 40), (300, 700)])
-def test_k1_random(native, n_boxes, max_pts):
+@pytest.fixture(params=[-1, 0, 2], ids=["auto", "tile", "group"])
+def k1_variant(request, native):
+    """-1 = by the table's shape (the group kernel — sixteen lanes per polygon — from 48 points per polygon on), 0 = the tile
+    kernel (a lane per polygon), 2 = the group kernel"""
+    native.check(native.lib().dyd_set_option(b"k1_variant", request.param), "set_option")
+    yield request.param
+    native.check(native.lib().dyd_set_option(b"k1_variant", -1), "set_option")
+
+
+@pytest.mark.parametrize("n_boxes,max_pts", [(1, 5), (63, 12), (256, 12), (257, 12), (5000, 12), (70000, 40), (300, 700), (1000, 64),
+                                             (17, 5000), (4097, 33)])
+def test_k1_random(native, k1_variant, n_boxes, max_pts):
     rng = np.random.default_rng(n_boxes * 31 + max_pts)
     xy, off = random_polygons(rng, n_boxes, max_pts)
     box, arg = native.bbox_minmax(xy, off)
@@ -39,7 +49,41 @@ def test_k1_random(native, n_boxes, max_pts):
     assert same_f64(box, obox)
 
 
-def test_k1_edges(native):
+def test_k1_group_kernel_ties_across_lanes(native):
+    """the group kernel folds sixteen lanes' partial extremes: equal values in different lanes must resolve to the lowest
+    index, signed zeros and infinities included, and a NaN must stick only from position 0"""
+    native.check(native.lib().dyd_set_option(b"k1_variant", 2), "set_option")
+    try:
+        rng = np.random.default_rng(5)
+        polys = []
+        for n in (1, 2, 15, 16, 17, 31, 32, 33, 100, 1000):
+            for kind in range(6):
+                p = np.round(rng.random((n, 2)) * 4, 0)                       # values 0..4: ties everywhere
+                if kind == 1:
+                    p[:, 0] = 7.0                                            # one value: index 0 wins both ends
+                elif kind == 2:
+                    p[rng.integers(0, n, max(1, n // 3)), 0] = -0.0
+                    p[rng.integers(0, n, max(1, n // 3)), 1] = 0.0
+                elif kind == 3:
+                    p[0] = np.nan                                            # poisons both coordinates
+                elif kind == 4:
+                    p[rng.integers(0, n, max(1, n // 2))] = np.nan           # ignored unless at position 0
+                elif kind == 5:
+                    p[rng.integers(0, n, max(1, n // 4)), 0] = np.inf
+                    p[rng.integers(0, n, max(1, n // 4)), 1] = -np.inf
+                polys.append(p)
+        off = np.zeros(len(polys) + 1, np.int32)
+        np.cumsum([len(p) for p in polys], out=off[1:])
+        xy = np.concatenate(polys)
+        box, arg = native.bbox_minmax(xy, off)
+        obox, oarg = olib.bbox_minmax(xy, off)
+        assert np.array_equal(arg, oarg) and same_f64(box, obox)
+        assert np.array_equal(np.signbit(box), np.signbit(obox))
+    finally:
+        native.check(native.lib().dyd_set_option(b"k1_variant", -1), "set_option")
+
+
+def test_k1_edges(native, k1_variant):
     # empty input, all-empty boxes, one giant box spanning many LDS chunks, NaN / -0.0 / tie rules
     box, arg = native.bbox_minmax(np.zeros((0, 2)), np.zeros(1, np.int32))
     assert box.shape == (0, 4) and arg.shape == (0, 4)
@@ -70,7 +114,7 @@ def test_k1_direct_variant_agrees(native):
     try:
         alt = native.bbox_minmax(xy, off)
     finally:
-        native.check(native.lib().dyd_set_option(b"k1_variant", 0), "set_option")
+        native.check(native.lib().dyd_set_option(b"k1_variant", -1), "set_option")
     assert np.array_equal(ref[1], alt[1]) and same_f64(ref[0], alt[0])
 
 

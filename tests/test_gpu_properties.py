@@ -29,7 +29,7 @@ def device_result(native, table):
     box = torch.empty((B, 4), dtype=torch.float64, device=dev)
     arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
     high = torch.empty(N, dtype=torch.uint8, device=dev)
-    native.check(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), po.data_ptr(), bo.data_ptr(), N, B, 2, 0.98, box.data_ptr(),
+    native.check(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), po.data_ptr(), bo.data_ptr(), N, B, int(xy.shape[0]), 2, 0.98, box.data_ptr(),
                                           arg.data_ptr(), high.data_ptr(), torch.cuda.current_stream().cuda_stream), "fused")
     torch.cuda.synchronize()
     return box.cpu().numpy(), arg.cpu().numpy(), high.cpu().numpy()

@@ -35,7 +35,7 @@ def main():
             for it in range(12):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98, out_box.data_ptr(),
+                ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, int(xy.shape[0]), 2, 0.98, out_box.data_ptr(),
                                             out_arg.data_ptr(), out_high.data_ptr(), sp), "k12")
                 b.record(); b.synchronize()
                 if it >= 2:

@@ -85,10 +85,10 @@ def main():
         for rnd in range(2):                      # interleaved rounds (guide rule 24)
             for variant in (0, 1):
                 ck(L.dyd_set_option(b"k1_variant", variant), "opt")
-                med, mn = timeit(lambda: ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B,
+                med, mn = timeit(lambda: ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, P,
                                                                    out_box.data_ptr(), out_arg.data_ptr(), sp), "k1"))
                 res.setdefault(variant, []).append((med, mn))
-        ck(L.dyd_set_option(b"k1_variant", 0), "opt")
+        ck(L.dyd_set_option(b"k1_variant", -1), "opt")
         for variant, name in ((0, "k1_bbox_lds"), (1, "k1_bbox_direct")):
             med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
             report(name, k1_bytes, med, mn, rows_per_s=round(N / med * 1e3))
@@ -115,7 +115,7 @@ def main():
             del table
 
     if "k2" in only:
-        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
+        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, P, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
         k2_bytes = 32 * B + 4 * (N + 1) + N
         nb64 = nbox.to(torch.int64)
         pairs = int((nb64 * (nb64 - 1) // 2).sum().item())
@@ -139,14 +139,14 @@ def main():
             for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
                 ck(L.dyd_set_option(b"fused_variant", variant), "opt")
                 med, mn = timeit(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(),
-                                                                      N, B, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
+                                                                      N, B, P, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
                                                                       out_high.data_ptr(), sp), "k12"))
                 res.setdefault(variant, []).append((med, mn))
         b2b = []
         names = {4: "4 waves/wg (default)", 8: "2 waves/wg", 7: "1 wave/wg"}
         for variant in (4, 8, 7, 4):   # interleaved, in one process: box-to-box variance is larger than the differences
             ck(L.dyd_set_option(b"fused_variant", variant), "opt")
-            ms = timeit_b2b(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98,
+            ms = timeit_b2b(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P, 2, 0.98,
                                                                 out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"))
             b2b.append([names[variant], round(ms, 4)])
         print(json.dumps({"k12_wave_back_to_back_ms": b2b}), flush=True)
@@ -242,7 +242,7 @@ def main():
     if "k7" in only:
         import ctypes as C
         # the shape of a split sheet: one labelled box per expanded row; boxes = K1's output for the synthetic polygons
-        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
+        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, P, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
         E = B
         one = torch.arange(E + 1, dtype=torch.int32, device=dev)
         w = torch.full((E,), 1920.0, dtype=torch.float64, device=dev); h = torch.full((E,), 1080.0, dtype=torch.float64, device=dev)
@@ -287,7 +287,7 @@ def main():
     if "k7mix" in only:
         # where the box-tiled kernel overtakes the row kernels: rows of one box with a share of two-box rows mixed in
         import ctypes as C
-        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
+        ck(L.dyd_bbox_minmax_dev(xy.data_ptr(), pt_off.data_ptr(), B, P, out_box.data_ptr(), out_arg.data_ptr(), sp), "k1")
         g = torch.Generator(device=dev).manual_seed(9)
         total = C.c_int64()
         for share in (0.0, 0.05, 0.1, 0.25, 0.5, 1.0):

@@ -112,7 +112,7 @@ def main():
                    ck(L.dyd_isin_dev(h.data_ptr(), N, hr.data_ptr(), R, hit.data_ptr(), sp), "k5")),
           post=lambda: {"hits": int(hit.sum().item())})
     stage("K1+K2 fused (poly->bbox + IoU flag)", 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N,
-          lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98,
+          lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P, 2, 0.98,
                                               out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"),
           post=lambda: {"high": int(out_high.sum().item())})
 
