@@ -194,6 +194,21 @@ def main():
                                                          pos.data_ptr(), sp), "k6"))
         report("k6_split_ids", 21 * E, med, mn, expanded_rows=E, rows_per_s=round(E / med * 1e3))
 
+    if "k3len" in only:
+        # K3 against the cell length (signed CDN URLs run to hundreds of bytes): ~1 GB of text per table
+        g = torch.Generator(device=dev).manual_seed(8)
+        for L_ in (30, 100, 400, 2000):
+            n3 = max(1000, 1_000_000_000 // L_)
+            lens = torch.randint(max(1, L_ // 2), L_ * 3 // 2 + 1, (n3,), generator=g, device=dev)
+            off3 = torch.zeros(n3 + 1, dtype=torch.int64, device=dev)
+            off3[1:] = torch.cumsum(lens, 0)
+            tot3 = int(off3[-1].item())
+            data3 = torch.randint(32, 127, (tot3,), generator=g, device=dev, dtype=torch.uint8)
+            h3 = torch.empty((n3, 2), dtype=torch.int64, device=dev)
+            med, mn = timeit(lambda: ck(L.dyd_hash128_dev(data3.data_ptr(), off3.data_ptr(), n3, h3.data_ptr(), sp), "k3"), iters=8, warm=2)
+            report(f"k3_hash128_len{L_}", tot3 + 8 * (n3 + 1) + 16 * n3, med, mn, rows=n3, text_GB=round(tot3 / 1e9, 3))
+            del lens, off3, data3, h3
+
     if "k5big" in only:
         # the 10 M-row pipeline's K4 / K5 on random 128-bit keys: 10 M rows (60 % distinct), 1 M reference keys, 10 % hits
         Nk = 10_000_000
