@@ -209,6 +209,24 @@ def main():
             report(f"k3_hash128_len{L_}", tot3 + 8 * (n3 + 1) + 16 * n3, med, mn, rows=n3, text_GB=round(tot3 / 1e9, 3))
             del lens, off3, data3, h3
 
+    if "k6cats" in only:
+        # K6 against the number of categories (the columns of the rules sheet): 16.5 M expanded rows, uniform labels
+        g = torch.Generator(device=dev).manual_seed(4)
+        E6 = 16_500_000
+        for ncat in (2, 16, 128, 1000, 5000):
+            cat6 = torch.randint(-1, ncat, (E6,), generator=g, device=dev, dtype=torch.int32)
+            sizes6 = torch.bincount(cat6[cat6 >= 0].to(torch.int64), minlength=ncat)
+            cat_off6 = torch.zeros(ncat + 1, dtype=torch.int64, device=dev)
+            cat_off6[1:] = torch.cumsum(sizes6, 0)
+            perm6 = torch.cat([torch.randperm(int(sz), generator=g, device=dev) for sz in sizes6.tolist()]).contiguous() if ncat <= 1000 else \
+                torch.arange(int(cat_off6[-1].item()), device=dev) - torch.repeat_interleave(cat_off6[:-1], sizes6)
+            ntr6 = (sizes6 * 8 // 10).contiguous(); nva6 = (sizes6 // 10).contiguous()
+            sp6 = torch.empty(E6, dtype=torch.uint8, device=dev); pos6 = torch.empty(E6, dtype=torch.int64, device=dev)
+            med, mn = timeit(lambda: ck(L.dyd_split_ids_dev(cat6.data_ptr(), E6, perm6.data_ptr(), cat_off6.data_ptr(), ntr6.data_ptr(),
+                                                             nva6.data_ptr(), ncat, sp6.data_ptr(), pos6.data_ptr(), sp), "k6"), iters=8, warm=2)
+            report(f"k6_split_ids_{ncat}_categories", 21 * E6, med, mn, expanded_rows=E6)
+            del cat6, perm6, sp6, pos6
+
     if "k5big" in only:
         # the 10 M-row pipeline's K4 / K5 on random 128-bit keys: 10 M rows (60 % distinct), 1 M reference keys, 10 % hits
         Nk = 10_000_000
