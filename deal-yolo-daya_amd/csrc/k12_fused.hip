@@ -97,7 +97,7 @@ int launch_k1(const double *xy, const int32_t *pt_off, int64_t n_boxes, int64_t 
               hipStream_t st);
 bool k1_wants_groups(int64_t n_boxes, int64_t n_points);
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st);
+              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above = 0x7fffffff);
 void set_k1_variant(int v);
 void set_k2_variant(int v);
 void set_k7_variant(int v);

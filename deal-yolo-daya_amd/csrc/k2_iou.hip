@@ -26,6 +26,8 @@
 // Arithmetic is f64 in the reference's operation order, built with -ffp-contract=off; the IEEE
 // division is only executed when a conservative bound (inter < 0.999*thr*union) cannot already
 // rule the pair out.
+#include <vector>
+
 #include "k2_filter.h"
 
 namespace dyd {
@@ -35,13 +37,13 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_iou_kernel(const double *__restri
                                                           const int32_t *__restrict__ row_off,
                                                           int64_t n_rows, int32_t min_boxes, double thr,
                                                           uint8_t *__restrict__ out_high,
-                                                          double *__restrict__ out_max) {
+                                                          double *__restrict__ out_max, int32_t skip_above) {
     __shared__ WaveLdsT<WROWS, WCAP> s_all[K2_WAVES];
     const int wave = threadIdx.x >> 6;
     const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * WROWS;
     if (r0 >= n_rows) return;  // whole wave leaves; no workgroup barrier exists in this kernel
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
-    k2_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave]);
+    k2_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave], skip_above);
 }
 
 // the same kernel with the f32 reject filter in front of the exact test (k2_filter.h)
@@ -50,18 +52,18 @@ __global__ __launch_bounds__(K2_BLOCK) void k2f_iou_kernel(const double *__restr
                                                            const int32_t *__restrict__ row_off,
                                                            int64_t n_rows, int32_t min_boxes, double thr,
                                                            uint8_t *__restrict__ out_high,
-                                                           double *__restrict__ out_max) {
+                                                           double *__restrict__ out_max, int32_t skip_above) {
     __shared__ WaveLdsF<WROWS, WCAP> s_all[K2_WAVES];
     const int wave = threadIdx.x >> 6;
     const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * WROWS;
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
-    k2f_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave]);
+    k2f_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave], skip_above);
 }
 
 template <int WROWS, int WCAP>
 static int launch_k2f_t(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-                        uint8_t *out_high, double *out_max, hipStream_t st) {
+                        uint8_t *out_high, double *out_max, int32_t skip_above, hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
@@ -69,17 +71,17 @@ static int launch_k2f_t(const double *box4, const int32_t *row_off, int64_t n_ro
     }
     if (out_max)
         hipLaunchKernelGGL((k2f_iou_kernel<true, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
     else
         hipLaunchKernelGGL((k2f_iou_kernel<false, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
 
 template <int WROWS, int WCAP>
 static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-                       uint8_t *out_high, double *out_max, hipStream_t st) {
+                       uint8_t *out_high, double *out_max, int32_t skip_above, hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
@@ -87,10 +89,10 @@ static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_row
     }
     if (out_max)
         hipLaunchKernelGGL((k2_iou_kernel<true, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
     else
         hipLaunchKernelGGL((k2_iou_kernel<false, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
@@ -101,13 +103,110 @@ static int g_k2_variant = 3;  // default: 8-row tiles + f32 reject filter (best 
 void set_k2_variant(int v) { g_k2_variant = v; }
 
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st) {
+              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above) {
     if (n_rows == 0) return DYD_OK;
-    if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
-    if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
-    if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
-    if (g_k2_variant == 3) return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
-    return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st);
+    if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
+    if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
+    if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
+    return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
+}
+
+// ---- rows of thousands of boxes ---------------------------------------------------------------------------------
+// The tile kernels keep a row on ONE wave: 1000 boxes take 1.4 ms there, 10 000 boxes 120 ms, 50 000 boxes 3 s
+// (tools/bigrow_probe.py).  The host entry point therefore hands rows of more than K2_BIG_ROW boxes (when there are few of them) to this kernel (the
+// tile kernel skips them): a row's pairs are cut into items of 64 boxes x K2_BIG_CHUNK partners, the items of all big rows are
+// numbered in one sequence, and wave w of the grid takes the items w, w + W, ...  Within an item lane l holds box i0 + l and
+// meets the partners j > i of its chunk, 64 at a time through LDS, always as (lower index, higher index) — the reference's
+// argument order, so rows with NaN corners need no special path.
+constexpr int32_t K2_BIG_ROW = 256;      // rows above this many boxes (the tile kernels hold 128 / 256 per tile)
+constexpr int32_t K2_BIG_LIST = 2048;    // at most this many of them
+constexpr int32_t K2_BIG_CHUNK = 4096;
+
+struct alignas(16) BigRowLds {
+    double x1[kWave], y1[kWave], x2[kWave], y2[kWave];
+};
+
+template <bool WANT_MAX>
+__global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__restrict__ box4,
+                                                               const int32_t *__restrict__ row_off,
+                                                               const int64_t *__restrict__ big_rows, int32_t n_big,
+                                                               int32_t min_boxes, double thr,
+                                                               uint8_t *__restrict__ out_high,
+                                                               unsigned long long *__restrict__ out_max_bits) {
+    __shared__ BigRowLds s_all[K2_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    BigRowLds &S = s_all[wave];
+    const int64_t n_waves = (int64_t)gridDim.x * K2_WAVES, me_wave = (int64_t)blockIdx.x * K2_WAVES + wave;
+    const bool zero_hits = (0.0 >= thr);
+    const double thr_lo = (thr > 0.0) ? thr * 0.999 : 0.0;
+    int64_t item = 0;   // running number of the items, the same in every wave
+    for (int32_t k = 0; k < n_big; ++k) {
+        const int64_t r = big_rows[k];
+        const int64_t base = row_off[r];
+        const int32_t n = (int32_t)(row_off[r + 1] - base);
+        if (!WANT_MAX && n < min_boxes) continue;
+        bool hit = false;
+        double mx = 0.0;
+        for (int32_t i0 = 0; i0 < n - 1; i0 += kWave) {
+            const int32_t first_j = i0 + 1;
+            const int32_t n_chunks = (n - first_j + K2_BIG_CHUNK - 1) / K2_BIG_CHUNK;
+            // the chunks of this i-tile that are this wave's: item + c == me_wave (mod n_waves)
+            int64_t c = ((me_wave - item) % n_waves + n_waves) % n_waves;
+            item += n_chunks;
+            if (c >= n_chunks) continue;
+            const int32_t i = i0 + lane;
+            const bool have = i < n - 1;
+            Corners me = {0.0, 0.0, 0.0, 0.0};
+            double me_ar = 0.0;
+            if (have) {
+                me = load_corners(box4, base + i);
+                me_ar = area_of(me);
+            }
+            for (; c < n_chunks; c += n_waves) {
+                const int32_t jlo = first_j + (int32_t)c * K2_BIG_CHUNK;
+                const int32_t jhi = (n - jlo > K2_BIG_CHUNK) ? jlo + K2_BIG_CHUNK : n;
+                for (int32_t tj = jlo; tj < jhi; tj += kWave) {
+                    const int32_t tn = (jhi - tj < kWave) ? jhi - tj : kWave;
+                    wave_sync();
+                    if (lane < tn) {
+                        const Corners v = load_corners(box4, base + tj + lane);
+                        S.x1[lane] = v.x1; S.y1[lane] = v.y1; S.x2[lane] = v.x2; S.y2[lane] = v.y2;
+                    }
+                    wave_sync();
+                    if (have) {
+                        for (int32_t q = (i + 1 > tj) ? i + 1 - tj : 0; q < tn; ++q) {
+                            const Corners o = {S.x1[q], S.y1[q], S.x2[q], S.y2[q]};
+                            hit |= pair_hits<WANT_MAX, false>(me, o, me_ar, o, thr, thr_lo, zero_hits, mx);   // i < j
+                        }
+                    }
+                }
+            }
+        }
+        if (__any(hit) && lane == 0 && n >= min_boxes) out_high[r] = 1;
+        if (WANT_MAX) {
+            unsigned long long bits = (unsigned long long)__double_as_longlong(mx);   // IoU >= 0: the bit patterns order like the values
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long o = __shfl_xor(bits, d);
+                bits = o > bits ? o : bits;
+            }
+            if (lane == 0 && bits) atomicMax(&out_max_bits[r], bits);
+        }
+    }
+}
+
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, const int64_t *big_rows, int32_t n_big, int32_t min_boxes,
+                       double thr, uint8_t *out_high, double *out_max, hipStream_t st) {
+    if (n_big == 0) return DYD_OK;
+    const unsigned blocks = (unsigned)ctx().num_cu * 4;   // 16 waves per CU, striding over the items
+    if (out_max)
+        hipLaunchKernelGGL(k2_big_rows_kernel<true>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, big_rows, n_big, min_boxes, thr,
+                           out_high, reinterpret_cast<unsigned long long *>(out_max));
+    else
+        hipLaunchKernelGGL(k2_big_rows_kernel<false>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, big_rows, n_big, min_boxes, thr,
+                           out_high, (unsigned long long *)nullptr);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
 }
 
 }  // namespace dyd
@@ -123,7 +222,7 @@ int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_row
     if (n_rows == 0) return DYD_OK;
     DYD_REQUIRE(row_off && out_high, "null pointer");
     DYD_REQUIRE((reinterpret_cast<uintptr_t>(box4) & 15) == 0, "box4 must be 16-byte aligned");
-    return launch_k2(box4, row_off, n_rows, min_boxes, thr, out_high, out_max_iou_or_null, pick_stream(stream));
+    return launch_k2(box4, row_off, n_rows, min_boxes, thr, out_high, out_max_iou_or_null, pick_stream(stream), 0x7fffffff);
 }
 
 int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
@@ -145,9 +244,30 @@ int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows, i
     hipStream_t st = ctx().stream;
     if (nb) DYD_HIP(hipMemcpyAsync(d_box.p, box4, 32 * (size_t)nb, hipMemcpyHostToDevice, st));
     DYD_HIP(hipMemcpyAsync(d_off.p, row_off, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice, st));
+    // rows of thousands of boxes go to their own kernel, which spreads each of them over the grid
+    // (every wave of that kernel walks the whole list, so the list is kept short: when a table has thousands of such rows
+    // the threshold doubles until at most K2_BIG_LIST are left — many big rows keep the tile kernel's waves busy anyway)
+    int32_t big_above = K2_BIG_ROW;
+    std::vector<int64_t> big;
+    while (true) {
+        big.clear();
+        for (int64_t i = 0; i < n_rows && (int64_t)big.size() <= K2_BIG_LIST; ++i)
+            if (row_off[i + 1] - row_off[i] > big_above) big.push_back(i);
+        if ((int64_t)big.size() <= K2_BIG_LIST || big_above > (1 << 29)) break;
+        big_above *= 2;
+    }
+    if ((int64_t)big.size() > K2_BIG_LIST) big.clear();
+    DevBuf d_big;
+    if (!big.empty()) {
+        if ((rc = d_big.alloc(8 * big.size()))) return rc;
+        DYD_HIP(hipMemcpyAsync(d_big.p, big.data(), 8 * big.size(), hipMemcpyHostToDevice, st));
+    }
     KernelTimer t(st);
     rc = launch_k2(d_box.as<double>(), d_off.as<int32_t>(), n_rows, min_boxes, thr, d_high.as<uint8_t>(),
-                   out_max_iou_or_null ? d_max.as<double>() : nullptr, st);
+                   out_max_iou_or_null ? d_max.as<double>() : nullptr, st, big.empty() ? 0x7fffffff : big_above);
+    if (rc) return rc;
+    rc = launch_k2_big_rows(d_box.as<double>(), d_off.as<int32_t>(), d_big.as<int64_t>(), (int32_t)big.size(), min_boxes, thr,
+                            d_high.as<uint8_t>(), out_max_iou_or_null ? d_max.as<double>() : nullptr, st);
     if (rc) return rc;
     t.finish();
     DYD_HIP(hipMemcpyAsync(out_high, d_high.p, (size_t)n_rows, hipMemcpyDeviceToHost, st));

@@ -124,7 +124,8 @@ __device__ __forceinline__ bool pair_hits(const Corners &p, const Corners &q, do
 template <bool WANT_MAX, int WROWS = K2_WROWS, int WCAP = K2_WCAP>
 __device__ __forceinline__ void k2_wave_rows(const double *box4, const int32_t *__restrict__ row_off, int64_t r0,
                                              int nr, int32_t min_boxes, double thr, uint8_t *__restrict__ out_high,
-                                             double *__restrict__ out_max, WaveLdsT<WROWS, WCAP> &S) {
+                                             double *__restrict__ out_max, WaveLdsT<WROWS, WCAP> &S,
+                                             int32_t skip_above = 0x7fffffff) {
     static_assert(WROWS < 63 && WCAP <= 65535, "rows map to lanes, box ids to 16 bits");
     const int lane = threadIdx.x & 63;
     // lane L (L <= nr) keeps row_off[r0 + L] in a register and in LDS
@@ -153,6 +154,10 @@ __device__ __forceinline__ void k2_wave_rows(const double *box4, const int32_t *
         if (taken == 0) {
             // ---- one row larger than the LDS tile: stream partner tiles through LDS ----------
             const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
+            if (n > skip_above) {   // a row of thousands of boxes: left to k2_big_rows_kernel, which spreads it over the grid
+                ra += 1;
+                continue;
+            }
             const bool counted = WANT_MAX || n >= min_boxes;
             bool hit = false;
             double mx = 0.0;

@@ -392,3 +392,29 @@ def test_whole_chain_with_label_replace_matches_the_cpu_port(native, tmp_path, m
     texts, _ = P.yolo_label_texts(sheet[P.BBOX_COL].tolist(), labels, cids, sheet["width"].tolist(), sheet["height"].tolist())
     assert texts == [osteps.yolo_row_text(c, lab, k, w, h)[0] for c, lab, k, w, h in
                      zip(sheet[P.BBOX_COL], labels, cids, sheet["width"], sheet["height"])] and any(texts)
+
+
+@pytest.mark.parametrize("sizes", [[1025], [3000, 5, 0, 1200], [10, 4100, 2, 1030, 7], [257, 256, 300, 1, 600], [300] * 2100 + [900]])
+@pytest.mark.parametrize("thr,min_boxes", [(0.98, 2), (0.3, 2), (0.0, 2), (0.98, 5000)])
+def test_k2_rows_of_thousands_of_boxes(native, sizes, thr, min_boxes):
+    """rows above 256 boxes (when a table has few of them) leave the tile kernel for k2_big_rows_kernel (their pairs spread over the grid): same flags and the
+    same maximum IoU as the oracle's double loop, NaN corners and exact ties included"""
+    rng = np.random.default_rng(sum(sizes) + int(thr * 100))
+    off = np.zeros(len(sizes) + 1, np.int32)
+    np.cumsum(sizes, out=off[1:])
+    nb = int(off[-1])
+    c = np.round(rng.random((nb, 2)) * 3000, 0)
+    box = np.concatenate([c, c + np.round(rng.random((nb, 2)) * 80 + 1, 0)], axis=1)
+    box[rng.integers(0, nb, 40), rng.integers(0, 4, 40)] = np.nan
+    swap = rng.random(nb) < 0.3
+    box[swap] = box[swap][:, [2, 3, 0, 1]]
+    for r in range(len(sizes)):                                   # a near-duplicate pair deep inside every big row
+        if sizes[r] > 256:
+            a, b = off[r] + sizes[r] - 3, off[r] + sizes[r] // 2
+            box[a] = [10, 10, 110, 110]
+            box[b] = [10, 10, 110, 109] if r % 2 == 0 else [500, 500, 501, 501]
+    got, gmx = native.iou_any_ge(box, off, min_boxes, thr, want_max=True)
+    want, wmx = olib.iou_any_ge(box, off, min_boxes, thr, want_max=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(gmx.view(np.uint64), wmx.view(np.uint64))
+    assert np.array_equal(native.iou_any_ge(box, off, min_boxes, thr), want)
