@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Randomised soak of the device kernels against the CPU oracle: fresh shapes and seeds every round, through the host entry
+points of the C ABI (K1, K2, K4, K5, K6, K7) and the fused device entry.  Stops at the first mismatch.
+    python tools/soak.py --seconds 240 [--seed N]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def same_f64(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint64), b[~np.isnan(b)].view(np.uint64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--seed", type=int, default=int(time.time()) & 0xffffff)
+    a = ap.parse_args()
+    import torch
+    from helpers import random_boxes, random_polygons
+    from deal_yolo_daya_amd import _native
+    from oracle import lib as olib
+    import test_gpu_yolo as ty
+    L = _native.lib()
+    rng = np.random.default_rng(a.seed)
+    t_end = time.time() + a.seconds
+    rounds, counts = 0, {}
+
+    def bump(name):
+        counts[name] = counts.get(name, 0) + 1
+
+    while time.time() < t_end:
+        rounds += 1
+        seed = int(rng.integers(0, 2 ** 31))
+        r = np.random.default_rng(seed)
+        what = rounds % 7
+        ctx = {"round": rounds, "seed": seed, "what": what}
+        try:
+            if what == 0:      # K1, all three kernels
+                n, mp = int(r.integers(1, 60000)), int(r.choice([3, 12, 30, 60, 300, 3000]))
+                n = min(n, 4_000_000 // mp + 1)
+                xy, off = random_polygons(r, n, mp)
+                obox, oarg = olib.bbox_minmax(xy, off)
+                for v in (-1, 0, 2):
+                    _native.check(L.dyd_set_option(b"k1_variant", v), "opt")
+                    box, arg = _native.bbox_minmax(xy, off)
+                    assert np.array_equal(arg, oarg) and same_f64(box, obox), ("k1", v)
+                _native.check(L.dyd_set_option(b"k1_variant", -1), "opt")
+                bump("k1")
+            elif what == 1:    # K2, small and big rows, with the maximum
+                fixed = int(r.choice([0, 0, 0, 200, 700, 3000]))
+                n_rows = int(r.integers(1, 3000)) if not fixed else int(r.integers(1, max(2, 6000 // fixed)))
+                box, off = random_boxes(r, n_rows, int(r.integers(1, 90)), True, fixed or None)
+                thr, mb = float(r.choice([0.98, 0.5, 0.0, 1.0, 0.9])), int(r.choice([2, 2, 3, 1]))
+                want, wmx = olib.iou_any_ge(box, off, mb, thr, want_max=True)
+                for v in (3, 0, 1, 2):
+                    _native.check(L.dyd_set_option(b"k2_variant", v), "opt")
+                    got, gmx = _native.iou_any_ge(box, off, mb, thr, want_max=True)
+                    assert np.array_equal(got, want) and np.array_equal(gmx.view(np.uint64), wmx.view(np.uint64)), ("k2", v)
+                _native.check(L.dyd_set_option(b"k2_variant", 3), "opt")
+                bump("k2")
+            elif what == 2:    # fused device entry, every variant
+                n_rows = int(r.integers(1, 4000))
+                mb_ = int(r.choice([4, 32, 70, 150]))
+                bx, boff = random_boxes(r, n_rows, mb_, False)
+                B = int(boff[-1])
+                xy, poff = random_polygons(r, B, int(r.choice([5, 12, 40, 120])))
+                obox, oarg = olib.bbox_minmax(xy, poff)
+                want = olib.iou_any_ge(obox, boff, 2, 0.5)
+                dev = torch.device("cuda:0")
+                t_xy = torch.from_numpy(np.ascontiguousarray(xy)).to(dev); t_po = torch.from_numpy(poff).to(dev); t_bo = torch.from_numpy(boff).to(dev)
+                t_box = torch.empty((B, 4), dtype=torch.float64, device=dev); t_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
+                t_high = torch.empty(n_rows, dtype=torch.uint8, device=dev)
+                for v in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8):
+                    _native.check(L.dyd_set_option(b"fused_variant", v), "opt")
+                    t_box.fill_(-7.0); t_arg.fill_(-7); t_high.fill_(9)
+                    _native.check(L.dyd_bbox_iou_fused_dev(t_xy.data_ptr(), t_po.data_ptr(), t_bo.data_ptr(), n_rows, B, int(xy.shape[0]), 2, 0.5,
+                                                           t_box.data_ptr(), t_arg.data_ptr(), t_high.data_ptr(), torch.cuda.current_stream().cuda_stream), "fused")
+                    torch.cuda.synchronize()
+                    assert np.array_equal(t_arg.cpu().numpy(), oarg) and same_f64(t_box.cpu().numpy(), obox), ("fused k1", v)
+                    assert np.array_equal(t_high.cpu().numpy(), want), ("fused k2", v)
+                _native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+                bump("fused")
+            elif what == 3:    # K4 / K5 on keys with many duplicates and forced slot collisions
+                n = int(r.integers(1, 200000))
+                distinct = int(r.choice([1, 3, 50, n // 3 + 1, n]))
+                keys = r.integers(0, 2 ** 63, (distinct, 2), dtype=np.int64).astype(np.uint64)
+                if r.random() < 0.3:
+                    keys[:, 0] &= np.uint64(0xff)                # same home slots
+                h = keys[r.integers(0, distinct, n)]
+                for keep in (0, 1, 2):
+                    assert np.array_equal(_native.dedup(h, {0: "first", 1: "last", 2: False}[keep]), olib.dedup(h, keep)), ("k4", keep)
+                ref = np.concatenate([keys[: max(1, distinct // 2)], r.integers(0, 2 ** 63, (int(r.integers(1, 5000)), 2), dtype=np.int64).astype(np.uint64)])
+                assert np.array_equal(_native.isin(h, ref), olib.isin(h, ref)), "k5"
+                bump("k4k5")
+            elif what == 4:    # K6
+                n, n_cat = int(r.integers(1, 300000)), int(r.choice([1, 2, 7, 300, 2000]))
+                cat = r.integers(-1, n_cat, n).astype(np.int32)
+                sizes = np.bincount(cat[cat >= 0], minlength=n_cat)
+                perm = np.concatenate([r.permutation(int(s)) for s in sizes]).astype(np.int64) if n_cat else np.zeros(0, np.int64)
+                cat_off = np.zeros(n_cat + 1, np.int64); np.cumsum(sizes, out=cat_off[1:])
+                ntr, nva = (sizes * 8 // 10).astype(np.int64), (sizes // 10).astype(np.int64)
+                got = _native.split_ids(cat, perm, cat_off, ntr, nva)
+                want = olib.split_ids(cat, perm, cat_off, ntr, nva)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "k6"
+                bump("k6")
+            else:              # K7, every kernel
+                n_rows, mbx = int(r.integers(1, 20000)), int(r.choice([1, 1, 2, 5, 40, 700]))
+                n_rows = min(n_rows, 400000 // mbx + 1)
+                case = ty._random_case(r, n_rows, mbx, bool(r.integers(0, 2)))
+                for v in (-1, 22, 2, 30):
+                    _native.check(L.dyd_set_option(b"k7_variant", v), "opt")
+                    ty._check_against_oracle(_native, *case)
+                _native.check(L.dyd_set_option(b"k7_variant", -1), "opt")
+                bump("k7")
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps({"FAILED": ctx, "error": repr(e)[:500]}), flush=True)
+            raise
+        if rounds % 50 == 0:
+            print(json.dumps({"rounds": rounds, "counts": counts}), flush=True)
+    print(json.dumps({"soak": "ok", "seed": a.seed, "rounds": rounds, "counts": counts}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
