@@ -864,6 +864,79 @@ __device__ __forceinline__ int64_t lower_bound_off(const int32_t *__restrict__ o
     return lo;
 }
 
+__device__ __forceinline__ RowIn k7_row(int64_t r, const int32_t *__restrict__ row_off, const double *__restrict__ width,
+                                        const double *__restrict__ height, const int32_t *__restrict__ class_id) {
+    RowIn ri;
+    ri.b0 = row_off[r];
+    ri.b1 = row_off[r + 1];
+    ri.w = width[r];
+    ri.h = height[r];
+    ri.cid = class_id[r];
+    ri.host = (ri.w == 0.0) || (ri.h == 0.0) || (ri.cid < 0);
+    return ri;
+}
+
+// A whole WAVE measures / prints one row (the box kernel's tiles of more than K7B_CAP boxes: label files of hundreds of
+// lines): the lanes take the row's boxes 64 at a time, lengths are summed, and while printing an exclusive wave scan of
+// the line costs (length + the "\n" in front; the row's first line writes none) gives every line its place.
+__device__ __forceinline__ void wave_row_measure(const RowIn &r, const double *__restrict__ box4, const uint8_t *__restrict__ sel,
+                                                 int lane, uint32_t &len_out, uint32_t &flag_out) {   // wave-uniform results
+    if (r.host) {
+        len_out = 0;
+        flag_out = 2;
+        return;
+    }
+    uint32_t len = 0, lines = 0;
+    bool exotic = false;
+    const int cd = cid_digits((uint32_t)r.cid);
+    for (int32_t b = r.b0 + lane; b < r.b1; b += kWave) {
+        if (sel && !sel[b]) continue;
+        const Line l = box_line(box4 + 4 * (int64_t)b, r.w, r.h);
+        if (!l.valid) continue;
+        if (l.exotic) exotic = true;
+        else { len += (uint32_t)line_len(l, cd); ++lines; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        len += __shfl_xor(len, d);
+        lines += __shfl_xor(lines, d);
+    }
+    if (__any(exotic)) {
+        len_out = 0;
+        flag_out = 2;
+        return;
+    }
+    flag_out = lines ? 0 : 1;
+    len_out = lines ? len + lines - 1 : 0;
+}
+
+__device__ __forceinline__ void wave_row_print(const RowIn &r, const double *__restrict__ box4, const uint8_t *__restrict__ sel,
+                                               int lane, unsigned char *dst) {
+    const int cd = cid_digits((uint32_t)r.cid);
+    uint32_t done = 0;   // cost of the lines printed so far (wave-uniform)
+    for (int32_t b0 = r.b0; b0 < r.b1; b0 += kWave) {
+        const int32_t b = b0 + lane;
+        Line l;
+        l.valid = false;
+        if (b < r.b1 && (!sel || sel[b])) l = box_line(box4 + 4 * (int64_t)b, r.w, r.h);
+        const uint32_t cost = l.valid ? (uint32_t)line_len(l, cd) + 1u : 0u;
+        uint32_t incl = cost;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, kWave - 1);
+        if (l.valid) {
+            const uint32_t pos = done + incl - cost;   // where this line's "\n" would sit; its text follows
+            if (pos) dst[pos - 1] = '\n';
+            unsigned char *mine = dst + pos;   // (for the row's first line pos is 0: no "\n", the text starts the row)
+            line_put(l, (uint32_t)r.cid, cd, 0, [&](int p, char c) { mine[p] = (unsigned char)c; });
+        }
+        done += total;
+    }
+}
+
 // tile t owns the rows [tile_row[t], tile_row[t + 1]): one binary search per tile, all tiles at once (inside the tile
 // kernel the 20 dependent loads of a search cost more than the rest of the tile)
 __global__ __launch_bounds__(K7_BLOCK) void k7_tile_rows_kernel(const int32_t *__restrict__ row_off, int64_t n_rows, int64_t n_tiles,
@@ -1048,31 +1121,17 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
         }
         tile_bytes = block_scan(len, s_pos);
     } else {
-        // ---- more boxes than the LDS arrays hold: a lane per row, 256 rows at a time; offsets relative to the tile -----
+        // ---- more boxes than the LDS arrays hold: a WAVE per row (the rows here run to hundreds of boxes); offsets relative to the tile -----
         uint32_t carry = 0;
-        for (int64_t c = 0; c < nr; c += K7_BLOCK) {
-            const int64_t r = r_lo + c + tid;
-            RowState st;
-            st.len = 0;
-            st.flag = 1;
+        for (int64_t c = 0; c < nr; c += K7_WAVES) {   // a wave per row, four rows at a time
+            const int64_t r = r_lo + c + wave;
+            uint32_t rlen = 0, rflag = 1;
             if (r < r_hi) {
-                RowIn ri;
-                ri.b0 = row_off[r];
-                ri.b1 = row_off[r + 1];
-                ri.w = width[r];
-                ri.h = height[r];
-                ri.cid = class_id[r];
-                ri.host = (ri.w == 0.0) || (ri.h == 0.0) || (ri.cid < 0);
-                row_measure(ri, box4, sel, st);
-            }
-            uint32_t incl = st.len;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
+                const RowIn ri = k7_row(r, row_off, width, height, class_id);
+                wave_row_measure(ri, box4, sel, lane, rlen, rflag);
             }
             __syncthreads();
-            if (lane == kWave - 1) s_wave[0][wave] = incl;
+            if (lane == 0) s_wave[0][wave] = rlen;
             __syncthreads();
             uint32_t before = carry;
 #pragma unroll
@@ -1080,9 +1139,9 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
                 if (w < wave) before += s_wave[0][w];
                 carry += s_wave[0][w];
             }
-            if (r < r_hi) {
-                text_off[r] = (int64_t)(before + incl - st.len);   // the tile's base is added below
-                flag_out[r] = (uint8_t)st.flag;
+            if (r < r_hi && lane == 0) {
+                text_off[r] = (int64_t)before;   // the tile's base is added below
+                flag_out[r] = (uint8_t)rflag;
             }
         }
         tile_bytes = carry;
@@ -1220,19 +1279,13 @@ __global__ __launch_bounds__(K7_BLOCK) void k7_yolo_box_kernel(const double *__r
         K7B_STAMP(7);
         return;
     }
-    for (int64_t r = r_lo + tid; r < r_hi; r += K7_BLOCK) {   // each lane wrote these entries itself
-        const int64_t at = base + text_off[r];
-        text_off[r] = at;
-        if (text && fits && flag_out[r] == 0) {
-            RowIn ri;
-            ri.b0 = row_off[r];
-            ri.b1 = row_off[r + 1];
-            ri.w = width[r];
-            ri.h = height[r];
-            ri.cid = class_id[r];
-            ri.host = false;
-            unsigned char *mine = text + at;
-            row_print(ri, box4, sel, [&](int p, char c) { mine[p] = (unsigned char)c; });
+    for (int64_t r = r_lo + wave; r < r_hi; r += K7_WAVES) {   // each wave's lane 0 wrote these entries itself
+        const int64_t at = base + __shfl((long long)text_off[r], 0);
+        const int rflag = __shfl((int)flag_out[r], 0);
+        if (lane == 0) text_off[r] = at;
+        if (text && fits && rflag == 0) {
+            const RowIn ri = k7_row(r, row_off, width, height, class_id);
+            wave_row_print(ri, box4, sel, lane, text + at);
         }
     }
     if (tile == n_tiles - 1 && tid == 0) text_off[n_rows] = base + tile_bytes;
