@@ -150,7 +150,7 @@ def main():
                                             out_arg.data_ptr(), sp), "dyd_bbox_minmax_dev")
 
     def k2():
-        _native.check(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, MIN_BOXES, THR,
+        _native.check(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, B, MIN_BOXES, THR,
                                            out_high.data_ptr(), None, sp), "dyd_iou_any_ge_dev")
 
     def fused():

@@ -57,7 +57,7 @@ SIGNATURES = {
     "dyd_bbox_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dyd_bbox_minmax_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_iou_any_ge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
-    "dyd_iou_any_ge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
+    "dyd_iou_any_ge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "dyd_bbox_iou_fused_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -77,6 +77,33 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
     k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave]);
 }
 
+// K2 alone with the wave kernel's pair stage: a wave owns 16 rows, walks them in tiles of whole rows with at most 64 boxes (one
+// box per lane, loaded 32 bytes per lane), and runs the same all-pairs loop — none of the tile kernels' bookkeeping (row ranks,
+// row search, permutation): 0.245 -> 0.15 ms on the bench table.  Rows beyond 64 boxes take the slow partner-tile route,
+// so tables with many of them stay with the tile kernels (launch_k2 decides by the mean).
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k2_wave64_kernel(const double *box4, const int32_t *__restrict__ box_off, int64_t n_rows,
+                                                             int32_t min_boxes, double thr, uint8_t *__restrict__ out_high) {
+    __shared__ WaveFuse s_all[WPB];
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * KW_ROWS;
+    if (r0 >= n_rows) return;
+    const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
+    k12_wave_rows<true>(nullptr, nullptr, box_off, r0, nr, min_boxes, thr, const_cast<double *>(box4), nullptr, out_high, s_all[wave]);
+}
+
+int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
+                     hipStream_t st) {
+    const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KW_ROWS);
+    if (blocks > 0x7fffffffLL) {
+        set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
+        return DYD_ERR_RANGE;
+    }
+    hipLaunchKernelGGL(k2_wave64_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, box4, row_off, n_rows, min_boxes, thr, out_high);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
+}
+
 template <int CHUNK, int WROWS, int WCAP, bool FILTER = false>
 static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
                         int32_t min_boxes, double thr, double *out_box4, int32_t *out_arg4, uint8_t *out_high,
@@ -97,7 +124,7 @@ int launch_k1(const double *xy, const int32_t *pt_off, int64_t n_boxes, int64_t 
               hipStream_t st);
 bool k1_wants_groups(int64_t n_boxes, int64_t n_points);
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above = 0x7fffffff);
+              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above = 0x7fffffff, int64_t n_boxes = -1);
 void set_k1_variant(int v);
 void set_k2_variant(int v);
 void set_k7_variant(int v);
@@ -131,7 +158,7 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     if (g_fused_variant == 1 || (g_fused_variant < 0 && k1_wants_groups(n_boxes, n_points))) {
         int rc = launch_k1(xy, pt_off, n_boxes, n_points, out_box4, out_arg4, st);
         if (rc) return rc;
-        return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st);
+        return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st, 0x7fffffff, n_boxes);
     }
     int v = g_fused_variant;
     // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes

@@ -72,6 +72,8 @@ __device__ __forceinline__ BoxAcc k12_wave_boxes(const double2 *__restrict__ xy,
     return acc;
 }
 
+// BOXES_IN: the boxes already exist (K2 alone): out_box4 is then the INPUT and neither xy / pt_off nor out_arg4 are touched
+template <bool BOXES_IN = false>
 __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
                                               const int32_t *__restrict__ box_off, int64_t r0, int nr,
                                               int32_t min_boxes, double thr, double *out_box4,
@@ -100,8 +102,9 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
         if (taken == 0) {
             // ---- a row with more than 64 boxes: K1 in passes, then K2 over partner tiles ---------
             const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            for (int32_t g = 0; g < n; g += kWave)
-                k12_wave_boxes(xy, pt_off, (int64_t)base + g, (n - g < kWave) ? n - g : kWave, out_box4, out_arg4, S);
+            if (!BOXES_IN)
+                for (int32_t g = 0; g < n; g += kWave)
+                    k12_wave_boxes(xy, pt_off, (int64_t)base + g, (n - g < kWave) ? n - g : kWave, out_box4, out_arg4, S);
             // this wave re-reads its own stores below: wait for them and drop any stale L1 lines
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             bool hit = false;
@@ -136,7 +139,17 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
         const int32_t nb = __builtin_amdgcn_readlane(my_off, rb) - base;  // 0 .. 64 boxes in the tile
         if (nb > 0) {
             // ---- K1: one box per lane ---------------------------------------------------------
-            const BoxAcc acc = k12_wave_boxes(xy, pt_off, (int64_t)base, nb, out_box4, out_arg4, S);
+            BoxAcc acc;
+            if (BOXES_IN) {
+                acc.empty();
+                if (lane < nb) {
+                    const double2 *g2 = reinterpret_cast<const double2 *>(out_box4 + 4 * ((int64_t)base + lane));
+                    const double2 lo2 = g2[0], hi2 = g2[1];
+                    acc.mnx = lo2.x; acc.mny = lo2.y; acc.mxx = hi2.x; acc.mxy = hi2.y;
+                }
+            } else {
+                acc = k12_wave_boxes(xy, pt_off, (int64_t)base, nb, out_box4, out_arg4, S);
+            }
             // ---- hand-off: the lanes overwrite the dead point buffer with their normalised box ------
             int lr = ra;  // the tile row that holds box `lane`
             for (int r2 = ra + 1; r2 < rb; ++r2) lr += (__builtin_amdgcn_readlane(my_off, r2) - base <= lane) ? 1 : 0;

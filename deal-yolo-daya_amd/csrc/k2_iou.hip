@@ -98,13 +98,22 @@ static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_row
 }
 
 // tile variant: 0 = 16 rows / 256 boxes per wave (16 waves per CU), 1 = 8 rows / 128 boxes (32 waves per CU),
-// 2 / 3 = the same two tilings with the f32 reject filter (k2_filter.h)
-static int g_k2_variant = 3;  // default: 8-row tiles + f32 reject filter (best on dense rows, on par on sparse ones)
+// 2 / 3 = the same two tilings with the f32 reject filter (k2_filter.h), 4 = the fused wave kernel's pair stage alone
+// -1 (default): by the table's shape — the wave kernel's pair stage for sparse tables (variant 4), else 8-row tiles + f32 filter (3)
+static int g_k2_variant = -1;
 void set_k2_variant(int v) { g_k2_variant = v; }
 
+int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
+                     hipStream_t st);   // k12_fused.hip
+
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above) {
+              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above, int64_t n_boxes) {
     if (n_rows == 0) return DYD_OK;
+    // sparse tables (at most 32 boxes per image on average, no diagnostic maximum, no rows handed to the big-row kernel): the
+    // wave kernel's pair stage
+    if ((g_k2_variant < 0 || g_k2_variant == 4) && !out_max && skip_above == 0x7fffffff &&
+        (g_k2_variant == 4 || (n_boxes >= 0 && n_boxes <= 32 * n_rows)))
+        return launch_k2_wave64(box4, row_off, n_rows, min_boxes, thr, out_high, st);
     if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
     if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
     if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
@@ -215,14 +224,14 @@ using namespace dyd;
 
 extern "C" {
 
-int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes,
+int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_rows, int64_t n_boxes, int32_t min_boxes,
                        double thr, uint8_t *out_high, double *out_max_iou_or_null, void *stream) {
     DYD_API_ENTER();
     DYD_REQUIRE(n_rows >= 0, "n_rows < 0");
     if (n_rows == 0) return DYD_OK;
     DYD_REQUIRE(row_off && out_high, "null pointer");
     DYD_REQUIRE((reinterpret_cast<uintptr_t>(box4) & 15) == 0, "box4 must be 16-byte aligned");
-    return launch_k2(box4, row_off, n_rows, min_boxes, thr, out_high, out_max_iou_or_null, pick_stream(stream), 0x7fffffff);
+    return launch_k2(box4, row_off, n_rows, min_boxes, thr, out_high, out_max_iou_or_null, pick_stream(stream), 0x7fffffff, n_boxes);
 }
 
 int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
@@ -264,7 +273,7 @@ int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows, i
     }
     KernelTimer t(st);
     rc = launch_k2(d_box.as<double>(), d_off.as<int32_t>(), n_rows, min_boxes, thr, d_high.as<uint8_t>(),
-                   out_max_iou_or_null ? d_max.as<double>() : nullptr, st, big.empty() ? 0x7fffffff : big_above);
+                   out_max_iou_or_null ? d_max.as<double>() : nullptr, st, big.empty() ? 0x7fffffff : big_above, nb);
     if (rc) return rc;
     rc = launch_k2_big_rows(d_box.as<double>(), d_off.as<int32_t>(), d_big.as<int64_t>(), (int32_t)big.size(), min_boxes, thr,
                             d_high.as<uint8_t>(), out_max_iou_or_null ? d_max.as<double>() : nullptr, st);

@@ -97,7 +97,8 @@ int dyd_bbox_minmax_dev(const double *xy, const int32_t *pt_off, int64_t n_boxes
 int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows,
                    int32_t min_boxes, double thr, uint8_t *out_high,
                    double *out_max_iou_or_null);
-int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_rows,
+/* n_boxes = row_off[n_rows] (picks the kernel by the table's shape; negative: not known) */
+int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_rows, int64_t n_boxes,
                        int32_t min_boxes, double thr, uint8_t *out_high,
                        double *out_max_iou_or_null, void *stream);
 

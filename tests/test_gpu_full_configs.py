@@ -168,7 +168,7 @@ def test_config4_dense_256_boxes_per_image(native):
         box[dst] = box[src]
         box[dst, 1] += torch.floor((box[src, 3] - box[src, 1]) * 0.01 * 100) / 100
         high = torch.empty(CHUNK, dtype=torch.uint8, device=dev)
-        ck(L.dyd_iou_any_ge_dev(box.data_ptr(), row_off.data_ptr(), CHUNK, 2, 0.98, high.data_ptr(), None, sp), "k2")
+        ck(L.dyd_iou_any_ge_dev(box.data_ptr(), row_off.data_ptr(), CHUNK, int(box.shape[0]), 2, 0.98, high.data_ptr(), None, sp), "k2")
         assert bool(high[planted].bool().all())
         rows = torch.sort(torch.randperm(CHUNK, generator=torch.Generator().manual_seed(c0 + 1))[:1500]).values.to(dev)
         rows = torch.cat([rows, planted[:100]])
@@ -176,9 +176,9 @@ def test_config4_dense_256_boxes_per_image(native):
         soff = (np.arange(len(rows) + 1) * PER).astype(np.int32)
         assert np.array_equal(high[rows].cpu().numpy(), olib.iou_any_ge(sb, soff, 2, 0.98))   # exact on the sample
         # thr = 0 makes every row with two boxes HIGH (inter == 0 -> 0.0 >= 0 holds, processor.py:334-335)
-        ck(L.dyd_iou_any_ge_dev(box.data_ptr(), row_off.data_ptr(), CHUNK, 2, 0.0, high.data_ptr(), None, sp), "k2")
+        ck(L.dyd_iou_any_ge_dev(box.data_ptr(), row_off.data_ptr(), CHUNK, int(box.shape[0]), 2, 0.0, high.data_ptr(), None, sp), "k2")
         assert bool(high.bool().all())
-        ck(L.dyd_iou_any_ge_dev(box.data_ptr(), row_off.data_ptr(), CHUNK, 257, 0.0, high.data_ptr(), None, sp), "k2")
+        ck(L.dyd_iou_any_ge_dev(box.data_ptr(), row_off.data_ptr(), CHUNK, int(box.shape[0]), 257, 0.0, high.data_ptr(), None, sp), "k2")
         assert not bool(high.bool().any())                                            # fewer boxes than min_boxes
         total_high += 1
         del box, high

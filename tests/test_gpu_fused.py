@@ -79,7 +79,7 @@ def test_dev_entry_points_on_a_side_stream(native):
         t_high = torch.empty(500, dtype=torch.uint8, device=dev)
         native.check(L.dyd_bbox_minmax_dev(t_xy.data_ptr(), t_po.data_ptr(), B, int(t_xy.shape[0]), t_box.data_ptr(), t_arg.data_ptr(),
                                            s.cuda_stream), "k1")
-        native.check(L.dyd_iou_any_ge_dev(t_box.data_ptr(), t_bo.data_ptr(), 500, 2, 0.9, t_high.data_ptr(), None,
+        native.check(L.dyd_iou_any_ge_dev(t_box.data_ptr(), t_bo.data_ptr(), 500, B, 2, 0.9, t_high.data_ptr(), None,
                                           s.cuda_stream), "k2")
     s.synchronize()
     obox, oarg = olib.bbox_minmax(xy, pt_off)
@@ -89,11 +89,12 @@ def test_dev_entry_points_on_a_side_stream(native):
 
 @pytest.mark.parametrize("n_rows,max_boxes,fixed", [(500, 32, None), (2000, 60, None), (40, None, 256), (3, None, 1500),
                                                     (2, None, 700)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4])
 @pytest.mark.parametrize("special", [True, False])
 def test_k2_variants(native, n_rows, max_boxes, fixed, variant, special):
     """K2 tile variants: 1 = 8-row / 128-box wave tiles, 2 / 3 = the f32 reject filter in front of the
-    exact test (16 / 8-row tiles).  Rows above the tile capacity take the streaming path."""
+    exact test (16 / 8-row tiles), 4 = the fused wave kernel's pair stage alone, -1 = by the table's shape.  Rows above
+    the tile capacity take the streaming path."""
     from helpers import random_boxes
     rng = np.random.default_rng(n_rows + (fixed or 0))
     box, off = random_boxes(rng, n_rows, max_boxes or 1, fixed=fixed, special=special)
@@ -105,7 +106,7 @@ def test_k2_variants(native, n_rows, max_boxes, fixed, variant, special):
         res = {(mb, thr): native.iou_any_ge(box, off, mb, thr) for mb, thr in ((2, 0.98), (3, 0.5), (2, 0.0), (2, 1.0))}
         gmx = native.iou_any_ge(box, off, 2, 0.5, want_max=True)
     finally:
-        native.check(L.dyd_set_option(b"k2_variant", 3), "opt")
+        native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
     for (mb, thr), got in res.items():
         assert np.array_equal(got, olib.iou_any_ge(box, off, mb, thr)), (mb, thr)
     wmx = olib.iou_any_ge(box, off, 2, 0.5, want_max=True)
@@ -126,12 +127,12 @@ def test_k2_filter_is_conservative_at_f32_resolution(native):
     box = np.concatenate(rows)
     off = np.zeros(len(rows) + 1, np.int32)
     np.cumsum([len(r) for r in rows], out=off[1:])
-    for variant in (0, 2, 3):
+    for variant in (0, 2, 3, 4, -1):
         native.check(L.dyd_set_option(b"k2_variant", variant), "opt")
         try:
             for thr in (1e-12, 0.5, 0.98):
                 assert np.array_equal(native.iou_any_ge(box, off, 2, thr), olib.iou_any_ge(box, off, 2, thr)), (variant, thr)
             g = native.iou_any_ge(box, off, 2, 0.5, want_max=True)[1]
         finally:
-            native.check(L.dyd_set_option(b"k2_variant", 3), "opt")
+            native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
         assert np.array_equal(g.view(np.uint64), olib.iou_any_ge(box, off, 2, 0.5, want_max=True)[1].view(np.uint64))

@@ -120,15 +120,15 @@ def main():
         nb64 = nbox.to(torch.int64)
         pairs = int((nb64 * (nb64 - 1) // 2).sum().item())
         for variant, nm in ((0, "k2_iou<16,256>"), (1, "k2_iou<8,128>"), (2, "k2f_iou<16,256> (f32 filter)"),
-                            (3, "k2f_iou<8,128> (f32 filter)")):
+                            (3, "k2f_iou<8,128> (f32 filter)"), (4, "k2_wave64 (the fused kernel's pair stage)"), (-1, "k2 auto")):
             ck(L.dyd_set_option(b"k2_variant", variant), "opt")
-            med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, 2, 0.98,
+            med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98,
                                                               out_high.data_ptr(), None, sp), "k2"))
             report(nm, k2_bytes, med, mn, rows_per_s=round(N / med * 1e3), pairs=pairs,
                    gpairs_per_s=round(pairs / med / 1e6, 2), high=int(out_high.sum().item()))
         ck(L.dyd_set_option(b"k2_variant", 3), "opt")
         mx = torch.empty(N, dtype=torch.float64, device=dev)
-        med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, 2, 0.98,
+        med, mn = timeit(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98,
                                                           out_high.data_ptr(), mx.data_ptr(), sp), "k2max"))
         report("k2_iou_want_max", k2_bytes + 8 * N, med, mn, gpairs_per_s=round(pairs / med / 1e6, 2))
 

@@ -62,11 +62,11 @@ def main():
                 box, off = random_boxes(r, n_rows, int(r.integers(1, 90)), True, fixed or None)
                 thr, mb = float(r.choice([0.98, 0.5, 0.0, 1.0, 0.9])), int(r.choice([2, 2, 3, 1]))
                 want, wmx = olib.iou_any_ge(box, off, mb, thr, want_max=True)
-                for v in (3, 0, 1, 2):
+                for v in (-1, 3, 0, 1, 2, 4):
                     _native.check(L.dyd_set_option(b"k2_variant", v), "opt")
                     got, gmx = _native.iou_any_ge(box, off, mb, thr, want_max=True)
                     assert np.array_equal(got, want) and np.array_equal(gmx.view(np.uint64), wmx.view(np.uint64)), ("k2", v)
-                _native.check(L.dyd_set_option(b"k2_variant", 3), "opt")
+                _native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
                 bump("k2")
             elif what == 2:    # fused device entry, every variant
                 n_rows = int(r.integers(1, 4000))
