@@ -39,6 +39,7 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hash_kernel(const uint8_t *__rest
     if (i >= n) return;
     const int64_t s = off[i];
     const int64_t len = off[i + 1] - s;
+    const int64_t total_bytes = off[n];
     const uint8_t *p = bytes + s;
     const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
     uint64_t h1 = 0, h2 = 0;
@@ -54,10 +55,23 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hash_kernel(const uint8_t *__rest
     const uint8_t *tail = p + 16 * nblocks;
     const int rem = (int)(len & 15);
     uint64_t k1 = 0, k2 = 0;
-    for (int t = 0; t < rem; ++t) {
-        const uint64_t v = tail[t];
-        if (t < 8) k1 |= v << (8 * t);
-        else k2 |= v << (8 * (t - 8));
+    if (s + 16 * nblocks + 16 <= total_bytes) {
+        // the 1..15 tail bytes with two 8-byte loads and a mask: the bytes read beyond the cell belong to the next cells (the
+        // buffer is known to reach that far), not one byte load per tail byte
+        if (rem > 0) {
+            k1 = load_u64_unaligned(tail);
+            if (rem < 8) k1 &= (1ull << (8 * rem)) - 1;
+        }
+        if (rem > 8) {
+            k2 = load_u64_unaligned(tail + 8);
+            k2 &= (1ull << (8 * (rem - 8))) - 1;   // rem - 8 is 1..7
+        }
+    } else {   // the last cells of the buffer: byte by byte
+        for (int t = 0; t < rem; ++t) {
+            const uint64_t v = tail[t];
+            if (t < 8) k1 |= v << (8 * t);
+            else k2 |= v << (8 * (t - 8));
+        }
     }
     if (rem > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
     if (rem > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
