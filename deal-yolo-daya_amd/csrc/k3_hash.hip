@@ -44,14 +44,23 @@ __global__ __launch_bounds__(K3_BLOCK) void k3_hash_kernel(const uint8_t *__rest
     const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
     uint64_t h1 = 0, h2 = 0;
     const int64_t nblocks = len >> 4;
-    for (int64_t b = 0; b < nblocks; ++b) {
-        uint64_t k1 = load_u64_unaligned(p + 16 * b);
-        uint64_t k2 = load_u64_unaligned(p + 16 * b + 8);
+    auto mix = [&](uint64_t k1, uint64_t k2) {
         k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
         h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
         k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
         h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    };
+    int64_t b = 0;
+    // long cells: the state chain is sequential but the loads are not — four 16-byte blocks (one 64-byte line) are requested
+    // before the first is mixed, so a lane keeps four loads in flight instead of one
+    for (; b + 4 <= nblocks; b += 4) {
+        const uint8_t *q = p + 16 * b;
+        const uint64_t a0 = load_u64_unaligned(q), a1 = load_u64_unaligned(q + 8), b0 = load_u64_unaligned(q + 16),
+                       b1 = load_u64_unaligned(q + 24), c0 = load_u64_unaligned(q + 32), c1_ = load_u64_unaligned(q + 40),
+                       d0 = load_u64_unaligned(q + 48), d1 = load_u64_unaligned(q + 56);
+        mix(a0, a1); mix(b0, b1); mix(c0, c1_); mix(d0, d1);
     }
+    for (; b < nblocks; ++b) mix(load_u64_unaligned(p + 16 * b), load_u64_unaligned(p + 16 * b + 8));
     const uint8_t *tail = p + 16 * nblocks;
     const int rem = (int)(len & 15);
     uint64_t k1 = 0, k2 = 0;
