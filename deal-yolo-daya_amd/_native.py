@@ -59,6 +59,8 @@ SIGNATURES = {
     "dyd_iou_any_ge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     "dyd_iou_any_ge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "dyd_bbox_iou_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "dyd_bbox_iou_fused_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_hash128": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "dyd_scan_status": (C.c_void_p, [C.c_void_p]),
     "dyd_scan_wh_kind": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_wh_value": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dyd_scan_iou_host": (C.c_void_p, [C.c_void_p]),
     "dyd_scan_free": (None, [C.c_void_p]),
     "dyd_json_scan_labelled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                          C.POINTER(C.c_void_p)]),
@@ -249,6 +252,24 @@ def iou_any_ge(box4: np.ndarray, row_off: np.ndarray, min_boxes: int, thr: float
     check(lib().dyd_iou_any_ge(_ptr(box4), _ptr(row_off), n, int(min_boxes), float(thr), _ptr(high),
                                _ptr(mx) if want_max else None), "dyd_iou_any_ge")
     return (high, mx) if want_max else high
+
+
+def bbox_iou_fused(xy: np.ndarray, pt_off: np.ndarray, box_off: np.ndarray, min_boxes: int, thr: float,
+                   want_box: bool = False):
+    """Fused K1+K2 over host arrays (one launch): (arg4 [B,4] i32, high [N] u8[, box4 [B,4] f64]).  The flag follows the
+    reference's replace -> IoU chain: a row's box list ends at its first polygon without a valid point."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    pt_off = np.ascontiguousarray(pt_off, dtype=np.int32)
+    box_off = np.ascontiguousarray(box_off, dtype=np.int32)
+    n, nb = len(box_off) - 1, len(pt_off) - 1
+    if n < 0 or nb < 0 or box_off[0] != 0 or pt_off[0] != 0 or int(box_off[-1]) != nb or 2 * int(pt_off[-1]) != xy.size:
+        raise ValueError("box_off / pt_off / xy sizes disagree")
+    arg = np.empty((nb, 4), np.int32)
+    high = np.zeros(n, np.uint8)
+    box = np.empty((nb, 4), np.float64) if want_box else None
+    check(lib().dyd_bbox_iou_fused(_ptr(xy), _ptr(pt_off), _ptr(box_off), n, int(min_boxes), float(thr),
+                                   _ptr(box) if want_box else None, _ptr(arg), _ptr(high)), "dyd_bbox_iou_fused")
+    return (arg, high, box) if want_box else (arg, high)
 
 
 def hash128(data: np.ndarray, off: np.ndarray) -> np.ndarray:

@@ -8,7 +8,7 @@ injects its own checker there; no such object exists inside this package.
 """
 from __future__ import annotations
 
-REQUIRED = ("bbox_minmax", "iou_any_ge", "hash128", "dedup", "isin", "mt19937_permutation", "split_ids", "yolo_lines")
+REQUIRED = ("bbox_minmax", "iou_any_ge", "bbox_iou_fused", "hash128", "dedup", "isin", "mt19937_permutation", "split_ids", "yolo_lines")
 
 
 def default_backend():

@@ -450,9 +450,10 @@ def replace_ptlist_frame(df: pd.DataFrame, backend=None, stats: Optional[dict] =
 _LATE_FALLBACK = object()
 
 
-def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, backend):
-    """CSV -> CSV replace step without pandas touching the annotation column (fastcsv + native JSON).
-    Returns NotImplemented whenever the fast path does not apply; nothing has been written then."""
+def _replace_csv_core(input_csv_path, backend, fuse=None):
+    """Shared front of the CSV -> CSV fast paths: native read, one native scan, the device stage, native emit.
+    ``fuse`` = (min_boxes, iou_threshold) runs the fused K1+K2 launch and also yields the HIGH flag per table row
+    (reference chain :262-281 -> :341-376); None runs K1 alone.  Returns NotImplemented when the fast path does not apply."""
     try:
         table = _fc.read_split(str(input_csv_path), [ANNOTATION_COL])
     except (OSError, ValueError, pd.errors.ParserError, UnicodeDecodeError):
@@ -465,10 +466,14 @@ def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, bac
     kept_rows = np.flatnonzero(ann.na == 0)
     excluded_rows = np.flatnonzero(ann.na != 0)
     scan = _nj.scan_polygons_buffers(ann.data, ann.off, ann.na)
-    totals = {"boxes": 0, "points": 0, "host_boxes": 0, "python_cells": 0}
+    totals = {"boxes": 0, "points": 0, "host_boxes": 0, "python_cells": 0, "host_rows": 0}
     irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
     py = (_replace_cells_python(ann.cells(irregular), be, totals) if len(irregular) else ([], [], []))   # may raise, like the reference
-    if scan.n_boxes:
+    high = None
+    if fuse is not None:
+        arg4, high = be.bbox_iou_fused(scan.xy, scan.pt_off, scan.cell_box_off, fuse[0], fuse[1])
+        high = high.astype(bool)
+    elif scan.n_boxes:
         _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
     else:
         arg4 = np.zeros((0, 4), np.int32)
@@ -479,6 +484,14 @@ def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, bac
             if v is Ellipsis:
                 col[i] = json.loads(ann.cell(i)).get(key)
     new_na = (scan.status != _nj.OK).astype(np.uint8)
+    if fuse is not None:
+        high[scan.status != _nj.OK] = False               # no bbox text -> a NaN cell -> no boxes (:344-345)
+        raw = None
+        for i in np.flatnonzero((scan.iou_host != 0) & (scan.status == _nj.OK)).tolist():      # ints beyond 2^25: CPython decides
+            raw = bytes(text) if raw is None else raw
+            high[i] = _iou_mask_python([raw[off[i]:off[i + 1]].decode("utf-8")], fuse[0], fuse[1], be, totals)[0]
+        for j, i in enumerate(irregular.tolist()):
+            high[i] = _iou_mask_python([py[0][j]], fuse[0], fuse[1], be, totals)[0]
     if len(irregular):                                   # splice the Python-path results into the column
         cells = [None] * table.n_rows
         ok_rows = np.flatnonzero(scan.status == _nj.OK)
@@ -504,10 +517,16 @@ def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, bac
     columns += [ann, new_col]
     names += ["width", "height"]
     columns += [full_w, full_h]
-    if not _fc.write_table(str(output_csv_path), names, columns, table.n_rows, rows=kept_rows):
-        scan.close()
+    return {"table": table, "scan": scan, "kept_rows": kept_rows, "excluded_rows": excluded_rows, "names": names,
+            "columns": columns, "high": high, "totals": totals}
+
+
+def _replace_csv_write(core, output_csv_path, excluded_output_file):
+    """processed CSV (native writer) + excluded CSV; returns the step's result dict, or _LATE_FALLBACK when the writer's
+    sample check against pandas refused the table (nothing written then)."""
+    table, kept_rows, excluded_rows = core["table"], core["kept_rows"], core["excluded_rows"]
+    if not _fc.write_table(str(output_csv_path), core["names"], core["columns"], table.n_rows, rows=kept_rows):
         return _LATE_FALLBACK                              # the row count was already printed
-    scan.close()
     if excluded_output_file is not None:
         excluded = table.light.iloc[excluded_rows].copy()
         excluded.insert(table.names.index(ANNOTATION_COL), ANNOTATION_COL, np.nan)
@@ -518,6 +537,18 @@ def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, bac
         "excluded_rows": int(len(excluded_rows)),
         "excluded_output": excluded_output_file,
     }
+
+
+def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, backend):
+    """CSV -> CSV replace step without pandas touching the annotation column (fastcsv + native JSON).
+    Returns NotImplemented whenever the fast path does not apply; nothing has been written then."""
+    core = _replace_csv_core(input_csv_path, backend)
+    if core is NotImplemented:
+        return NotImplemented
+    try:
+        return _replace_csv_write(core, output_csv_path, excluded_output_file)
+    finally:
+        core["scan"].close()
 
 
 def process_csv_replace_ptlist(
@@ -673,6 +704,157 @@ def filter_by_box_count_and_iou(
     Path(other_csv).parent.mkdir(parents=True, exist_ok=True)
     high.to_csv(high_iou_csv, index=False, encoding="utf-8-sig")
     other.to_csv(other_csv, index=False, encoding="utf-8-sig")
+
+
+# =============================================================================== a3 + a4  replace -> IoU in one pass
+# The processing page runs the two steps back to back on the same rows (reference ui/pages/processing.py:580-598), and the
+# replace step's output box IS the two-point ptList the IoU step reads back (:260 -> :354-362).  The functions below do both
+# with ONE native scan, ONE fused K1+K2 launch (dyd_bbox_iou_fused, points / offsets resident on the device between the
+# two stages) and one native emit.  Results are those of the two reference steps in sequence, including the row whose
+# polygon has no valid point: it is emitted with null coordinates and ends the row's IoU box list (:254-255, :364-365).
+def _replace_iou_cells_native(cells, min_boxes, iou_threshold, be, totals):
+    try:
+        scan = _nj.scan_polygons(cells)
+    except UnicodeEncodeError:                         # a lone surrogate somewhere: the two steps in sequence, CPython flatten
+        totals["python_cells"] += len(cells)
+        texts, widths, heights = _replace_cells_python(cells, be, totals)
+        return texts, widths, heights, _iou_mask_python(texts, min_boxes, iou_threshold, be, totals)
+    irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+    totals["python_cells"] += int(len(irregular))
+    # irregular cells first: they are the only ones that can raise, and they must raise before any output
+    py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
+    arg4, high = be.bbox_iou_fused(scan.xy, scan.pt_off, scan.cell_box_off, min_boxes, iou_threshold)
+    high = high.astype(bool)
+    texts = scan.emit(arg4)
+    widths, heights = scan.width_height(0), scan.width_height(1)
+    for col, key in ((widths, "width"), (heights, "height")):
+        for i, v in enumerate(col):
+            if v is Ellipsis:
+                col[i] = json.loads(cells[i]).get(key)
+    high[scan.status != _nj.OK] = False                # no bbox text -> a NaN cell -> no boxes (:344-345)
+    for i in np.flatnonzero((scan.iou_host != 0) & (scan.status == _nj.OK)).tolist():   # ints beyond 2^25: CPython decides
+        high[i] = _iou_mask_python([texts[i]], min_boxes, iou_threshold, be, totals)[0]
+    for j, i in enumerate(irregular.tolist()):
+        texts[i], widths[i], heights[i] = py[0][j], py[1][j], py[2][j]
+        high[i] = _iou_mask_python([py[0][j]], min_boxes, iou_threshold, be, totals)[0]
+    totals["boxes"] += scan.n_boxes
+    totals["points"] += int(scan.xy.shape[0])
+    totals["fused_launches"] += 1
+    scan.close()
+    return texts, widths, heights, high
+
+
+def replace_and_filter_cells(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
+                             stats: Optional[dict] = None) -> tuple:
+    """(new JSON text or None, width, height) per annotation cell plus the HIGH flag the IoU step would give the row:
+    native scan -> fused K1+K2 -> native emit, in batches of _NATIVE_CHUNK_CELLS cells."""
+    be = _backend(backend)
+    cells = list(cells)
+    totals = {"cells": len(cells), "boxes": 0, "points": 0, "host_boxes": 0, "host_rows": 0, "python_cells": 0,
+              "fused_launches": 0}
+    texts, widths, heights, parts = [], [], [], []
+    if _nj.enabled():
+        for start in range(0, len(cells), _NATIVE_CHUNK_CELLS):
+            t, w, h, m = _replace_iou_cells_native(cells[start:start + _NATIVE_CHUNK_CELLS], min_boxes, iou_threshold, be, totals)
+            texts.extend(t); widths.extend(w); heights.extend(h); parts.append(m)
+    else:                                              # DYD_NATIVE_JSON=0: the two steps in sequence on the CPython flatten
+        totals["python_cells"] = len(cells)
+        texts, widths, heights = _replace_cells_python(cells, be, totals)
+        parts.append(_iou_mask_python(texts, min_boxes, iou_threshold, be, totals))
+    high = np.concatenate(parts) if parts else np.zeros(0, bool)
+    if stats is not None:
+        stats.update(totals)
+    return texts, widths, heights, high
+
+
+def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
+                             stats: Optional[dict] = None):
+    """In-memory twin of replace_ptlist -> iou_filter run back to back:
+    -> (kept frame with the three new columns, excluded rows, HIGH rows of kept, other rows of kept)."""
+    kept = df.dropna(subset=[ANNOTATION_COL]).copy()               # :249
+    excluded = df[df[ANNOTATION_COL].isna()].copy()                # :250
+    texts, widths, heights, high = replace_and_filter_cells(kept[ANNOTATION_COL].tolist(), min_boxes, iou_threshold,
+                                                            backend, stats)
+    kept[BBOX_COL] = pd.Series(texts, index=kept.index, dtype=object)
+    kept["width"] = widths
+    kept["height"] = heights
+    return kept, excluded, kept[high], kept[~high]
+
+
+def _as_reread(core, names):
+    """The light columns of the processed table as the IoU step's read_csv would type them (:379): the same table width
+    (heavy cells left empty), parsed by pandas itself; scattered back to table rows for the writer."""
+    table, kept_rows = core["table"], core["kept_rows"]
+    light = {nm: (col.iloc[kept_rows].reset_index(drop=True) if not isinstance(col, _fc.Utf8Column) else np.nan)
+             for nm, col in zip(names, core["columns"])}
+    text = pd.DataFrame(light, columns=names, index=pd.RangeIndex(len(kept_rows))).to_csv(index=False)
+    light_names = [nm for nm, col in zip(names, core["columns"]) if not isinstance(col, _fc.Utf8Column)]
+    back = pd.read_csv(io.StringIO(text), usecols=light_names) if light_names else pd.DataFrame()
+    out = []
+    for nm, col in zip(names, core["columns"]):
+        if isinstance(col, _fc.Utf8Column):
+            out.append(col)
+            continue
+        vals = back[nm].to_numpy()
+        full = np.empty(table.n_rows, dtype=vals.dtype)
+        if vals.dtype == object:
+            full[:] = np.nan
+        else:
+            full[:] = 0
+        full[kept_rows] = vals
+        out.append(pd.Series(full))
+    return out
+
+
+def process_csv_replace_and_filter(
+        input_csv_path: str,
+        output_csv_path: str = "processed_replaced_ptlist.csv",
+        excluded_output_file: Optional[str] = "processed_excluded.csv",
+        high_iou_csv="high_iou_0.98.csv",
+        other_csv="other_data.csv",
+        min_boxes: int = 2,
+        iou_threshold: float = 0.98,
+        backend=None,
+):
+    """process_csv_replace_ptlist(input, output, excluded) followed by filter_by_box_count_and_iou(output, high, other,
+    min_boxes, iou_threshold) — the same five files, prints and return value (the replace step's dict, or None), from one
+    native read, one native scan, one fused K1+K2 launch and one native emit.  Whenever the fast path does not apply (or
+    its writer refuses a table) the two step functions are simply called in sequence."""
+    if _fc.enabled() and _nj.enabled() and os.path.isfile(str(input_csv_path)):
+        core = _replace_csv_core(input_csv_path, backend, fuse=(min_boxes, iou_threshold))
+        if core is not NotImplemented:
+            try:
+                heavy_ok = all((c.na != 0).sum() < len(c) or len(c) == 0 for c in core["columns"]
+                               if isinstance(c, _fc.Utf8Column))                    # an all-NaN text column is re-read as float
+                kept_rows, high = core["kept_rows"], core["high"]
+                res = _replace_csv_write(core, output_csv_path, excluded_output_file) if heavy_ok else _LATE_FALLBACK
+                if res is not _LATE_FALLBACK:
+                    cols = _as_reread(core, core["names"])
+                    n = core["table"].n_rows
+                    ok = (_fc.write_table(str(high_iou_csv), core["names"], cols, n, rows=kept_rows[high[kept_rows]])
+                          and _fc.write_table(str(other_csv), core["names"], cols, n, rows=kept_rows[~high[kept_rows]]))
+                    if ok:
+                        LAST_IO_PATH["replace_iou"] = "fused-native"
+                        LAST_IO_PATH["replace"] = LAST_IO_PATH["iou"] = "native"
+                        return res
+                    LAST_IO_PATH["replace_iou"] = "fused-native + iou step"
+                    LAST_IO_PATH["replace"] = "native"
+                    filter_by_box_count_and_iou(output_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold, backend)
+                    return res
+            finally:
+                core["scan"].close()
+            # the writer refused the processed table after the row count was printed: pandas writes it, silently
+            LAST_IO_PATH["replace_iou"] = "two steps"
+            import contextlib
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = process_csv_replace_ptlist(input_csv_path, output_csv_path, excluded_output_file, backend)
+            filter_by_box_count_and_iou(output_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold, backend)
+            return res
+    LAST_IO_PATH["replace_iou"] = "two steps"
+    res = process_csv_replace_ptlist(input_csv_path, output_csv_path, excluded_output_file, backend)
+    if res is not None:
+        filter_by_box_count_and_iou(output_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold, backend)
+    return res
 
 
 # =============================================================================== a5  split

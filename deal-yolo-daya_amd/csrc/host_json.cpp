@@ -535,6 +535,7 @@ struct CellSink {
     std::string *out = nullptr;
     const int32_t *arg4 = nullptr;  // arg indices of this cell's boxes
     int box = 0;                    // boxes seen so far in this cell
+    bool big_int = false;           // scan: some coordinate is an int beyond 2^25 (the IoU step's products leave f64's exact range)
     WH w, h;
 };
 
@@ -543,6 +544,7 @@ void corner_points(Parser &ps, CellSink &sk, const std::vector<PointTok> &pts) {
         for (const PointTok &t : pts) {
             const Num nx = classify_number(t.x), ny = classify_number(t.y);
             if ((nx.is_int && !nx.exact) || (ny.is_int && !ny.exact)) ps.irregular();  // exact big-int compare
+            if ((nx.is_int && std::fabs(nx.v) > 33554432.0) || (ny.is_int && std::fabs(ny.v) > 33554432.0)) sk.big_int = true;
             sk.xy->push_back(nx.v);
             sk.xy->push_back(ny.v);
         }
@@ -940,6 +942,7 @@ struct dyd_scan {
     std::vector<uint8_t> w_kind, h_kind;
     std::vector<double> w_val, h_val;
     std::vector<uint8_t> sel;           // labelled scan: box carries the row's label
+    std::vector<uint8_t> iou_host;      // polygon scan: the cell's IoU flag needs CPython's exact int arithmetic (see dyd_scan_iou_host)
     // emit output
     std::string text;
     std::vector<int64_t> text_off;
@@ -958,6 +961,7 @@ int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const u
     h->status.assign((size_t)n_cells, CELL_OK);
     h->w_kind.assign((size_t)n_cells, 0); h->h_kind.assign((size_t)n_cells, 0);
     h->w_val.assign((size_t)n_cells, 0.0); h->h_val.assign((size_t)n_cells, 0.0);
+    h->iou_host.assign((size_t)n_cells, 0);
     std::vector<int32_t> boxes_in_cell((size_t)n_cells, 0);
     struct Part { std::vector<double> xy; std::vector<int32_t> npts; int64_t lo = 0, hi = 0; };
     std::vector<Part> parts(64);
@@ -976,6 +980,7 @@ int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const u
                 try {
                     walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
                     boxes_in_cell[(size_t)i] = sk.box;
+                    h->iou_host[(size_t)i] = sk.big_int ? 1 : 0;
                     h->w_kind[(size_t)i] = sk.w.kind; h->w_val[(size_t)i] = sk.w.v;
                     h->h_kind[(size_t)i] = sk.h.kind; h->h_val[(size_t)i] = sk.h.v;
                 } catch (Fail f) {
@@ -1018,6 +1023,7 @@ const int32_t *dyd_scan_cell_box_off(const dyd_scan *h) { return h->cell_box_off
 const uint8_t *dyd_scan_status(const dyd_scan *h) { return h->status.data(); }
 const uint8_t *dyd_scan_wh_kind(const dyd_scan *h, int which) { return which ? h->h_kind.data() : h->w_kind.data(); }
 const double *dyd_scan_wh_value(const dyd_scan *h, int which) { return which ? h->h_val.data() : h->w_val.data(); }
+const uint8_t *dyd_scan_iou_host(const dyd_scan *h) { return h->iou_host.empty() ? nullptr : h->iou_host.data(); }
 
 // Emit the rewritten JSON text of every CELL_OK cell (empty text for the others).  arg4 = K1's arg indices
 // for the boxes of the scan, in scan order.  Output stays owned by the handle.

@@ -92,6 +92,66 @@ __global__ __launch_bounds__(64 * WPB) void k2_wave64_kernel(const double *box4,
     k12_wave_rows<true>(nullptr, nullptr, box_off, r0, nr, min_boxes, thr, const_cast<double *>(box4), nullptr, out_high, s_all[wave]);
 }
 
+// Chain semantics for the variants whose pair stage reads the boxes back from memory (workgroup tiles, the
+// two-launch route of long polygons): a polygon without a valid point (arg index -1) ends its row's IoU box list
+// (reference processor.py:254-255 -> :364-365, see k12_wave.h).  This pass runs after them, looks for such boxes —
+// 16 bytes per box, which is noise for tables of dense rows or long polygons — and recomputes the flag of the few
+// rows that hold one from the prefix before it, pairs in the reference's (i < j) order.
+__global__ __launch_bounds__(256) void k12_null_fix_kernel(const int32_t *__restrict__ arg4, const double *__restrict__ box4,
+                                                           const int32_t *__restrict__ box_off, int64_t n_rows, int64_t n_boxes,
+                                                           int32_t min_boxes, double thr, uint8_t *__restrict__ out_high) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x >> 6) * kWave;
+    const bool zero_hits = (0.0 >= thr);
+    const double thr_lo = (thr > 0.0) ? thr * 0.999 : 0.0;
+    double unused_mx = 0.0;
+    for (int64_t b0 = wave * kWave; b0 < n_boxes; b0 += stride) {
+        const int64_t b = b0 + lane;
+        unsigned long long em = __ballot(b < n_boxes && arg4[4 * b] < 0);
+        while (em != 0ull) {  // wave-uniform
+            const int64_t be = b0 + (__ffsll((long long)em) - 1);
+            em &= em - 1ull;
+            int64_t lo = 0, hi = n_rows;  // the row r with box_off[r] <= be < box_off[r + 1]
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)box_off[mid] <= be) lo = mid; else hi = mid;
+            }
+            const int64_t s = box_off[lo];
+            bool earlier = false;  // an earlier empty polygon of the same row decides instead
+            for (int64_t j = s + lane; j < be; j += kWave) earlier |= arg4[4 * j] < 0;
+            if (__ballot(earlier) != 0ull) continue;
+            const int64_t n = be - s;
+            bool hit = false;
+            if (n >= 2 && n >= min_boxes) {
+                for (int64_t i = lane; i < n - 1; i += kWave) {
+                    const double2 *gi = reinterpret_cast<const double2 *>(box4 + 4 * (s + i));
+                    const Corners me = normalise(gi[0], gi[1]);
+                    const double me_ar = area_of(me);
+                    for (int64_t j = i + 1; j < n; ++j) {
+                        const double2 *gj = reinterpret_cast<const double2 *>(box4 + 4 * (s + j));
+                        const Corners o = normalise(gj[0], gj[1]);
+                        hit |= pair_hits<false, false>(me, o, me_ar, o, thr, thr_lo, zero_hits, unused_mx);
+                    }
+                }
+            }
+            const bool any = __ballot(hit) != 0ull;
+            if (lane == 0) out_high[lo] = (uint8_t)any;
+        }
+    }
+}
+
+static int launch_null_fix(const int32_t *arg4, const double *box4, const int32_t *box_off, int64_t n_rows, int64_t n_boxes,
+                           int32_t min_boxes, double thr, uint8_t *out_high, hipStream_t st) {
+    if (n_boxes == 0 || n_rows == 0) return DYD_OK;
+    const int64_t want = ceil_div(n_boxes, 256);
+    const int64_t cap = (int64_t)ctx().num_cu * 8;
+    hipLaunchKernelGGL(k12_null_fix_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, arg4, box4, box_off, n_rows,
+                       n_boxes, min_boxes, thr, out_high);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
+}
+
 int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
                      hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KW_ROWS);
@@ -158,7 +218,9 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     if (g_fused_variant == 1 || (g_fused_variant < 0 && k1_wants_groups(n_boxes, n_points))) {
         int rc = launch_k1(xy, pt_off, n_boxes, n_points, out_box4, out_arg4, st);
         if (rc) return rc;
-        return launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st, 0x7fffffff, n_boxes);
+        rc = launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st, 0x7fffffff, n_boxes);
+        if (rc) return rc;
+        return launch_null_fix(out_arg4, out_box4, box_off, n_rows, n_boxes, min_boxes, thr, out_high, st);
     }
     int v = g_fused_variant;
     // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
@@ -185,15 +247,56 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         DYD_HIP(hipGetLastError());
         return DYD_OK;
     }
+    int rc;
     if (v == 5)
-        return launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
-    if (v == 6)
-        return launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
-    if (v == 2)
-        return launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
-    if (v == 3)
-        return launch_fused<1024, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
-    return launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+        rc = launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    else if (v == 6)
+        rc = launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    else if (v == 2)
+        rc = launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    else if (v == 3)
+        rc = launch_fused<1024, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    else
+        rc = launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+    if (rc) return rc;
+    return launch_null_fix(out_arg4, out_box4, box_off, n_rows, n_boxes, min_boxes, thr, out_high, st);
+}
+
+// Host-pointer twin: stages the three input arrays, runs the fused launch on the library's stream and copies back the arg
+// indices (what the JSON emitter needs), the flags and — only when asked for — the boxes.
+int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows, int32_t min_boxes,
+                       double thr, double *out_box4_or_null, int32_t *out_arg4, uint8_t *out_high) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n_rows >= 0, "n_rows < 0");
+    if (n_rows == 0) return DYD_OK;
+    DYD_REQUIRE(pt_off && box_off && out_high, "null pointer");
+    DYD_REQUIRE(box_off[0] == 0 && pt_off[0] == 0, "offsets must start at 0");
+    for (int64_t i = 0; i < n_rows; ++i) DYD_REQUIRE(box_off[i + 1] >= box_off[i], "box_off not monotone");
+    const int64_t n_boxes = box_off[n_rows];
+    for (int64_t i = 0; i < n_boxes; ++i) DYD_REQUIRE(pt_off[i + 1] >= pt_off[i], "pt_off not monotone");
+    const int64_t n_pts = pt_off[n_boxes];
+    DYD_REQUIRE(n_pts == 0 || xy, "xy is null");
+    DYD_REQUIRE(n_boxes == 0 || out_arg4, "out_arg4 is null");
+    DevBuf d_xy, d_po, d_bo, d_box, d_arg, d_high;
+    int rc;
+    if ((rc = d_xy.alloc(16 * (size_t)n_pts)) || (rc = d_po.alloc(4 * (size_t)(n_boxes + 1))) ||
+        (rc = d_bo.alloc(4 * (size_t)(n_rows + 1))) || (rc = d_box.alloc(32 * (size_t)n_boxes)) ||
+        (rc = d_arg.alloc(16 * (size_t)n_boxes)) || (rc = d_high.alloc((size_t)n_rows)))
+        return rc;
+    hipStream_t st = ctx().stream;
+    if (n_pts) DYD_HIP(hipMemcpyAsync(d_xy.p, xy, 16 * (size_t)n_pts, hipMemcpyHostToDevice, st));
+    DYD_HIP(hipMemcpyAsync(d_po.p, pt_off, 4 * (size_t)(n_boxes + 1), hipMemcpyHostToDevice, st));
+    DYD_HIP(hipMemcpyAsync(d_bo.p, box_off, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice, st));
+    KernelTimer t(st);
+    rc = dyd_bbox_iou_fused_dev(d_xy.as<double>(), d_po.as<int32_t>(), d_bo.as<int32_t>(), n_rows, n_boxes, n_pts, min_boxes, thr,
+                                d_box.as<double>(), d_arg.as<int32_t>(), d_high.as<uint8_t>(), st);
+    if (rc) return rc;
+    t.finish();
+    if (n_boxes) DYD_HIP(hipMemcpyAsync(out_arg4, d_arg.p, 16 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
+    if (n_boxes && out_box4_or_null) DYD_HIP(hipMemcpyAsync(out_box4_or_null, d_box.p, 32 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(out_high, d_high.p, (size_t)n_rows, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    return DYD_OK;
 }
 
 // Tuning / A-B hook (not part of the reference-facing ABI): selects kernel variants.

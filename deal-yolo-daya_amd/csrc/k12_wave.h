@@ -12,6 +12,12 @@
 //       (reference :328-339, :359-362, :368-376).
 // A row with more than 64 boxes takes a slower general path: K1 in 64-box passes to global
 // memory, then K2 streaming 64-box partner tiles through LDS.
+//
+// Chain semantics (reference :254-255 -> :364-365): a polygon without a valid point becomes a ptList of
+// null coordinates in the replace step, and the IoU step's extract_boxes raises on it inside its blanket
+// try — the row's box list is the PREFIX collected before that object.  K1 marks such a box with
+// arg index -1; the pair stage below ends the row's list at the first of them (one ballot per tile, and
+// nothing else unless a tile really holds an empty polygon).
 #pragma once
 
 #include "k1_tile.h"
@@ -101,10 +107,17 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
         const int taken = __popcll(fits);
         if (taken == 0) {
             // ---- a row with more than 64 boxes: K1 in passes, then K2 over partner tiles ---------
-            const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (!BOXES_IN)
-                for (int32_t g = 0; g < n; g += kWave)
-                    k12_wave_boxes(xy, pt_off, (int64_t)base + g, (n - g < kWave) ? n - g : kWave, out_box4, out_arg4, S);
+            int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
+            if (!BOXES_IN) {
+                int32_t n_eff = n;
+                for (int32_t g = 0; g < n; g += kWave) {
+                    const int cnt = (n - g < kWave) ? n - g : kWave;
+                    const BoxAcc a = k12_wave_boxes(xy, pt_off, (int64_t)base + g, cnt, out_box4, out_arg4, S);
+                    const unsigned long long em = __ballot(lane < cnt && a.imnx < 0);
+                    if (em != 0ull && g + (__ffsll((long long)em) - 1) < n_eff) n_eff = g + (__ffsll((long long)em) - 1);
+                }
+                n = n_eff;  // the row's IoU list ends at its first empty polygon
+            }
             // this wave re-reads its own stores below: wait for them and drop any stale L1 lines
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             bool hit = false;
@@ -154,6 +167,7 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
             int lr = ra;  // the tile row that holds box `lane`
             for (int r2 = ra + 1; r2 < rb; ++r2) lr += (__builtin_amdgcn_readlane(my_off, r2) - base <= lane) ? 1 : 0;
             const Corners me = normalise(make_double2(acc.mnx, acc.mny), make_double2(acc.mxx, acc.mxy));
+            const unsigned long long em = BOXES_IN ? 0ull : __ballot(lane < nb && acc.imnx < 0);  // empty polygons of the tile
             wave_sync();
             if (lane < nb) {
                 S.c.x1[lane] = me.x1; S.c.y1[lane] = me.y1; S.c.x2[lane] = me.x2; S.c.y2[lane] = me.y2;
@@ -163,9 +177,14 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
             // ---- K2: lane owns box i of its row, partners j = i+d (mod n), d = 1..n/2 ---------------
             if (lane < nb) {
                 const int32_t rs = S.off[lr] - base;
-                const int32_t n = S.off[lr + 1] - S.off[lr];
-                if (n >= 2 && n >= min_boxes) {
-                    const int32_t i = lane - rs;
+                int32_t n = S.off[lr + 1] - S.off[lr];
+                if (em != 0ull) {  // wave-uniform, rare: cut the row at its first empty polygon
+                    const unsigned long long row_bits = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) << rs;
+                    const unsigned long long m = em & row_bits;
+                    if (m != 0ull) n = (__ffsll((long long)m) - 1) - rs;
+                }
+                const int32_t i = lane - rs;
+                if (n >= 2 && n >= min_boxes && i < n) {
                     const double me_ar = area_of(me);
                     const int32_t half = n >> 1;
                     const int32_t trips = ((n & 1) == 0 && i >= half) ? half - 1 : half;

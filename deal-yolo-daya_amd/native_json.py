@@ -87,6 +87,7 @@ class PolygonScan(_Scan):
         self.h_kind = _view(L.dyd_scan_wh_kind(handle, 1), np.uint8, n_cells).copy()
         self.w_val = _view(L.dyd_scan_wh_value(handle, 0), np.float64, n_cells).copy()
         self.h_val = _view(L.dyd_scan_wh_value(handle, 1), np.float64, n_cells).copy()
+        self.iou_host = _view(L.dyd_scan_iou_host(handle), np.uint8, n_cells).copy()   # cells whose IoU flag the host decides
 
     def emit_buffers(self, arg4: np.ndarray, n_threads: int = 0) -> tuple:
         """Rewritten JSON text of every cell as flat utf-8 + offsets (views into the handle, valid until

@@ -106,7 +106,16 @@ int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_row
  * One launch that produces K1's outputs and K2's flag for rows whose boxes all come
  * from K1 (processing.py:580-598 runs the two steps back to back on the same rows).
  * box_off : box offsets per image row [n_rows+1], n_boxes = box_off[n_rows], n_points = pt_off[n_boxes]
- *           (or negative: not known); other arguments as K1 / K2. */
+ *           (or negative: not known); other arguments as K1 / K2.
+ * The flag is the one the reference's two steps produce in sequence, not merely "K2 on K1's boxes": a polygon
+ * without a valid point is written as a ptList of null coordinates by the replace step (processor.py:254-255), and
+ * extract_boxes of the IoU step raises on it inside its blanket try (:359 -> :364-365), so the row's box list is the
+ * PREFIX before that object — out_high[r] is computed over that prefix (out_box4 / out_arg4 still cover every box).
+ * dyd_bbox_iou_fused is the host-pointer twin (stages the inputs, copies out_arg4 / out_high back, out_box4 only when
+ * it is not NULL — the JSON emitter needs the arg indices, not the values). */
+int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
+                       int32_t min_boxes, double thr, double *out_box4_or_null, int32_t *out_arg4,
+                       uint8_t *out_high);
 int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_t *box_off,
                            int64_t n_rows, int64_t n_boxes, int64_t n_points, int32_t min_boxes, double thr,
                            double *out_box4, int32_t *out_arg4, uint8_t *out_high, void *stream);
@@ -217,6 +226,10 @@ const int32_t *dyd_scan_cell_box_off(const dyd_scan *scan);   /* [n_cells+1] */
 const uint8_t *dyd_scan_status(const dyd_scan *scan);         /* [n_cells] */
 const uint8_t *dyd_scan_wh_kind(const dyd_scan *scan, int which);   /* which: 0 width, 1 height; 0 none 1 int 2 float 3 other */
 const double *dyd_scan_wh_value(const dyd_scan *scan, int which);
+/* polygon scan only, [n_cells]: 1 = some coordinate of the cell is an int beyond 2^25.  calculate_iou (processor.py:328-339)
+ * multiplies coordinate differences in CPython's exact int arithmetic; f64 follows it only while every product stays below
+ * 2^53, so the fused K1+K2 flag of such a cell is not used: the host decides it from the emitted boxes (flatten.py). */
+const uint8_t *dyd_scan_iou_host(const dyd_scan *scan);
 /* YOLO step (utils.py:681-710, processor.py:1006): per cell the (min x, min y, max x, max y) of every named object
  * with a non-empty ptList, in dyd_scan_xy as box4, and dyd_scan_sel[b] = 1 when the object's name equals the row's
  * label value (label_text / label_off: one label per cell).  Undecodable cells give no boxes, like the reference's

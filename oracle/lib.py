@@ -55,6 +55,28 @@ def iou_any_ge(box4: np.ndarray, row_off: np.ndarray, min_boxes: int, thr: float
     return (high, mx) if want_max else high
 
 
+def bbox_iou_chain(xy: np.ndarray, pt_off: np.ndarray, box_off: np.ndarray, min_boxes: int, thr: float):
+    """The reference's replace step followed by its IoU step on the same rows (processor.py:262-281 then :341-376), at the
+    array interface: K1 per polygon, then per row the all-pairs test over the boxes BEFORE the row's first polygon without a
+    valid point — such a polygon is emitted with null coordinates (:254-255), min(None, None) raises inside extract_boxes'
+    blanket try (:359, :364-365) and the boxes collected so far are what meet_conditions sees.  -> (box4, arg4, high)"""
+    box, arg = bbox_minmax(xy, pt_off)
+    box_off = np.ascontiguousarray(box_off, dtype=np.int64)
+    n = len(box_off) - 1
+    empty = np.flatnonzero(arg[:, 0] < 0)
+    cnt = np.diff(box_off)
+    if len(empty):
+        row = np.searchsorted(box_off, empty, side="right") - 1
+        first = np.full(n, np.iinfo(np.int64).max)
+        np.minimum.at(first, row, empty - box_off[row])
+        cnt = np.minimum(cnt, first)
+    off2 = np.zeros(n + 1, np.int64)
+    np.cumsum(cnt, out=off2[1:])
+    keep = np.repeat(box_off[:-1] - off2[:-1], cnt) + np.arange(int(off2[-1]))
+    high = iou_any_ge(box[keep], off2.astype(np.int32), min_boxes, thr)
+    return box, arg, high
+
+
 def hash128(data: np.ndarray, off: np.ndarray):
     data = np.ascontiguousarray(data, dtype=np.uint8)
     if data.size == 0:

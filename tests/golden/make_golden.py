@@ -207,6 +207,61 @@ def make_iou():
     _dump("iou_cases.json", out)
 
 
+# ------------------------------------------------------------------------------- a3 -> a4 in sequence
+def _poly(*pts):
+    return {"polygon": {"ptList": [{"x": x, "y": y} for x, y in pts]}}
+
+
+_A = [(0, 0), (100, 0), (100, 100), (0, 100)]
+_A98 = [(0, 0), (100, 0), (100, 98), (0, 98)]
+_AF = [(0.5, 0.25), (100.5, 0.25), (100.5, 100.25), (0.5, 100.25)]
+_FAR = [(500, 500), (600, 500), (600, 650)]
+_BIG = [(2 ** 26, 0), (2 ** 26 + 100, 0), (2 ** 26 + 100, 100)]
+CHAIN_CASES = {
+    "A_null_A": {"objects": [_poly(*_A), _poly(), _poly(*_A)]},
+    "A_A_null": {"objects": [_poly(*_A), _poly(*_A), _poly()]},
+    "null_A_A": {"objects": [_poly(), _poly(*_A), _poly(*_A)]},
+    "A_A98_exact_tie": {"objects": [_poly(*_A), _poly(*_A98)]},
+    "A_far_A98_far": {"width": 1920, "height": 1080, "objects": [_poly(*_A), _poly(*_FAR), _poly(*_A98), _poly(*_FAR)]},
+    "float_pair": {"width": 1920.5, "objects": [_poly(*_AF), _poly(*_AF)]},
+    "int_float_mix": {"objects": [_poly(*_A), _poly(*[(float(x), float(y)) for x, y in _A])]},
+    "single": {"objects": [_poly(*_A)]},
+    "none": {"objects": []},
+    "no_polygon_member_then_pair": {"objects": [{"name": "x"}, _poly(*_A), _poly(*_A)]},
+    "pair_then_no_polygon_member": {"objects": [_poly(*_A), _poly(*_A), {"name": "x"}]},
+    "points_without_keys_only": {"objects": [_poly(*_A), {"polygon": {"ptList": [{"x": 1}, 5, None]}}, _poly(*_A)]},
+    "non_dict_objects": {"objects": [3, _poly(*_A), "s", _poly(*_A)]},
+    "big_ints_pair": {"objects": [_poly(*_BIG), _poly(*_BIG)]},
+    "big_ints_disjoint": {"objects": [_poly(*_BIG), _poly(*_FAR)]},
+    "nan_first_point": {"objects": [_poly((float("nan"), 0), (100, 100)), _poly(*_A), _poly(*_A)]},
+    "zero_area_identical": {"objects": [_poly((5, 5), (5, 5)), _poly((5, 5), (5, 5))]},
+    "three_of_which_last_two": {"objects": [_poly(*_FAR), _poly(*_A), _poly(*_A98)]},
+}
+CHAIN_RAW = {"undecodable": '{"objects": [', "blank": " "}
+CHAIN_PARAMS = [(2, 0.98), (3, 0.98), (2, 0.0), (1, 0.5), (2, 0.9800000000000001)]
+
+
+def make_chain():
+    """polygon cells through process_csv_replace_ptlist and then filter_by_box_count_and_iou, as the processing page runs
+    them (ui/pages/processing.py:580-598): every file of both steps"""
+    names = list(CHAIN_CASES) + list(CHAIN_RAW) + ["nan_annotation"]
+    cells = [json.dumps(CHAIN_CASES[n], ensure_ascii=False) for n in CHAIN_CASES] + list(CHAIN_RAW.values()) + [None]
+    sources = [f"http://img/{n}.jpg" for n in names]
+    sources[3] = "007"            # read back as the number 7 by the IoU step
+    out = {"names": names, "runs": []}
+    with tempfile.TemporaryDirectory() as d:
+        inp, proc, exc = (os.path.join(d, n) for n in ("in.csv", "processed.csv", "excluded.csv"))
+        pd.DataFrame({"source": sources, ANN: cells, "extra": list(range(len(cells)))}).to_csv(inp, index=False, encoding="utf-8-sig")
+        res = ref.process_csv_replace_ptlist(inp, proc, exc)
+        out.update({"input_csv": _read_text(inp), "processed_csv": _read_text(proc), "excluded_csv": _read_text(exc),
+                    "result": {"filtered_rows": res["filtered_rows"], "excluded_rows": res["excluded_rows"]}})
+        for mb, thr in CHAIN_PARAMS:
+            hi, lo = os.path.join(d, "hi.csv"), os.path.join(d, "lo.csv")
+            ref.filter_by_box_count_and_iou(proc, hi, lo, mb, thr)
+            out["runs"].append({"min_boxes": mb, "thr": thr, "high_csv": _read_text(hi), "other_csv": _read_text(lo)})
+    _dump("chain_cases.json", out)
+
+
 # ------------------------------------------------------------------------------- a1 / a2
 def make_dedup():
     cases = {
@@ -865,6 +920,6 @@ def make_draw():
 if __name__ == "__main__":
     makers = {"replace": make_replace, "iou": make_iou, "dedup": make_dedup, "ref_filter": make_ref_filter, "perm": make_perm,
               "split": make_split, "e2e": make_e2e, "yolo": make_yolo, "merge": make_merge, "label_replace": make_label_replace,
-              "summaries": make_summaries, "draw": make_draw}
+              "summaries": make_summaries, "draw": make_draw, "chain": make_chain}
     for name in (sys.argv[1:] or list(makers)):
         makers[name]()

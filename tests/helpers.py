@@ -21,6 +21,10 @@ class OracleBackend:
     def iou_any_ge(self, box4, row_off, min_boxes, thr, want_max=False):
         return olib.iou_any_ge(box4, row_off, min_boxes, thr, want_max)
 
+    def bbox_iou_fused(self, xy, pt_off, box_off, min_boxes, thr, want_box=False):
+        box, arg, high = olib.bbox_iou_chain(xy, pt_off, box_off, min_boxes, thr)
+        return (arg, high, box) if want_box else (arg, high)
+
     def hash128(self, data, off):
         return olib.hash128(data, off)
 

@@ -1,5 +1,6 @@
-"""The fused K1+K2 launch (dyd_bbox_iou_fused_dev) and the device-pointer (_dev) entry points on
-HBM-resident tensors, against the CPU oracle.  Needs a real MI355X (-m gpu)."""
+"""The fused K1+K2 launch (dyd_bbox_iou_fused_dev / dyd_bbox_iou_fused) and the device-pointer (_dev) entry points on
+HBM-resident tensors, against the CPU oracle of the reference's replace -> IoU chain (oracle.lib.bbox_iou_chain: a row's IoU box
+list ends at its first polygon without a valid point, processor.py:254-255 -> :364-365).  Needs a real MI355X (-m gpu)."""
 import numpy as np
 import pytest
 
@@ -37,13 +38,12 @@ def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, varia
     rng = np.random.default_rng(n_rows * 13 + max_boxes)
     xy, pt_off, box_off = _table(rng, n_rows, max_boxes, max_pts, special)
     B = len(pt_off) - 1
-    obox, oarg = olib.bbox_minmax(xy, pt_off)
     L = native.lib()
     dev = torch.device("cuda:0")
     t_xy = torch.from_numpy(xy).to(dev) if len(xy) else torch.zeros((1, 2), dtype=torch.float64, device=dev)
     t_po, t_bo = torch.from_numpy(pt_off).to(dev), torch.from_numpy(box_off).to(dev)
     for thr, mb in ((0.98, 2), (0.5, 3)):
-        ohigh = olib.iou_any_ge(obox, box_off, mb, thr)
+        obox, oarg, ohigh = olib.bbox_iou_chain(xy, pt_off, box_off, mb, thr)
         t_box = torch.full((max(B, 1), 4), -7.0, dtype=torch.float64, device=dev)
         t_arg = torch.full((max(B, 1), 4), -7, dtype=torch.int32, device=dev)
         t_high = torch.full((n_rows,), 9, dtype=torch.uint8, device=dev)
@@ -60,6 +60,58 @@ def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, varia
         assert np.array_equal(np.isnan(box), np.isnan(obox))
         assert np.array_equal(box[~np.isnan(box)].view(np.uint64), obox[~np.isnan(obox)].view(np.uint64))
         assert np.array_equal(high, ohigh), (thr, mb)
+
+
+def _chain_table(rng, n_rows, max_boxes, empty_share):
+    """rows of near-identical boxes (every pair is HIGH) with empty polygons planted: whether a row is HIGH then depends
+    only on where its first empty polygon sits"""
+    nb = rng.integers(0, max_boxes + 1, size=n_rows)
+    box_off = np.zeros(n_rows + 1, np.int32)
+    np.cumsum(nb, out=box_off[1:])
+    B = int(box_off[-1])
+    npts = np.where(rng.random(B) < empty_share, 0, 4)
+    pt_off = np.zeros(B + 1, np.int32)
+    np.cumsum(npts, out=pt_off[1:])
+    row = np.repeat(np.arange(n_rows), nb)[np.repeat(np.arange(B), npts)]
+    corner = np.tile(np.array([[0.0, 0.0], [100.0, 0.0], [100.0, 100.0], [0.0, 100.0]]), (int(npts.sum()) // 4, 1))
+    xy = corner + (row % 7)[:, None] * 1000.0
+    return xy, pt_off, box_off
+
+
+@pytest.mark.parametrize("n_rows,max_boxes,share", [(400, 6, 0.3), (3000, 32, 0.05), (300, 64, 0.02), (40, 200, 0.01), (6, 700, 0.003),
+                                                    (50, 5, 1.0)])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 4, 6, 7])
+def test_fused_ends_a_row_at_its_first_empty_polygon(native, n_rows, max_boxes, share, variant):
+    """[A, null, A] is not HIGH, [A, A, null] is (reference processor.py:254-255 -> :364-365): every fused variant, rows below
+    and above the 64 boxes of a wave tile, through the host-pointer entry"""
+    rng = np.random.default_rng(n_rows + max_boxes)
+    xy, pt_off, box_off = _chain_table(rng, n_rows, max_boxes, share)
+    L = native.lib()
+    native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+    try:
+        got = {(mb, thr): native.bbox_iou_fused(xy, pt_off, box_off, mb, thr, want_box=True) for mb, thr in ((2, 0.98), (3, 0.5), (1, 0.0))}
+    finally:
+        native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+    plain_differs = False
+    for (mb, thr), (arg, high, box) in got.items():
+        obox, oarg, ohigh = olib.bbox_iou_chain(xy, pt_off, box_off, mb, thr)
+        assert np.array_equal(arg, oarg)
+        assert np.array_equal(np.isnan(box), np.isnan(obox)) and np.array_equal(box[~np.isnan(box)], obox[~np.isnan(obox)])
+        assert np.array_equal(high, ohigh), (mb, thr, np.flatnonzero(high != ohigh)[:10])
+        plain_differs |= not np.array_equal(ohigh, olib.iou_any_ge(obox, box_off, mb, thr))
+    assert plain_differs or share in (1.0,), "the table must tell the chain from K2-on-K1's-boxes"
+
+
+def test_fused_host_entry_edges(native):
+    """no rows, rows without boxes, boxes without points"""
+    arg, high = native.bbox_iou_fused(np.zeros((0, 2)), np.zeros(1, np.int32), np.zeros(1, np.int32), 2, 0.98)
+    assert arg.shape == (0, 4) and high.shape == (0,)
+    arg, high = native.bbox_iou_fused(np.zeros((0, 2)), np.zeros(1, np.int32), np.zeros(4, np.int32), 2, 0.98)
+    assert arg.shape == (0, 4) and high.tolist() == [0, 0, 0]
+    arg, high = native.bbox_iou_fused(np.zeros((0, 2)), np.zeros(4, np.int32), np.array([0, 3], np.int32), 2, 0.0)
+    assert (arg == -1).all() and high.tolist() == [0]
+    with pytest.raises(ValueError):
+        native.bbox_iou_fused(np.zeros((1, 2)), np.array([0, 2], np.int32), np.array([0, 1], np.int32), 2, 0.98)
 
 
 def test_dev_entry_points_on_a_side_stream(native):

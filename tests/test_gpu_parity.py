@@ -261,6 +261,12 @@ def test_split_golden_gpu(native):
     host.run_split_golden(native)
 
 
+def test_chain_golden_gpu(native, tmp_path):
+    """replace -> IoU through the fused K1+K2 launch behind the step API (process_csv_replace_and_filter,
+    replace_and_filter_frame): the reference's files of both steps, byte for byte"""
+    host.run_chain_golden(native, tmp_path)
+
+
 def test_e2e_golden_gpu(native, tmp_path):
     host.run_e2e_golden(native, tmp_path)
 

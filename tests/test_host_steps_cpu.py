@@ -131,7 +131,69 @@ def run_e2e_golden(backend, tmp_path):
             _frames_equal(frame[want["columns"]], want, (cat, name))
 
 
+def run_chain_golden(backend, tmp_path):
+    """replace -> IoU in ONE pass (fused K1+K2 behind process_csv_replace_and_filter / replace_and_filter_frame) against what the
+    reference's two steps wrote in sequence: tests/golden/chain_cases.json ([A, null, A] is not HIGH, [A, A, null] is, ints
+    beyond 2^25, NaN, objects without a polygon ...) and the 240-row table of the end-to-end fixture."""
+    from oracle import steps as osteps
+
+    g = load_golden("chain_cases.json")
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    write_csv_text(Q("in.csv"), g["input_csv"])
+    for run in g["runs"]:
+        P.LAST_IO_PATH.clear()
+        res = P.process_csv_replace_and_filter(Q("in.csv"), Q("p.csv"), Q("x.csv"), Q("hi.csv"), Q("lo.csv"), run["min_boxes"], run["thr"],
+                                               backend=backend)
+        assert P.LAST_IO_PATH["replace_iou"] == "fused-native"
+        assert res == {"filtered_rows": g["result"]["filtered_rows"], "excluded_rows": g["result"]["excluded_rows"], "excluded_output": Q("x.csv")}
+        assert read_text(Q("p.csv")) == g["processed_csv"] and read_text(Q("x.csv")) == g["excluded_csv"]
+        assert read_text(Q("hi.csv")) == run["high_csv"], (run["min_boxes"], run["thr"])
+        assert read_text(Q("lo.csv")) == run["other_csv"], (run["min_boxes"], run["thr"])
+        # the frame twin: same rows
+        df = pd.read_csv(Q("in.csv"), encoding="utf-8-sig")
+        stats = {}
+        kept, excluded, high, other = P.replace_and_filter_frame(df, run["min_boxes"], run["thr"], backend, stats)
+        assert stats["fused_launches"] == 1 and stats["host_rows"] >= 1            # big_ints_* rows: CPython decides
+        want_hi = pd.read_csv(Q("hi.csv"), encoding="utf-8-sig", dtype={"source": str})["source"].tolist()
+        assert high["source"].tolist() == want_hi and len(high) + len(other) == len(kept) == g["result"]["filtered_rows"]
+        assert kept[P.BBOX_COL].isna().sum() == 2 and len(excluded) == 1
+    # the end-to-end fixture (240 rows through the reference): filtered -> processed / excluded / high / other, byte for byte
+    write_csv_text(Q("filtered.csv"), golden_csv_text("e2e_filtered.csv.gz"))
+    P.LAST_IO_PATH.clear()
+    P.process_csv_replace_and_filter(Q("filtered.csv"), Q("processed.csv"), Q("excluded.csv"), Q("high.csv"), Q("other.csv"), 2, 0.98,
+                                     backend=backend)
+    assert P.LAST_IO_PATH["replace_iou"] == "fused-native"
+    for n in ("processed", "excluded", "high", "other"):
+        assert read_text(Q(n + ".csv")) == golden_csv_text(f"e2e_{n}.csv.gz"), n
+    # random polygon tables with empty polygons planted: fused twin == CPU port of the two reference steps in sequence
+    rng = np.random.default_rng(5)
+    cells = []
+    for _ in range(300):
+        objs = []
+        for _b in range(int(rng.integers(0, 7))):
+            kind = rng.random()
+            if kind < 0.15:
+                objs.append({"polygon": {"ptList": []}})
+            elif kind < 0.2:
+                objs.append({"name": "no polygon"})
+            else:
+                x, y = (int(v) for v in rng.integers(0, 3, size=2) * 200)
+                objs.append({"polygon": {"ptList": [{"x": x, "y": y}, {"x": x + 100, "y": y}, {"x": x + 100, "y": y + 100 - int(rng.integers(0, 4))}]}})
+        cells.append(json.dumps({"objects": objs}))
+    df = pd.DataFrame({"source": [f"s{i}" for i in range(len(cells))], P.ANNOTATION_COL: cells})
+    for mb, thr in ((2, 0.98), (3, 0.5), (0, 0.0)):
+        _, _, high, other = P.replace_and_filter_frame(df, mb, thr, backend)
+        okept, oproj, _ = osteps.replace_frame(df)
+        ohi, olo = osteps.iou_filter_frame(oproj, mb, thr)
+        assert high["source"].tolist() == ohi["source"].tolist() and other["source"].tolist() == olo["source"].tolist(), (mb, thr)
+        assert high[P.BBOX_COL].tolist() == ohi[osteps.NEW_COL].tolist()
+
+
 # ---------------------------------------------------------------------------------- CPU runs
+def test_chain_golden(oracle_backend, tmp_path):
+    run_chain_golden(oracle_backend, tmp_path)
+
+
 def test_replace_golden(oracle_backend, tmp_path):
     run_replace_golden(oracle_backend, tmp_path)
 

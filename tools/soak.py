@@ -74,8 +74,7 @@ def main():
                 bx, boff = random_boxes(r, n_rows, mb_, False)
                 B = int(boff[-1])
                 xy, poff = random_polygons(r, B, int(r.choice([5, 12, 40, 120])))
-                obox, oarg = olib.bbox_minmax(xy, poff)
-                want = olib.iou_any_ge(obox, boff, 2, 0.5)
+                obox, oarg, want = olib.bbox_iou_chain(xy, poff, boff, 2, 0.5)
                 dev = torch.device("cuda:0")
                 t_xy = torch.from_numpy(np.ascontiguousarray(xy)).to(dev); t_po = torch.from_numpy(poff).to(dev); t_bo = torch.from_numpy(boff).to(dev)
                 t_box = torch.empty((B, 4), dtype=torch.float64, device=dev); t_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
