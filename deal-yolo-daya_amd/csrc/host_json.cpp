@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -928,6 +929,37 @@ void parallel_cells(int64_t n, int n_threads, F fn) {
     for (auto &x : th) x.join();
 }
 
+#include "host_json_fast.h"
+
+// as parallel_cells, but a bad_alloc inside a worker is reported instead of ending the process
+template <class F>
+bool parallel_cells_safe(int64_t n, int n_threads, F fn) {
+    int failed = 0;
+    parallel_cells(n, n_threads, [&](int t, int64_t lo, int64_t hi) {
+        try {
+            fn(t, lo, hi);
+        } catch (const std::bad_alloc &) {
+            __atomic_store_n(&failed, 1, __ATOMIC_RELAXED);
+        }
+    });
+    return failed == 0;
+}
+
+template <class F>
+bool parallel_index_safe(int n, F fn) {   // fn(k) for k in [0, n), one thread each
+    int failed = 0;
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; ++k)
+        th.emplace_back([&, k] {
+            try { fn(k); } catch (const std::bad_alloc &) { __atomic_store_n(&failed, 1, __ATOMIC_RELAXED); }
+        });
+    if (n > 0) {
+        try { fn(0); } catch (const std::bad_alloc &) { __atomic_store_n(&failed, 1, __ATOMIC_RELAXED); }
+    }
+    for (auto &x : th) x.join();
+    return failed == 0;
+}
+
 }  // namespace
 
 // ===================================================================================================
@@ -946,79 +978,130 @@ struct dyd_scan {
     // emit output
     std::string text;
     std::vector<int64_t> text_off;
+    // polygon scan (host_json_fast.h): per-thread parts, gathered SoA arrays, gathered text
+    bool fast = false;
+    std::vector<std::unique_ptr<FastPart>> parts;
+    Raw<double> f_xy;
+    Raw<int32_t> f_pt_off;
+    Raw<char> f_text;
 };
 
 extern "C" {
 
 // Scan annotation cells for the replace step (processor.py:262-281).  text/cell_off: concatenated UTF-8
 // cells; missing[i] != 0 marks a NaN cell.  The handle owns every output array.
+// Regular cells go through the single-parse lane of host_json_fast.h; a cell that lane does not take is walked by the
+// exact parser (walk_cell), which also decides between undecodable and irregular.  DYD_JSON_FAST=0 sends every cell there.
 int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
                            int n_threads, dyd_scan **out) {
     if (!out || n_cells < 0 || (n_cells > 0 && !cell_off)) return DYD_ERR_INVALID;
     dyd_scan *h = new (std::nothrow) dyd_scan();
     if (!h) return DYD_ERR_OOM;
-    h->n_cells = n_cells;
-    h->status.assign((size_t)n_cells, CELL_OK);
-    h->w_kind.assign((size_t)n_cells, 0); h->h_kind.assign((size_t)n_cells, 0);
-    h->w_val.assign((size_t)n_cells, 0.0); h->h_val.assign((size_t)n_cells, 0.0);
-    h->iou_host.assign((size_t)n_cells, 0);
-    std::vector<int32_t> boxes_in_cell((size_t)n_cells, 0);
-    struct Part { std::vector<double> xy; std::vector<int32_t> npts; int64_t lo = 0, hi = 0; };
-    std::vector<Part> parts(64);
-    int used = 0;
+    const char *env = getenv("DYD_JSON_FAST");
+    const bool use_fast = !(env && env[0] == '0');
     const bool timing = getenv("DYD_JSON_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
     try {
-        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
-            Part &pt = parts[(size_t)t];
-            pt.lo = lo; pt.hi = hi;
+        h->n_cells = n_cells;
+        h->fast = true;
+        h->status.assign((size_t)n_cells, CELL_OK);
+        h->w_kind.assign((size_t)n_cells, 0); h->h_kind.assign((size_t)n_cells, 0);
+        h->w_val.assign((size_t)n_cells, 0.0); h->h_val.assign((size_t)n_cells, 0.0);
+        h->iou_host.assign((size_t)n_cells, 0);
+        h->cell_box_off.assign((size_t)n_cells + 1, 0);   // holds the per-cell counts until the prefix sum below
+        for (int t = 0; t < 64; ++t) h->parts.emplace_back(new FastPart());
+        int32_t *boxes_in_cell = h->cell_box_off.data() + 1;
+        const bool ok = parallel_cells_safe(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
+            FastPart &A = *h->parts[(size_t)t];
+            A.lo = lo; A.hi = hi;
+            std::string tmp;
+            std::vector<double> sxy;
+            std::vector<int32_t> snp;
+            const size_t bytes = (size_t)(cell_off[hi] - cell_off[lo]);
+            A.seg_off.need((size_t)(hi - lo) + 1);
+            A.lane.need((size_t)(hi - lo));
+            A.seg.need(bytes / 3 + 64);          // the usual share of a cell that is not point text
+            A.xy.need(bytes / 12 + 64);          // ~ one point (2 doubles) per 35 bytes of text
             for (int64_t i = lo; i < hi; ++i) {
-                if (missing && missing[i]) { h->status[(size_t)i] = CELL_MISSING; continue; }
-                const size_t xy_mark = pt.xy.size(), np_mark = pt.npts.size();
+                A.seg_off.push((int64_t)A.seg.n);
+                if (missing && missing[i]) { h->status[(size_t)i] = CELL_MISSING; A.lane.push(0); continue; }
+                const size_t m_xy = A.xy.n, m_ii = A.isint.n, m_np = A.npts.n, m_ho = A.hole.n, m_sg = A.seg.n;
+                const char *b = (const char *)text + cell_off[i], *e = (const char *)text + cell_off[i + 1];
+                if (use_fast) {
+                    FastCell fc(b, e, A, tmp);
+                    if (fc.cell()) {
+                        A.lane.push(1);
+                        boxes_in_cell[i] = fc.box;
+                        h->iou_host[(size_t)i] = fc.big_int ? 1 : 0;
+                        h->w_kind[(size_t)i] = fc.w.kind; h->w_val[(size_t)i] = fc.w.v;
+                        h->h_kind[(size_t)i] = fc.h.kind; h->h_val[(size_t)i] = fc.h.v;
+                        continue;
+                    }
+                    A.xy.n = m_xy; A.isint.n = m_ii; A.npts.n = m_np; A.hole.n = m_ho; A.seg.n = m_sg;
+                }
+                A.lane.push(0);
+                sxy.clear(); snp.clear();
                 CellSink sk;
-                sk.xy = &pt.xy; sk.npts = &pt.npts;
+                sk.xy = &sxy; sk.npts = &snp;
                 try {
-                    walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
-                    boxes_in_cell[(size_t)i] = sk.box;
+                    walk_cell(Span{b, e}, sk);
+                    A.xy.put(sxy.data(), sxy.size());
+                    A.isint.need(sxy.size() / 2);
+                    memset(A.isint.p + A.isint.n, 0, sxy.size() / 2);
+                    A.isint.n += sxy.size() / 2;
+                    A.npts.put(snp.data(), snp.size());
+                    for (size_t k = 0; k < snp.size(); ++k) A.hole.push(0);
+                    boxes_in_cell[i] = sk.box;
                     h->iou_host[(size_t)i] = sk.big_int ? 1 : 0;
                     h->w_kind[(size_t)i] = sk.w.kind; h->w_val[(size_t)i] = sk.w.v;
                     h->h_kind[(size_t)i] = sk.h.kind; h->h_val[(size_t)i] = sk.h.v;
                 } catch (Fail f) {
-                    pt.xy.resize(xy_mark); pt.npts.resize(np_mark);
                     h->status[(size_t)i] = (f.code == 1) ? CELL_UNDECODABLE : CELL_IRREGULAR;
                 }
             }
+            A.seg_off.push((int64_t)A.seg.n);
         });
+        if (!ok) throw std::bad_alloc();
         if (timing) fprintf(stderr, "scan parallel part: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
-        for (auto &pt : parts) if (pt.hi > pt.lo || !pt.npts.empty()) ++used;
-        size_t nb = 0, np2 = 0;
-        for (auto &pt : parts) { nb += pt.npts.size(); np2 += pt.xy.size(); }
-        if (np2 / 2 >= (size_t)1 << 31) { delete h; return DYD_ERR_RANGE; }
-        h->xy.reserve(np2);
-        h->pt_off.reserve(nb + 1);
-        h->pt_off.push_back(0);
-        std::sort(parts.begin(), parts.end(), [](const Part &a, const Part &b) { return a.lo < b.lo; });
-        int32_t run = 0;
-        for (auto &pt : parts) {
-            h->xy.insert(h->xy.end(), pt.xy.begin(), pt.xy.end());
-            for (int32_t c : pt.npts) { run += c; h->pt_off.push_back(run); }
-        }
-        h->cell_box_off.resize((size_t)n_cells + 1);
-        h->cell_box_off[0] = 0;
-        for (int64_t i = 0; i < n_cells; ++i) h->cell_box_off[(size_t)i + 1] = h->cell_box_off[(size_t)i] + boxes_in_cell[(size_t)i];
+        std::sort(h->parts.begin(), h->parts.end(), [](const std::unique_ptr<FastPart> &a, const std::unique_ptr<FastPart> &b) {
+            const bool ea = a->hi <= a->lo, eb = b->hi <= b->lo;   // unused parts last
+            if (ea != eb) return eb;
+            return a->lo < b->lo;
+        });
+        while (!h->parts.empty() && h->parts.back()->hi <= h->parts.back()->lo) h->parts.pop_back();
+        size_t nb = 0, npnt = 0;
+        for (auto &pp : h->parts) { pp->box_base = nb; pp->pt_base = npnt; nb += pp->npts.n; npnt += pp->xy.n / 2; }
+        if (npnt >= (size_t)1 << 31) { delete h; return DYD_ERR_RANGE; }
+        h->f_xy.need(2 * npnt + 2);
+        h->f_xy.n = 2 * npnt;
+        h->f_pt_off.need(nb + 1);
+        h->f_pt_off.n = nb + 1;
+        h->f_pt_off.p[0] = 0;
+        // gather the parts into the contiguous arrays K1 takes, one thread per part
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                FastPart &A = *h->parts[(size_t)k];
+                if (A.xy.n) memcpy(h->f_xy.p + 2 * A.pt_base, A.xy.p, A.xy.n * sizeof(double));
+                int32_t run = (int32_t)A.pt_base;
+                int32_t *po = h->f_pt_off.p + A.box_base + 1;
+                for (size_t b = 0; b < A.npts.n; ++b) { run += A.npts.p[b]; po[b] = run; }
+                A.xy.clear_free();      // pass 2 reads the gathered copies
+                A.npts.clear_free();
+            }))
+            throw std::bad_alloc();
+        for (int64_t i = 0; i < n_cells; ++i) h->cell_box_off[(size_t)i + 1] += h->cell_box_off[(size_t)i];
+        if (timing) fprintf(stderr, "scan total: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
     } catch (const std::bad_alloc &) {
         delete h;
         return DYD_ERR_OOM;
     }
-    (void)used;
     *out = h;
     return DYD_OK;
 }
 
-int64_t dyd_scan_n_boxes(const dyd_scan *h) { return h ? (int64_t)h->pt_off.size() - 1 : 0; }
-int64_t dyd_scan_n_points(const dyd_scan *h) { return h ? (int64_t)h->xy.size() / 2 : 0; }
-const double *dyd_scan_xy(const dyd_scan *h) { return h->xy.data(); }
-const int32_t *dyd_scan_pt_off(const dyd_scan *h) { return h->pt_off.data(); }
+int64_t dyd_scan_n_boxes(const dyd_scan *h) { return h ? (h->fast ? (int64_t)h->f_pt_off.n - 1 : (int64_t)h->pt_off.size() - 1) : 0; }
+int64_t dyd_scan_n_points(const dyd_scan *h) { return h ? (h->fast ? (int64_t)h->f_xy.n / 2 : (int64_t)h->xy.size() / 2) : 0; }
+const double *dyd_scan_xy(const dyd_scan *h) { return h->fast ? h->f_xy.p : h->xy.data(); }
+const int32_t *dyd_scan_pt_off(const dyd_scan *h) { return h->fast ? h->f_pt_off.p : h->pt_off.data(); }
 const int32_t *dyd_scan_cell_box_off(const dyd_scan *h) { return h->cell_box_off.data(); }
 const uint8_t *dyd_scan_status(const dyd_scan *h) { return h->status.data(); }
 const uint8_t *dyd_scan_wh_kind(const dyd_scan *h, int which) { return which ? h->h_kind.data() : h->w_kind.data(); }
@@ -1026,51 +1109,78 @@ const double *dyd_scan_wh_value(const dyd_scan *h, int which) { return which ? h
 const uint8_t *dyd_scan_iou_host(const dyd_scan *h) { return h->iou_host.empty() ? nullptr : h->iou_host.data(); }
 
 // Emit the rewritten JSON text of every CELL_OK cell (empty text for the others).  arg4 = K1's arg indices
-// for the boxes of the scan, in scan order.  Output stays owned by the handle.
+// for the boxes of the scan, in scan order.  Output stays owned by the handle.  Cells of the fast lane are assembled from
+// their segments (no parsing); the others are re-walked by the exact parser.
 int dyd_json_emit_polygons(dyd_scan *h, const uint8_t *text, const int64_t *cell_off, const int32_t *arg4,
                            int n_threads, const uint8_t **out_text, const int64_t **out_off) {
-    if (!h || !out_text || !out_off) return DYD_ERR_INVALID;
+    if (!h || !out_text || !out_off || !h->fast) return DYD_ERR_INVALID;
+    (void)n_threads;   // one thread per part of the scan
     const int64_t n = h->n_cells;
-    std::vector<std::string> parts(64);
-    std::vector<int64_t> lens((size_t)n, 0);
-    std::vector<std::pair<int64_t, int>> order;
-    std::vector<std::pair<int64_t, int64_t>> ranges(64, {0, 0});
     int bad = 0;
     try {
-        parallel_cells(n, n_threads, [&](int t, int64_t lo, int64_t hi) {
-            std::string &o = parts[(size_t)t];
-            ranges[(size_t)t] = {lo, hi};
-            for (int64_t i = lo; i < hi; ++i) {
-                if (h->status[(size_t)i] != CELL_OK) continue;
-                const size_t mark = o.size();
-                CellSink sk;
-                sk.out = &o;
-                sk.arg4 = arg4 + 4 * (int64_t)h->cell_box_off[(size_t)i];
-                try {
-                    walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
-                    lens[(size_t)i] = (int64_t)(o.size() - mark);
-                } catch (Fail) {
-                    o.resize(mark);
-                    __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                FastPart &A = *h->parts[(size_t)k];
+                std::string tmp, slow;
+                A.out.n = 0;
+                A.out_len.n = 0;
+                A.out_len.need((size_t)(A.hi - A.lo));
+                A.out.need(A.seg.n + A.seg.n / 2 + 64);
+                for (int64_t i = A.lo; i < A.hi; ++i) {
+                    const size_t mark = A.out.n;
+                    if (h->status[(size_t)i] != CELL_OK) { A.out_len.push(0); continue; }
+                    const int32_t b0 = h->cell_box_off[(size_t)i], b1 = h->cell_box_off[(size_t)i + 1];
+                    if (A.lane.p[i - A.lo]) {
+                        const char *sg = A.seg.p + A.seg_off.p[i - A.lo];
+                        const size_t sg_len = (size_t)(A.seg_off.p[i - A.lo + 1] - A.seg_off.p[i - A.lo]);
+                        size_t prev = 0;
+                        for (int32_t b = b0; b < b1; ++b) {
+                            const size_t hb = A.hole.p[(size_t)b - A.box_base];
+                            A.out.put(sg + prev, hb - prev);
+                            prev = hb;
+                            const int32_t p0 = h->f_pt_off.p[b], p1 = h->f_pt_off.p[b + 1];
+                            if (!fj_put_corners(A.out, h->f_xy.p + 2 * (size_t)p0, A.isint.p + ((size_t)p0 - A.pt_base), p1 - p0,
+                                                arg4 + 4 * (int64_t)b, tmp))
+                                __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+                        }
+                        A.out.put(sg + prev, sg_len - prev);
+                    } else {
+                        slow.clear();
+                        CellSink sk;
+                        sk.out = &slow;
+                        sk.arg4 = arg4 + 4 * (int64_t)b0;
+                        try {
+                            walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
+                            A.out.put(slow.data(), slow.size());
+                        } catch (Fail) {
+                            A.out.n = mark;
+                            __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+                        }
+                    }
+                    A.out_len.push((int64_t)(A.out.n - mark));
                 }
-            }
-        });
+            }))
+            return DYD_ERR_OOM;
         if (bad) return DYD_ERR_INVALID;  // arg4 inconsistent with the scan
-        std::vector<int> idx;
-        for (int t = 0; t < 64; ++t) if (ranges[(size_t)t].second > ranges[(size_t)t].first) idx.push_back(t);
-        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return ranges[(size_t)a].first < ranges[(size_t)b].first; });
         size_t total = 0;
-        for (int t : idx) total += parts[(size_t)t].size();
-        h->text.clear();
-        h->text.reserve(total);
-        for (int t : idx) h->text += parts[(size_t)t];
+        std::vector<size_t> base(h->parts.size() + 1, 0);
+        for (size_t k = 0; k < h->parts.size(); ++k) { base[k] = total; total += h->parts[k]->out.n; }
+        h->f_text.n = 0;
+        h->f_text.need(total + 1);
+        h->f_text.n = total;
         h->text_off.resize((size_t)n + 1);
         h->text_off[0] = 0;
-        for (int64_t i = 0; i < n; ++i) h->text_off[(size_t)i + 1] = h->text_off[(size_t)i] + lens[(size_t)i];
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                FastPart &A = *h->parts[(size_t)k];
+                if (A.out.n) memcpy(h->f_text.p + base[(size_t)k], A.out.p, A.out.n);
+                int64_t run = (int64_t)base[(size_t)k];
+                for (int64_t i = A.lo; i < A.hi; ++i) { run += A.out_len.p[i - A.lo]; h->text_off[(size_t)i + 1] = run; }
+                A.out.clear_free();
+            }))
+            return DYD_ERR_OOM;
     } catch (const std::bad_alloc &) {
         return DYD_ERR_OOM;
     }
-    *out_text = reinterpret_cast<const uint8_t *>(h->text.data());
+    *out_text = reinterpret_cast<const uint8_t *>(h->f_text.p);
     *out_off = h->text_off.data();
     return DYD_OK;
 }

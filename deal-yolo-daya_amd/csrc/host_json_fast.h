@@ -1,0 +1,629 @@
+// host_json_fast.h — the fast lane of the native flatten / emit (included by host_json.cpp, inside its anonymous namespace).
+//
+// The exact walker of host_json.cpp (Parser / walk_cell) parses every annotation cell TWICE — once to collect the points, once
+// more, after K1, to re-emit the document around the new ptLists — through std::string appends, per-object key sets and
+// exceptions.  On the 10M-row configuration that host work, not the kernels, decides rows/s, so regular cells
+// take this lane instead:
+//
+//   pass 1 (scan)  ONE parse per cell.  Points go to the SoA arrays (value + "was an int token" flag); everything else of the
+//                  document is written straight away in its canonical json.dumps(..., ensure_ascii=False) form into a
+//                  per-thread SEGMENT buffer with a hole where each ptList stood (reference processor.py:262-279);
+//   pass 2 (emit)  no parsing: per cell the segments are copied and each hole is filled with the two corner points K1 chose,
+//                  printed from the stored VALUE — repr(float(tok)) and str(int(tok)) are functions of the value alone, so the
+//                  selected token itself is not needed (ints are exact below 2^53, anything larger never gets here).
+//
+// The lane is deliberately narrow: at the first construct it does not reproduce byte for byte (escaped or repeated keys, odd
+// number spellings, non-array ptList ...) it BAILS, the cell's partial output is rolled back, and the exact walker processes
+// the cell as before — so classification (regular / undecodable / irregular) and every edge case remain the exact walker's.
+#pragma once
+
+// growable raw array: no zero fill, realloc growth (mremap for the multi-GB arrays of a 1M-row batch)
+template <class T>
+struct Raw {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    Raw() = default;
+    Raw(const Raw &) = delete;
+    Raw &operator=(const Raw &) = delete;
+    ~Raw() { free(p); }
+    void grow(size_t need) {
+        size_t c = cap * 2;
+        if (c < need) c = need;
+        if (c < 1024) c = 1024;
+        T *q = static_cast<T *>(realloc(p, c * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = c;
+    }
+    inline void need(size_t k) { if (n + k > cap) grow(n + k); }
+    inline void push(T v) { if (n == cap) grow(n + 1); p[n++] = v; }
+    inline void put(const T *s, size_t k) { need(k); memcpy(p + n, s, k * sizeof(T)); n += k; }
+    void clear_free() { free(p); p = nullptr; n = cap = 0; }
+};
+
+struct FastPart {
+    int64_t lo = 0, hi = 0;          // cell range [lo, hi)
+    Raw<double> xy;                  // 2 per point
+    Raw<uint8_t> isint;              // per point: bit 0 = x was an int token, bit 1 = y
+    Raw<int32_t> npts;               // per box
+    Raw<uint32_t> hole;              // per box: where its ptList goes inside the cell's segment text
+    Raw<char> seg;                   // canonical text of the lane's cells, ptLists cut out
+    Raw<int64_t> seg_off;            // per cell: start in seg (hi - lo + 1 entries)
+    Raw<uint8_t> lane;               // per cell: 1 = segments (this lane), 0 = the exact walker re-parses it in pass 2
+    // pass 2
+    Raw<char> out;
+    Raw<int64_t> out_len;            // per cell
+    size_t box_base = 0, pt_base = 0;  // global index of the part's first box / point
+};
+
+inline bool fj_is_digit(char c) { return c >= '0' && c <= '9'; }
+inline bool fj_is_ws(char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }
+
+// integer value -> decimal text (|v| < 2^63)
+inline size_t fj_put_int(char *dst, int64_t v) {
+    char tmp[24];
+    size_t k = 0;
+    uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+    do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    size_t o = 0;
+    if (v < 0) dst[o++] = '-';
+    while (k) dst[o++] = tmp[--k];
+    return o;
+}
+
+struct FastNum {
+    const char *b = nullptr, *e = nullptr;   // the token
+    bool is_int = false, exact = false, big = false;   // big: more digits than the lane evaluates (value not set)
+    double v = 0.0;
+    // canonical spelling: [b, canon_e) when canon_e != nullptr (ints, and floats whose trimmed token IS their repr), else print v
+    const char *canon_e = nullptr;
+    bool minus_zero_int = false;             // the int token "-0" prints as "0"
+};
+
+struct FastKeys {   // duplicate-key check of one JSON object (bail above 24 members)
+    const char *b[24];
+    uint32_t len[24];
+    int n = 0;
+    inline bool add(const char *kb, size_t kl) {   // false -> bail
+        for (int i = 0; i < n; ++i)
+            if (len[i] == kl && !memcmp(b[i], kb, kl)) return false;
+        if (n == 24) return false;
+        b[n] = kb;
+        len[n] = (uint32_t)kl;
+        ++n;
+        return true;
+    }
+};
+
+struct FastCell {
+    const char *p, *end;
+    FastPart &A;
+    std::string &tmp;     // scratch of the thread (escaped strings, general float printing)
+    int depth = 0;
+    int box = 0;
+    bool big_int = false;
+    WH w, h;
+
+    FastCell(const char *b, const char *e, FastPart &a, std::string &t) : p(b), end(e), A(a), tmp(t) {}
+
+    inline void ws() { while (p < end && fj_is_ws(*p)) ++p; }
+    inline void put(const char *s, size_t k) { A.seg.put(s, k); }
+    inline void putc(char c) { A.seg.push(c); }
+    template <size_t N>
+    inline void lit(const char (&s)[N]) { A.seg.put(s, N - 1); }
+
+    // p at '"': a string without escapes / control characters; b..e = the raw span between the quotes
+    inline bool plain_string(const char *&b, const char *&e) {
+        const char *q = p + 1;
+        while (q < end) {
+            const unsigned char c = (unsigned char)*q;
+            if (c == '"') { b = p + 1; e = q; p = q + 1; return true; }
+            if (c == '\\' || c < 0x20) return false;
+            ++q;
+        }
+        return false;
+    }
+
+    // p at '"': copies the string in its canonical spelling
+    template <bool OUT>
+    bool string_value() {
+        const char *b, *e;
+        if (plain_string(b, e)) {
+            if (OUT) put(b - 1, (size_t)(e - b) + 2);
+            return true;
+        }
+        try {   // escapes: the exact decoder / re-encoder, for this one string
+            Parser ps{p, end};
+            const Span s = ps.string_token();
+            if (OUT) {
+                tmp.clear();
+                ps.emit_string(tmp, s);
+                put(tmp.data(), tmp.size());
+            }
+            p = ps.p;
+            return true;
+        } catch (Fail) {
+            return false;
+        }
+    }
+
+    // p at the first character of a number (digit, '-', 'N', 'I').  false -> bail.
+    bool number(FastNum &t) {
+        const char *q = p;
+        t = FastNum();
+        t.b = q;
+        bool neg = false;
+        if (*q == '-') { neg = true; ++q; if (q >= end) return false; }
+        if (*q == 'N') {
+            if (neg || end - q < 3 || memcmp(q, "NaN", 3)) return false;
+            q += 3;
+            t.v = NAN; t.canon_e = q;
+        } else if (*q == 'I') {
+            if (end - q < 8 || memcmp(q, "Infinity", 8)) return false;
+            q += 8;
+            t.v = neg ? -INFINITY : INFINITY; t.canon_e = q;
+        } else {
+            const char *ib = q;
+            if (*q == '0') {
+                ++q;
+                if (q < end && fj_is_digit(*q)) return false;   // "01": NUMBER_RE stops after the 0
+            } else if (*q >= '1' && *q <= '9') {
+                while (q < end && fj_is_digit(*q)) ++q;
+            } else {
+                return false;
+            }
+            const char *ie = q, *fb = nullptr, *fe = nullptr;
+            if (q < end && *q == '.') {
+                if (q + 1 < end && fj_is_digit(q[1])) {
+                    fb = ++q;
+                    while (q < end && fj_is_digit(*q)) ++q;
+                    fe = q;
+                } else {
+                    return false;
+                }
+            }
+            bool has_exp = false;
+            if (q < end && (*q == 'e' || *q == 'E')) {
+                const char *r = q + 1;
+                if (r < end && (*r == '+' || *r == '-')) ++r;
+                if (r < end && fj_is_digit(*r)) {
+                    while (r < end && fj_is_digit(*r)) ++r;
+                    q = r;
+                    has_exp = true;
+                } else {
+                    return false;
+                }
+            }
+            const size_t n_int = (size_t)(ie - ib), n_frac = fb ? (size_t)(fe - fb) : 0;
+            if (!fb && !has_exp) {   // an int token
+                t.is_int = true;
+                t.canon_e = q;
+                if (n_int <= 18) {
+                    uint64_t m = 0;
+                    for (const char *d = ib; d < ie; ++d) m = m * 10 + (uint64_t)(*d - '0');
+                    t.exact = m <= 9007199254740992ull;
+                    t.v = neg ? -(double)m : (double)m;
+                    t.minus_zero_int = neg && m == 0;
+                } else {
+                    t.big = true;
+                    if (q - t.b > 4000) return false;   // int() refuses more than 4300 digits: the exact walker's business
+                }
+            } else if (has_exp || n_int + n_frac > 19) {
+                char buf[64];
+                const size_t tl = (size_t)(q - t.b);
+                if (tl >= sizeof(buf)) return false;
+                memcpy(buf, t.b, tl);
+                buf[tl] = 0;
+                t.v = strtod(buf, nullptr);   // glibc: correctly rounded, like float()
+            } else {
+                uint64_t m = 0;
+                int first_nz = -1, last_nz = -1, idx = 0;
+                for (const char *d = ib; d < ie; ++d, ++idx) { m = m * 10 + (uint64_t)(*d - '0'); if (*d != '0') { if (first_nz < 0) first_nz = idx; last_nz = idx; } }
+                for (const char *d = fb; d < fe; ++d, ++idx) { m = m * 10 + (uint64_t)(*d - '0'); if (*d != '0') { if (first_nz < 0) first_nz = idx; last_nz = idx; } }
+                static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                             1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+                if (m <= 9007199254740992ull) {
+                    const double d = (double)m / p10[n_frac];   // exact operands, one correctly rounded division (Clinger)
+                    t.v = neg ? -d : d;
+                } else {
+                    char buf[64];
+                    const size_t tl = (size_t)(q - t.b);
+                    memcpy(buf, t.b, tl);
+                    buf[tl] = 0;
+                    t.v = strtod(buf, nullptr);
+                }
+                // repr(float(tok)) == the token minus trailing fractional zeros when it has at most 15 significant digits
+                // (every such decimal survives the round trip through f64, so the shortest round-tripping spelling is the
+                // token itself) and repr prints in fixed notation: 1e-4 <= |v| < 1e16, or v == 0
+                const int sig = first_nz < 0 ? 0 : last_nz - first_nz + 1;
+                const int lead_frac_zeros = (first_nz < 0) ? 0 : first_nz - (int)n_int;   // zeros between the point and the first digit
+                const bool fixed = first_nz < 0 || first_nz < (int)n_int || lead_frac_zeros <= 3;
+                if (sig <= 15 && n_int <= 16 && fixed) {
+                    const char *ce = fe;
+                    while (ce > fb + 1 && ce[-1] == '0') --ce;
+                    t.canon_e = ce;
+                }
+            }
+        }
+        if (q < end) {   // what follows must end the value, or the document is not JSON (the exact walker says which)
+            const char c = *q;
+            if (!(c == ',' || c == '}' || c == ']' || fj_is_ws(c))) return false;
+        }
+        t.e = q;
+        p = q;
+        return true;
+    }
+
+    inline void put_number(const FastNum &t) {
+        if (t.minus_zero_int) { putc('0'); return; }
+        if (t.canon_e) { put(t.b, (size_t)(t.canon_e - t.b)); return; }
+        tmp.clear();
+        append_py_float(tmp, t.v);
+        put(tmp.data(), tmp.size());
+    }
+
+    inline bool literal(const char *s, size_t k) {
+        if ((size_t)(end - p) < k || memcmp(p, s, k)) return false;
+        p += k;
+        return true;
+    }
+
+    // any JSON value, canonical copy (OUT) or validation only
+    template <bool OUT>
+    bool value() {
+        ws();
+        if (p >= end) return false;
+        switch (*p) {
+            case '{': {
+                if (++depth > 200) return false;
+                ++p;
+                if (OUT) putc('{');
+                ws();
+                if (p < end && *p == '}') { ++p; if (OUT) putc('}'); --depth; return true; }
+                FastKeys ks;
+                bool first = true;
+                while (true) {
+                    ws();
+                    if (p >= end || *p != '"') return false;
+                    const char *kb, *ke;
+                    if (!plain_string(kb, ke)) return false;
+                    if (!ks.add(kb, (size_t)(ke - kb))) return false;
+                    if (OUT) {
+                        if (!first) lit(", ");
+                        put(kb - 1, (size_t)(ke - kb) + 2);
+                        lit(": ");
+                    }
+                    first = false;
+                    ws();
+                    if (p >= end || *p != ':') return false;
+                    ++p;
+                    if (!value<OUT>()) return false;
+                    ws();
+                    if (p < end && *p == ',') { ++p; continue; }
+                    if (p < end && *p == '}') { ++p; break; }
+                    return false;
+                }
+                if (OUT) putc('}');
+                --depth;
+                return true;
+            }
+            case '[': {
+                if (++depth > 200) return false;
+                ++p;
+                if (OUT) putc('[');
+                ws();
+                if (p < end && *p == ']') { ++p; if (OUT) putc(']'); --depth; return true; }
+                bool first = true;
+                while (true) {
+                    if (OUT && !first) lit(", ");
+                    first = false;
+                    if (!value<OUT>()) return false;
+                    ws();
+                    if (p < end && *p == ',') { ++p; continue; }
+                    if (p < end && *p == ']') { ++p; break; }
+                    return false;
+                }
+                if (OUT) putc(']');
+                --depth;
+                return true;
+            }
+            case '"': return string_value<OUT>();
+            case 't': if (!literal("true", 4)) return false; if (OUT) lit("true"); return true;
+            case 'f': if (!literal("false", 5)) return false; if (OUT) lit("false"); return true;
+            case 'n': if (!literal("null", 4)) return false; if (OUT) lit("null"); return true;
+            default: {
+                const char c = *p;
+                if (!(c == '-' || c == 'N' || c == 'I' || fj_is_digit(c))) return false;
+                FastNum t;
+                if (!number(t)) return false;
+                if (OUT) put_number(t);
+                return true;
+            }
+        }
+    }
+
+    // the hole of one ptList: npts points were pushed for it
+    inline void close_box(int32_t npts) {
+        A.npts.push(npts);
+        A.hole.push((uint32_t)(A.seg.n - (size_t)A.seg_off.p[A.seg_off.n - 1]));
+        ++box;
+    }
+
+    // p at the '[' of a ptList (reference :253): pushes the valid points; no output
+    bool ptlist(int32_t &count) {
+        ++p;
+        count = 0;
+        ws();
+        if (p < end && *p == ']') { ++p; return true; }
+        while (true) {
+            ws();
+            if (p >= end) return false;
+            if (*p == '{') {
+                ++p;
+                bool hx = false, hy = false;
+                FastNum nx, ny;
+                ws();
+                if (p < end && *p == '}') {
+                    ++p;
+                } else {
+                    FastKeys ks;
+                    while (true) {
+                        ws();
+                        if (p >= end || *p != '"') return false;
+                        const char *kb, *ke;
+                        if (!plain_string(kb, ke)) return false;
+                        if (!ks.add(kb, (size_t)(ke - kb))) return false;
+                        ws();
+                        if (p >= end || *p != ':') return false;
+                        ++p;
+                        const bool isx = (ke - kb == 1 && *kb == 'x'), isy = (ke - kb == 1 && *kb == 'y');
+                        if (isx || isy) {
+                            ws();
+                            if (p >= end) return false;
+                            const char c = *p;
+                            if (!(c == '-' || c == 'N' || c == 'I' || fj_is_digit(c))) return false;   // None / str / ...: exact walker
+                            FastNum &t = isx ? nx : ny;
+                            if (!number(t)) return false;
+                            if (t.big || (t.is_int && !t.exact)) return false;
+                            if (isx) hx = true; else hy = true;
+                        } else if (!value<false>()) {
+                            return false;
+                        }
+                        ws();
+                        if (p < end && *p == ',') { ++p; continue; }
+                        if (p < end && *p == '}') { ++p; break; }
+                        return false;
+                    }
+                }
+                if (hx && hy) {
+                    A.xy.need(2);
+                    A.xy.p[A.xy.n] = nx.v;
+                    A.xy.p[A.xy.n + 1] = ny.v;
+                    A.xy.n += 2;
+                    A.isint.push((uint8_t)((nx.is_int ? 1 : 0) | (ny.is_int ? 2 : 0)));
+                    if ((nx.is_int && std::fabs(nx.v) > 33554432.0) || (ny.is_int && std::fabs(ny.v) > 33554432.0)) big_int = true;
+                    ++count;
+                }
+            } else if (!value<false>()) {   // a non-dict element is not a valid point
+                return false;
+            }
+            ws();
+            if (p < end && *p == ',') { ++p; continue; }
+            if (p < end && *p == ']') { ++p; return true; }
+            return false;
+        }
+    }
+
+    // generic object walker with one special member; SPECIAL(key) handles the value and returns 0 bail / 1 handled / 2 not mine
+    bool polygon() {   // p at '{'
+        ++p;
+        putc('{');
+        bool first = true, seen = false;
+        FastKeys ks;
+        ws();
+        if (p < end && *p == '}') {
+            ++p;
+        } else {
+            while (true) {
+                ws();
+                if (p >= end || *p != '"') return false;
+                const char *kb, *ke;
+                if (!plain_string(kb, ke)) return false;
+                if (!ks.add(kb, (size_t)(ke - kb))) return false;
+                if (!first) lit(", ");
+                first = false;
+                put(kb - 1, (size_t)(ke - kb) + 2);
+                lit(": ");
+                ws();
+                if (p >= end || *p != ':') return false;
+                ++p;
+                if (ke - kb == 6 && !memcmp(kb, "ptList", 6)) {
+                    ws();
+                    if (p >= end || *p != '[') return false;   // None / str / dict / number ptList: exact walker
+                    seen = true;
+                    int32_t cnt;
+                    if (!ptlist(cnt)) return false;
+                    close_box(cnt);
+                } else if (!value<true>()) {
+                    return false;
+                }
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; break; }
+                return false;
+            }
+        }
+        if (!seen) {   // obj.get("polygon", {}).get("ptList", []) -> []; the ptList member is appended (:276)
+            if (!first) lit(", ");
+            lit("\"ptList\": ");
+            close_box(0);
+        }
+        putc('}');
+        return true;
+    }
+
+    bool object() {   // p at '{': one dict element of "objects"
+        ++p;
+        putc('{');
+        bool first = true, seen = false;
+        FastKeys ks;
+        ws();
+        if (p < end && *p == '}') {
+            ++p;
+        } else {
+            while (true) {
+                ws();
+                if (p >= end || *p != '"') return false;
+                const char *kb, *ke;
+                if (!plain_string(kb, ke)) return false;
+                if (!ks.add(kb, (size_t)(ke - kb))) return false;
+                if (!first) lit(", ");
+                first = false;
+                put(kb - 1, (size_t)(ke - kb) + 2);
+                lit(": ");
+                ws();
+                if (p >= end || *p != ':') return false;
+                ++p;
+                if (ke - kb == 7 && !memcmp(kb, "polygon", 7)) {
+                    ws();
+                    if (p >= end || *p != '{') return false;   // None / list ...: AttributeError in Python -> exact walker
+                    seen = true;
+                    if (!polygon()) return false;
+                } else if (!value<true>()) {
+                    return false;
+                }
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; break; }
+                return false;
+            }
+        }
+        if (!seen) {   // :274-276 — a polygon dict is added at the end
+            if (!first) lit(", ");
+            lit("\"polygon\": {\"ptList\": ");
+            close_box(0);
+            putc('}');
+        }
+        putc('}');
+        return true;
+    }
+
+    bool read_wh(WH &dst) {
+        ws();
+        if (p >= end) return false;
+        const char c = *p;
+        if (c == 'n') { dst.kind = 0; return value<true>(); }
+        if (c == '-' || c == 'N' || c == 'I' || fj_is_digit(c)) {
+            FastNum t;
+            if (!number(t)) return false;
+            put_number(t);
+            if (t.big || (t.is_int && !t.exact)) { dst.kind = 3; return true; }
+            dst.kind = t.is_int ? 1 : 2;
+            dst.v = t.v;
+            return true;
+        }
+        dst.kind = 3;
+        return value<true>();
+    }
+
+    // the whole cell; false -> bail (the caller rolls the part back to its marks)
+    bool cell() {
+        ws();
+        if (p >= end || *p != '{') return false;
+        ++p;
+        putc('{');
+        bool first = true, seen = false;
+        FastKeys ks;
+        ws();
+        if (p < end && *p == '}') {
+            ++p;
+        } else {
+            while (true) {
+                ws();
+                if (p >= end || *p != '"') return false;
+                const char *kb, *ke;
+                if (!plain_string(kb, ke)) return false;
+                if (!ks.add(kb, (size_t)(ke - kb))) return false;
+                if (!first) lit(", ");
+                first = false;
+                put(kb - 1, (size_t)(ke - kb) + 2);
+                lit(": ");
+                ws();
+                if (p >= end || *p != ':') return false;
+                ++p;
+                const size_t kl = (size_t)(ke - kb);
+                if (kl == 7 && !memcmp(kb, "objects", 7)) {
+                    ws();
+                    if (p >= end || *p != '[') return false;   // null / dict / str / number "objects": exact walker
+                    seen = true;
+                    ++p;
+                    putc('[');
+                    bool efirst = true;
+                    ws();
+                    if (p < end && *p == ']') {
+                        ++p;
+                    } else {
+                        while (true) {
+                            ws();
+                            if (p < end && *p == '{') {
+                                if (!efirst) lit(", ");
+                                efirst = false;
+                                if (!object()) return false;
+                            } else if (!value<false>()) {   // non-dict objects are dropped (:270)
+                                return false;
+                            }
+                            ws();
+                            if (p < end && *p == ',') { ++p; continue; }
+                            if (p < end && *p == ']') { ++p; break; }
+                            return false;
+                        }
+                    }
+                    putc(']');
+                } else if (kl == 5 && !memcmp(kb, "width", 5)) {
+                    if (!read_wh(w)) return false;
+                } else if (kl == 6 && !memcmp(kb, "height", 6)) {
+                    if (!read_wh(h)) return false;
+                } else if (!value<true>()) {
+                    return false;
+                }
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; break; }
+                return false;
+            }
+        }
+        ws();
+        if (p != end) return false;   // "Extra data"
+        if (!seen) { if (!first) lit(", "); lit("\"objects\": []"); }   // data["objects"] = [] (:278)
+        putc('}');
+        return true;
+    }
+};
+
+// pass 2 helper: one coordinate printed from its value
+inline void fj_put_coord(Raw<char> &o, double v, bool is_int, std::string &tmp) {
+    if (is_int) {
+        o.need(24);
+        o.n += fj_put_int(o.p + o.n, (int64_t)v);   // exact: |v| <= 2^53; -0.0 (the token "-0") prints as 0
+        return;
+    }
+    tmp.clear();
+    append_py_float(tmp, v);
+    o.put(tmp.data(), tmp.size());
+}
+
+// pass 2: the corner points of one box (:254-260)
+inline bool fj_put_corners(Raw<char> &o, const double *xy, const uint8_t *isint, int32_t npts, const int32_t *a, std::string &tmp) {
+    static const char kNull[] = "[{\"x\": null, \"y\": null}, {\"x\": null, \"y\": null}]";
+    if (npts == 0) { o.put(kNull, sizeof(kNull) - 1); return true; }
+    for (int i = 0; i < 4; ++i)
+        if (a[i] < 0 || a[i] >= npts) return false;
+    static const char *const lead[4] = {"[{\"x\": ", ", \"y\": ", "}, {\"x\": ", ", \"y\": "};
+    for (int i = 0; i < 4; ++i) {
+        o.put(lead[i], strlen(lead[i]));
+        const int32_t k = a[i];
+        fj_put_coord(o, xy[2 * (size_t)k + (i & 1)], (isint[k] >> (i & 1)) & 1, tmp);
+    }
+    o.put("}]", 2);
+    return true;
+}

@@ -63,8 +63,8 @@ def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, varia
 
 
 def _chain_table(rng, n_rows, max_boxes, empty_share):
-    """rows of near-identical boxes (every pair is HIGH) with empty polygons planted: whether a row is HIGH then depends
-    only on where its first empty polygon sits"""
+    """rows of disjoint boxes whose LAST box repeats the first, with empty polygons planted: "K2 on K1's boxes" calls such a row
+    HIGH whenever its two ends are there, the reference chain only when no empty polygon comes before the last box"""
     nb = rng.integers(0, max_boxes + 1, size=n_rows)
     box_off = np.zeros(n_rows + 1, np.int32)
     np.cumsum(nb, out=box_off[1:])
@@ -72,10 +72,11 @@ def _chain_table(rng, n_rows, max_boxes, empty_share):
     npts = np.where(rng.random(B) < empty_share, 0, 4)
     pt_off = np.zeros(B + 1, np.int32)
     np.cumsum(npts, out=pt_off[1:])
-    row = np.repeat(np.arange(n_rows), nb)[np.repeat(np.arange(B), npts)]
+    k_in_row = np.arange(B) - np.repeat(box_off[:-1], nb)
+    k_in_row[(box_off[1:] - 1)[nb > 1]] = 0                      # the last box of a row sits on its first
+    shift = np.repeat(k_in_row, npts)[:, None] * np.array([[150.0, 0.0]])
     corner = np.tile(np.array([[0.0, 0.0], [100.0, 0.0], [100.0, 100.0], [0.0, 100.0]]), (int(npts.sum()) // 4, 1))
-    xy = corner + (row % 7)[:, None] * 1000.0
-    return xy, pt_off, box_off
+    return corner + shift, pt_off, box_off
 
 
 @pytest.mark.parametrize("n_rows,max_boxes,share", [(400, 6, 0.3), (3000, 32, 0.05), (300, 64, 0.02), (40, 200, 0.01), (6, 700, 0.003),
@@ -99,7 +100,7 @@ def test_fused_ends_a_row_at_its_first_empty_polygon(native, n_rows, max_boxes, 
         assert np.array_equal(np.isnan(box), np.isnan(obox)) and np.array_equal(box[~np.isnan(box)], obox[~np.isnan(obox)])
         assert np.array_equal(high, ohigh), (mb, thr, np.flatnonzero(high != ohigh)[:10])
         plain_differs |= not np.array_equal(ohigh, olib.iou_any_ge(obox, box_off, mb, thr))
-    assert plain_differs or share in (1.0,), "the table must tell the chain from K2-on-K1's-boxes"
+    assert plain_differs or share == 1.0, "the table must tell the chain from K2-on-K1's-boxes"
 
 
 def test_fused_host_entry_edges(native):
