@@ -94,6 +94,8 @@ SIGNATURES = {
     "dyd_scan_wh_kind": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_wh_value": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dyd_scan_iou_host": (C.c_void_p, [C.c_void_p]),
+    "dyd_scan_fast_cells": (C.c_int64, [C.c_void_p]),
+    "dyd_json_scan_polygons_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "dyd_scan_free": (None, [C.c_void_p]),
     "dyd_json_scan_labelled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                          C.POINTER(C.c_void_p)]),

@@ -931,6 +931,25 @@ void parallel_cells(int64_t n, int n_threads, F fn) {
 
 #include "host_json_fast.h"
 
+// where the cells of a scan live: one flat buffer + offsets, or one pointer + length per cell
+struct CellSrc {
+    const uint8_t *text = nullptr;
+    const int64_t *off = nullptr;
+    const uint8_t *const *ptr = nullptr;
+    const int64_t *len = nullptr;
+    inline Span get(int64_t i) const {
+        if (ptr) return Span{(const char *)ptr[i], (const char *)ptr[i] + len[i]};
+        return Span{(const char *)text + off[i], (const char *)text + off[i + 1]};
+    }
+    size_t bytes(int64_t lo, int64_t hi) const {
+        if (hi <= lo) return 0;
+        if (!ptr) return (size_t)(off[hi] - off[lo]);
+        size_t s = 0;
+        for (int64_t i = lo; i < hi; ++i) s += (size_t)len[i];
+        return s;
+    }
+};
+
 // as parallel_cells, but a bad_alloc inside a worker is reported instead of ending the process
 template <class F>
 bool parallel_cells_safe(int64_t n, int n_threads, F fn) {
@@ -967,6 +986,7 @@ bool parallel_index_safe(int n, F fn) {   // fn(k) for k in [0, n), one thread e
 // ===================================================================================================
 struct dyd_scan {
     int64_t n_cells = 0;
+    CellSrc src;                        // polygon scan: where the cells are (kept for the exact walker's pass 2)
     std::vector<double> xy;
     std::vector<int32_t> pt_off;        // [n_boxes + 1]
     std::vector<int32_t> cell_box_off;  // [n_cells + 1]
@@ -986,89 +1006,190 @@ struct dyd_scan {
     Raw<char> f_text;
 };
 
+// ---------------------------------------------------------------------------------------------------
+// polygon scan / emit over per-thread parts (host_json_fast.h)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+int default_threads() {   // the process's CPU share: cgroup quota when there is one (a 16-CPU slice of a 256-thread host)
+    static int cached = 0;
+    if (cached) return cached;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    double quota = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = {0};
+        double per = 0;
+        if (fscanf(f, "%63s %lf", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) quota = atof(a) / per;
+        fclose(f);
+    }
+    int n = (int)hw;
+    if (quota >= 1.0 && quota < n) n = (int)(quota + 0.5);
+    if (const char *e = getenv("DYD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) n = v; }
+    cached = std::max(1, std::min(n, 64));
+    return cached;
+}
+
+inline bool use_fast_lane() {
+    const char *env = getenv("DYD_JSON_FAST");
+    return !(env && env[0] == '0');
+}
+
+// pass 1 over the part's cell range: fills A and the per-cell arrays of h
+void scan_part(dyd_scan *h, const CellSrc &src, const uint8_t *missing, FastPart &A, bool use_fast) {
+    std::string tmp;
+    std::vector<double> sxy;
+    std::vector<int32_t> snp;
+    const int64_t lo = A.lo, hi = A.hi;
+    const size_t bytes = src.bytes(lo, hi);
+    A.seg_off.need((size_t)(hi - lo) + 1);
+    A.lane.need((size_t)(hi - lo));
+    A.cell_boxes.need((size_t)(hi - lo));
+    A.seg.need(bytes / 3 + 64);          // the usual share of a cell that is not point text
+    A.xy.need(bytes / 12 + 64);          // ~ one point (2 doubles) per 35 bytes of text
+    for (int64_t i = lo; i < hi; ++i) {
+        A.seg_off.push((int64_t)A.seg.n);
+        if (missing && missing[i]) { h->status[(size_t)i] = CELL_MISSING; A.lane.push(0); A.cell_boxes.push(0); continue; }
+        const size_t m_xy = A.xy.n, m_ii = A.isint.n, m_np = A.npts.n, m_ho = A.hole.n, m_sg = A.seg.n;
+        const Span cell = src.get(i);
+        if (use_fast) {
+            FastCell fc(cell.b, cell.e, A, tmp);
+            if (fc.cell()) {
+                A.lane.push(1);
+                A.cell_boxes.push(fc.box);
+                h->iou_host[(size_t)i] = fc.big_int ? 1 : 0;
+                h->w_kind[(size_t)i] = fc.w.kind; h->w_val[(size_t)i] = fc.w.v;
+                h->h_kind[(size_t)i] = fc.h.kind; h->h_val[(size_t)i] = fc.h.v;
+                continue;
+            }
+            A.xy.n = m_xy; A.isint.n = m_ii; A.npts.n = m_np; A.hole.n = m_ho; A.seg.n = m_sg;
+        }
+        A.lane.push(0);
+        sxy.clear(); snp.clear();
+        CellSink sk;
+        sk.xy = &sxy; sk.npts = &snp;
+        try {
+            walk_cell(cell, sk);
+            A.xy.put(sxy.data(), sxy.size());
+            A.isint.need(sxy.size() / 2);
+            memset(A.isint.p + A.isint.n, 0, sxy.size() / 2);
+            A.isint.n += sxy.size() / 2;
+            A.npts.put(snp.data(), snp.size());
+            for (size_t k = 0; k < snp.size(); ++k) A.hole.push(0);
+            A.cell_boxes.push(sk.box);
+            h->iou_host[(size_t)i] = sk.big_int ? 1 : 0;
+            h->w_kind[(size_t)i] = sk.w.kind; h->w_val[(size_t)i] = sk.w.v;
+            h->h_kind[(size_t)i] = sk.h.kind; h->h_val[(size_t)i] = sk.h.v;
+        } catch (Fail f) {
+            A.cell_boxes.push(0);
+            h->status[(size_t)i] = (f.code == 1) ? CELL_UNDECODABLE : CELL_IRREGULAR;
+        }
+    }
+    A.seg_off.push((int64_t)A.seg.n);
+}
+
+// pass 2 over the part: arg4 = K1's arg indices of the PART's boxes (local order); xy / pt_off as the part's views say
+// (A.xyv: the part's first point; A.ptv[b] - A.ptv_bias: first point of local box b).  false: arg4 does not fit the scan.
+bool emit_part(const dyd_scan *h, const CellSrc &src, FastPart &A, const int32_t *arg4) {
+    std::string tmp, slow;
+    bool good = true;
+    A.out.n = 0;
+    A.out_len.n = 0;
+    A.out_len.need((size_t)(A.hi - A.lo));
+    A.out.need(A.seg.n + A.seg.n / 2 + 64);
+    size_t lb = 0;   // local box index
+    for (int64_t i = A.lo; i < A.hi; ++i) {
+        const size_t mark = A.out.n;
+        const size_t nb = (size_t)A.cell_boxes.p[i - A.lo];
+        if (h->status[(size_t)i] != CELL_OK) { A.out_len.push(0); lb += nb; continue; }
+        if (A.lane.p[i - A.lo]) {
+            const char *sg = A.seg.p + A.seg_off.p[i - A.lo];
+            const size_t sg_len = (size_t)(A.seg_off.p[i - A.lo + 1] - A.seg_off.p[i - A.lo]);
+            size_t prev = 0;
+            for (size_t b = lb; b < lb + nb; ++b) {
+                const size_t hb = A.hole.p[b];
+                A.out.put(sg + prev, hb - prev);
+                prev = hb;
+                const size_t p0 = (size_t)(A.ptv[b] - A.ptv_bias), p1 = (size_t)(A.ptv[b + 1] - A.ptv_bias);
+                if (!fj_put_corners(A.out, A.xyv + 2 * p0, A.isint.p + p0, (int32_t)(p1 - p0), arg4 + 4 * b, tmp)) good = false;
+            }
+            A.out.put(sg + prev, sg_len - prev);
+        } else {
+            slow.clear();
+            CellSink sk;
+            sk.out = &slow;
+            sk.arg4 = arg4 + 4 * lb;
+            try {
+                walk_cell(src.get(i), sk);
+                A.out.put(slow.data(), slow.size());
+            } catch (Fail) {
+                A.out.n = mark;
+                good = false;
+            }
+        }
+        lb += nb;
+        A.out_len.push((int64_t)(A.out.n - mark));
+    }
+    return good;
+}
+
+// the parts' texts -> one buffer + offsets (one thread per part)
+bool gather_text(dyd_scan *h) {
+    size_t total = 0;
+    std::vector<size_t> base(h->parts.size() + 1, 0);
+    for (size_t k = 0; k < h->parts.size(); ++k) { base[k] = total; total += h->parts[k]->out.n; }
+    h->f_text.n = 0;
+    h->f_text.need(total + 1);
+    h->f_text.n = total;
+    h->text_off.resize((size_t)h->n_cells + 1);
+    h->text_off[0] = 0;
+    return parallel_index_safe((int)h->parts.size(), [&](int k) {
+        FastPart &A = *h->parts[(size_t)k];
+        if (A.out.n) memcpy(h->f_text.p + base[(size_t)k], A.out.p, A.out.n);
+        int64_t run = (int64_t)base[(size_t)k];
+        for (int64_t i = A.lo; i < A.hi; ++i) { run += A.out_len.p[i - A.lo]; h->text_off[(size_t)i + 1] = run; }
+        A.out.clear_free();
+    });
+}
+
+void init_polygon_handle(dyd_scan *h, int64_t n_cells, int n_threads, const CellSrc &src) {
+    h->n_cells = n_cells;
+    h->fast = true;
+    h->src = src;
+    h->status.assign((size_t)n_cells, CELL_OK);
+    h->w_kind.assign((size_t)n_cells, 0); h->h_kind.assign((size_t)n_cells, 0);
+    h->w_val.assign((size_t)n_cells, 0.0); h->h_val.assign((size_t)n_cells, 0.0);
+    h->iou_host.assign((size_t)n_cells, 0);
+    h->cell_box_off.assign((size_t)n_cells + 1, 0);
+    if (n_threads <= 0) n_threads = default_threads();
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n_cells / 256));
+    n_threads = std::min(n_threads, 64);
+    for (int t = 0; t < n_threads; ++t) {
+        h->parts.emplace_back(new FastPart());
+        h->parts.back()->lo = n_cells * t / n_threads;
+        h->parts.back()->hi = n_cells * (t + 1) / n_threads;
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 // Scan annotation cells for the replace step (processor.py:262-281).  text/cell_off: concatenated UTF-8
 // cells; missing[i] != 0 marks a NaN cell.  The handle owns every output array.
 // Regular cells go through the single-parse lane of host_json_fast.h; a cell that lane does not take is walked by the
 // exact parser (walk_cell), which also decides between undecodable and irregular.  DYD_JSON_FAST=0 sends every cell there.
-int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
-                           int n_threads, dyd_scan **out) {
-    if (!out || n_cells < 0 || (n_cells > 0 && !cell_off)) return DYD_ERR_INVALID;
+static int scan_polygons_src(const CellSrc &src, const uint8_t *missing, int64_t n_cells, int n_threads, dyd_scan **out) {
     dyd_scan *h = new (std::nothrow) dyd_scan();
     if (!h) return DYD_ERR_OOM;
-    const char *env = getenv("DYD_JSON_FAST");
-    const bool use_fast = !(env && env[0] == '0');
+    const bool use_fast = use_fast_lane();
     const bool timing = getenv("DYD_JSON_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
     try {
-        h->n_cells = n_cells;
-        h->fast = true;
-        h->status.assign((size_t)n_cells, CELL_OK);
-        h->w_kind.assign((size_t)n_cells, 0); h->h_kind.assign((size_t)n_cells, 0);
-        h->w_val.assign((size_t)n_cells, 0.0); h->h_val.assign((size_t)n_cells, 0.0);
-        h->iou_host.assign((size_t)n_cells, 0);
-        h->cell_box_off.assign((size_t)n_cells + 1, 0);   // holds the per-cell counts until the prefix sum below
-        for (int t = 0; t < 64; ++t) h->parts.emplace_back(new FastPart());
-        int32_t *boxes_in_cell = h->cell_box_off.data() + 1;
-        const bool ok = parallel_cells_safe(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
-            FastPart &A = *h->parts[(size_t)t];
-            A.lo = lo; A.hi = hi;
-            std::string tmp;
-            std::vector<double> sxy;
-            std::vector<int32_t> snp;
-            const size_t bytes = (size_t)(cell_off[hi] - cell_off[lo]);
-            A.seg_off.need((size_t)(hi - lo) + 1);
-            A.lane.need((size_t)(hi - lo));
-            A.seg.need(bytes / 3 + 64);          // the usual share of a cell that is not point text
-            A.xy.need(bytes / 12 + 64);          // ~ one point (2 doubles) per 35 bytes of text
-            for (int64_t i = lo; i < hi; ++i) {
-                A.seg_off.push((int64_t)A.seg.n);
-                if (missing && missing[i]) { h->status[(size_t)i] = CELL_MISSING; A.lane.push(0); continue; }
-                const size_t m_xy = A.xy.n, m_ii = A.isint.n, m_np = A.npts.n, m_ho = A.hole.n, m_sg = A.seg.n;
-                const char *b = (const char *)text + cell_off[i], *e = (const char *)text + cell_off[i + 1];
-                if (use_fast) {
-                    FastCell fc(b, e, A, tmp);
-                    if (fc.cell()) {
-                        A.lane.push(1);
-                        boxes_in_cell[i] = fc.box;
-                        h->iou_host[(size_t)i] = fc.big_int ? 1 : 0;
-                        h->w_kind[(size_t)i] = fc.w.kind; h->w_val[(size_t)i] = fc.w.v;
-                        h->h_kind[(size_t)i] = fc.h.kind; h->h_val[(size_t)i] = fc.h.v;
-                        continue;
-                    }
-                    A.xy.n = m_xy; A.isint.n = m_ii; A.npts.n = m_np; A.hole.n = m_ho; A.seg.n = m_sg;
-                }
-                A.lane.push(0);
-                sxy.clear(); snp.clear();
-                CellSink sk;
-                sk.xy = &sxy; sk.npts = &snp;
-                try {
-                    walk_cell(Span{b, e}, sk);
-                    A.xy.put(sxy.data(), sxy.size());
-                    A.isint.need(sxy.size() / 2);
-                    memset(A.isint.p + A.isint.n, 0, sxy.size() / 2);
-                    A.isint.n += sxy.size() / 2;
-                    A.npts.put(snp.data(), snp.size());
-                    for (size_t k = 0; k < snp.size(); ++k) A.hole.push(0);
-                    boxes_in_cell[i] = sk.box;
-                    h->iou_host[(size_t)i] = sk.big_int ? 1 : 0;
-                    h->w_kind[(size_t)i] = sk.w.kind; h->w_val[(size_t)i] = sk.w.v;
-                    h->h_kind[(size_t)i] = sk.h.kind; h->h_val[(size_t)i] = sk.h.v;
-                } catch (Fail f) {
-                    h->status[(size_t)i] = (f.code == 1) ? CELL_UNDECODABLE : CELL_IRREGULAR;
-                }
-            }
-            A.seg_off.push((int64_t)A.seg.n);
-        });
-        if (!ok) throw std::bad_alloc();
+        init_polygon_handle(h, n_cells, n_threads, src);
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) { scan_part(h, src, missing, *h->parts[(size_t)k], use_fast); }))
+            throw std::bad_alloc();
         if (timing) fprintf(stderr, "scan parallel part: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count());
-        std::sort(h->parts.begin(), h->parts.end(), [](const std::unique_ptr<FastPart> &a, const std::unique_ptr<FastPart> &b) {
-            const bool ea = a->hi <= a->lo, eb = b->hi <= b->lo;   // unused parts last
-            if (ea != eb) return eb;
-            return a->lo < b->lo;
-        });
-        while (!h->parts.empty() && h->parts.back()->hi <= h->parts.back()->lo) h->parts.pop_back();
         size_t nb = 0, npnt = 0;
         for (auto &pp : h->parts) { pp->box_base = nb; pp->pt_base = npnt; nb += pp->npts.n; npnt += pp->xy.n / 2; }
         if (npnt >= (size_t)1 << 31) { delete h; return DYD_ERR_RANGE; }
@@ -1084,8 +1205,13 @@ int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const u
                 int32_t run = (int32_t)A.pt_base;
                 int32_t *po = h->f_pt_off.p + A.box_base + 1;
                 for (size_t b = 0; b < A.npts.n; ++b) { run += A.npts.p[b]; po[b] = run; }
+                int32_t *cb = h->cell_box_off.data() + 1;
+                for (int64_t i = A.lo; i < A.hi; ++i) cb[i] = A.cell_boxes.p[i - A.lo];
                 A.xy.clear_free();      // pass 2 reads the gathered copies
                 A.npts.clear_free();
+                A.xyv = h->f_xy.p + 2 * A.pt_base;
+                A.ptv = h->f_pt_off.p + A.box_base;
+                A.ptv_bias = (int32_t)A.pt_base;
             }))
             throw std::bad_alloc();
         for (int64_t i = 0; i < n_cells; ++i) h->cell_box_off[(size_t)i + 1] += h->cell_box_off[(size_t)i];
@@ -1098,6 +1224,24 @@ int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const u
     return DYD_OK;
 }
 
+int dyd_json_scan_polygons(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                           int n_threads, dyd_scan **out) {
+    if (!out || n_cells < 0 || (n_cells > 0 && !cell_off)) return DYD_ERR_INVALID;
+    CellSrc src;
+    src.text = text; src.off = cell_off;
+    return scan_polygons_src(src, missing, n_cells, n_threads, out);
+}
+
+// the same over one (pointer, length) pair per cell — e.g. the UTF-8 views of the str objects of a DataFrame column, so that
+// no cell is copied; the pointers must stay valid until the handle is freed
+int dyd_json_scan_polygons_v(const uint8_t *const *cell_ptr, const int64_t *cell_len, const uint8_t *missing, int64_t n_cells,
+                             int n_threads, dyd_scan **out) {
+    if (!out || n_cells < 0 || (n_cells > 0 && (!cell_ptr || !cell_len))) return DYD_ERR_INVALID;
+    CellSrc src;
+    src.ptr = cell_ptr; src.len = cell_len;
+    return scan_polygons_src(src, missing, n_cells, n_threads, out);
+}
+
 int64_t dyd_scan_n_boxes(const dyd_scan *h) { return h ? (h->fast ? (int64_t)h->f_pt_off.n - 1 : (int64_t)h->pt_off.size() - 1) : 0; }
 int64_t dyd_scan_n_points(const dyd_scan *h) { return h ? (h->fast ? (int64_t)h->f_xy.n / 2 : (int64_t)h->xy.size() / 2) : 0; }
 const double *dyd_scan_xy(const dyd_scan *h) { return h->fast ? h->f_xy.p : h->xy.data(); }
@@ -1107,76 +1251,33 @@ const uint8_t *dyd_scan_status(const dyd_scan *h) { return h->status.data(); }
 const uint8_t *dyd_scan_wh_kind(const dyd_scan *h, int which) { return which ? h->h_kind.data() : h->w_kind.data(); }
 const double *dyd_scan_wh_value(const dyd_scan *h, int which) { return which ? h->h_val.data() : h->w_val.data(); }
 const uint8_t *dyd_scan_iou_host(const dyd_scan *h) { return h->iou_host.empty() ? nullptr : h->iou_host.data(); }
+int64_t dyd_scan_fast_cells(const dyd_scan *h) {
+    int64_t n = 0;
+    if (h)
+        for (const auto &pp : h->parts)
+            for (size_t i = 0; i < pp->lane.n; ++i) n += pp->lane.p[i];
+    return n;
+}
 
 // Emit the rewritten JSON text of every CELL_OK cell (empty text for the others).  arg4 = K1's arg indices
 // for the boxes of the scan, in scan order.  Output stays owned by the handle.  Cells of the fast lane are assembled from
-// their segments (no parsing); the others are re-walked by the exact parser.
+// their segments (no parsing); the others are re-walked by the exact parser.  text / cell_off may be NULL: the cells the
+// scan was given are used (they must still be alive).
 int dyd_json_emit_polygons(dyd_scan *h, const uint8_t *text, const int64_t *cell_off, const int32_t *arg4,
                            int n_threads, const uint8_t **out_text, const int64_t **out_off) {
     if (!h || !out_text || !out_off || !h->fast) return DYD_ERR_INVALID;
     (void)n_threads;   // one thread per part of the scan
-    const int64_t n = h->n_cells;
+    CellSrc src = h->src;
+    if (text && cell_off) { src = CellSrc(); src.text = text; src.off = cell_off; }
     int bad = 0;
     try {
         if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
                 FastPart &A = *h->parts[(size_t)k];
-                std::string tmp, slow;
-                A.out.n = 0;
-                A.out_len.n = 0;
-                A.out_len.need((size_t)(A.hi - A.lo));
-                A.out.need(A.seg.n + A.seg.n / 2 + 64);
-                for (int64_t i = A.lo; i < A.hi; ++i) {
-                    const size_t mark = A.out.n;
-                    if (h->status[(size_t)i] != CELL_OK) { A.out_len.push(0); continue; }
-                    const int32_t b0 = h->cell_box_off[(size_t)i], b1 = h->cell_box_off[(size_t)i + 1];
-                    if (A.lane.p[i - A.lo]) {
-                        const char *sg = A.seg.p + A.seg_off.p[i - A.lo];
-                        const size_t sg_len = (size_t)(A.seg_off.p[i - A.lo + 1] - A.seg_off.p[i - A.lo]);
-                        size_t prev = 0;
-                        for (int32_t b = b0; b < b1; ++b) {
-                            const size_t hb = A.hole.p[(size_t)b - A.box_base];
-                            A.out.put(sg + prev, hb - prev);
-                            prev = hb;
-                            const int32_t p0 = h->f_pt_off.p[b], p1 = h->f_pt_off.p[b + 1];
-                            if (!fj_put_corners(A.out, h->f_xy.p + 2 * (size_t)p0, A.isint.p + ((size_t)p0 - A.pt_base), p1 - p0,
-                                                arg4 + 4 * (int64_t)b, tmp))
-                                __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
-                        }
-                        A.out.put(sg + prev, sg_len - prev);
-                    } else {
-                        slow.clear();
-                        CellSink sk;
-                        sk.out = &slow;
-                        sk.arg4 = arg4 + 4 * (int64_t)b0;
-                        try {
-                            walk_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, sk);
-                            A.out.put(slow.data(), slow.size());
-                        } catch (Fail) {
-                            A.out.n = mark;
-                            __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
-                        }
-                    }
-                    A.out_len.push((int64_t)(A.out.n - mark));
-                }
+                if (!emit_part(h, src, A, arg4 + 4 * A.box_base)) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
             }))
             return DYD_ERR_OOM;
         if (bad) return DYD_ERR_INVALID;  // arg4 inconsistent with the scan
-        size_t total = 0;
-        std::vector<size_t> base(h->parts.size() + 1, 0);
-        for (size_t k = 0; k < h->parts.size(); ++k) { base[k] = total; total += h->parts[k]->out.n; }
-        h->f_text.n = 0;
-        h->f_text.need(total + 1);
-        h->f_text.n = total;
-        h->text_off.resize((size_t)n + 1);
-        h->text_off[0] = 0;
-        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
-                FastPart &A = *h->parts[(size_t)k];
-                if (A.out.n) memcpy(h->f_text.p + base[(size_t)k], A.out.p, A.out.n);
-                int64_t run = (int64_t)base[(size_t)k];
-                for (int64_t i = A.lo; i < A.hi; ++i) { run += A.out_len.p[i - A.lo]; h->text_off[(size_t)i + 1] = run; }
-                A.out.clear_free();
-            }))
-            return DYD_ERR_OOM;
+        if (!gather_text(h)) return DYD_ERR_OOM;
     } catch (const std::bad_alloc &) {
         return DYD_ERR_OOM;
     }

@@ -50,6 +50,11 @@ struct FastPart {
     Raw<char> seg;                   // canonical text of the lane's cells, ptLists cut out
     Raw<int64_t> seg_off;            // per cell: start in seg (hi - lo + 1 entries)
     Raw<uint8_t> lane;               // per cell: 1 = segments (this lane), 0 = the exact walker re-parses it in pass 2
+    Raw<int32_t> cell_boxes;         // per cell: boxes it contributed
+    // views pass 2 reads the points through: xyv = the part's first point, local box b starts at point ptv[b] - ptv_bias
+    const double *xyv = nullptr;
+    const int32_t *ptv = nullptr;
+    int32_t ptv_bias = 0;
     // pass 2
     Raw<char> out;
     Raw<int64_t> out_len;            // per cell

@@ -1,0 +1,154 @@
+/* pyhelpers.c — CPython glue between a pandas object column and the flat buffers of libdyd_gfx950.so
+ * (module deal_yolo_daya_amd._dydpy; built with the interpreter's own headers, see the Makefile).
+ *
+ * The annotation column of a DataFrame is an array of str objects of ~4 KB each.  Joining and encoding them in
+ * Python (native_json.cells_to_buffers) costs more than scanning them, and a million 2 KB result strings created
+ * one by one cost more than emitting them.  Two functions, both taking raw addresses (numpy `.ctypes.data`):
+ *
+ *   str_views(objs, n, ptr_out, len_out, missing_out)
+ *       per element: a str -> the address and length of its UTF-8 form (the object's own buffer for ASCII text, its
+ *       cached UTF-8 copy otherwise — no per-call copy), anything else -> missing (reference processor.py:264, :344:
+ *       `not isinstance(json_str, str)`).  The views live as long as the str objects do.
+ *   strs_from_utf8(text, off, n, na, objs_out, n_threads)
+ *       per element with na == 0: a new str of text[off[i]:off[i+1]] stored into the object array (which must hold
+ *       None everywhere).  ASCII cells are allocated with the GIL held and filled by worker threads without it.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <string.h>
+
+static PyObject *str_views(PyObject *self, PyObject *args) {
+    unsigned long long a_objs, a_ptr, a_len, a_missing;
+    Py_ssize_t n;
+    if (!PyArg_ParseTuple(args, "KnKKK", &a_objs, &n, &a_ptr, &a_len, &a_missing)) return NULL;
+    PyObject **objs = (PyObject **)(uintptr_t)a_objs;
+    const char **ptr = (const char **)(uintptr_t)a_ptr;
+    int64_t *len = (int64_t *)(uintptr_t)a_len;
+    uint8_t *missing = (uint8_t *)(uintptr_t)a_missing;
+    Py_ssize_t n_str = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *o = objs[i];
+        if (o != NULL && PyUnicode_CheckExact(o)) {
+            Py_ssize_t k = 0;
+            const char *p = PyUnicode_AsUTF8AndSize(o, &k);
+            if (p == NULL) return NULL; /* lone surrogate: UnicodeEncodeError, as "".encode() would raise */
+            ptr[i] = p;
+            len[i] = (int64_t)k;
+            missing[i] = 0;
+            ++n_str;
+        } else {
+            ptr[i] = "";
+            len[i] = 0;
+            missing[i] = 1;
+        }
+    }
+    return PyLong_FromSsize_t(n_str);
+}
+
+typedef struct {
+    const char *text;
+    const int64_t *off;
+    const uint8_t *na;
+    PyObject **objs;
+    uint8_t *ascii; /* per cell: 1 = pure ASCII */
+    int64_t lo, hi;
+    int phase;
+} work_t;
+
+static void *worker(void *arg) {
+    work_t *w = (work_t *)arg;
+    if (w->phase == 0) { /* classify */
+        for (int64_t i = w->lo; i < w->hi; ++i) {
+            if (w->na && w->na[i]) { w->ascii[i] = 0; continue; }
+            const unsigned char *s = (const unsigned char *)w->text + w->off[i];
+            const int64_t k = w->off[i + 1] - w->off[i];
+            uint64_t acc = 0;
+            int64_t j = 0;
+            for (; j + 8 <= k; j += 8) {
+                uint64_t v;
+                memcpy(&v, s + j, 8);
+                acc |= v;
+            }
+            for (; j < k; ++j) acc |= s[j];
+            w->ascii[i] = (acc & 0x8080808080808080ull) ? 0 : 1;
+        }
+    } else { /* fill the ASCII objects */
+        for (int64_t i = w->lo; i < w->hi; ++i) {
+            if (!w->ascii[i]) continue;
+            memcpy(PyUnicode_1BYTE_DATA(w->objs[i]), w->text + w->off[i], (size_t)(w->off[i + 1] - w->off[i]));
+        }
+    }
+    return NULL;
+}
+
+static void run_phase(work_t *proto, int64_t n, int n_threads, int phase) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (n < 4096) n_threads = 1;
+    pthread_t th[64];
+    work_t w[64];
+    int started[64];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t] = *proto;
+        w[t].lo = n * t / n_threads;
+        w[t].hi = n * (t + 1) / n_threads;
+        w[t].phase = phase;
+        started[t] = (t > 0) && pthread_create(&th[t], NULL, worker, &w[t]) == 0;
+    }
+    for (int t = 0; t < n_threads; ++t)
+        if (!started[t]) worker(&w[t]);
+    for (int t = 0; t < n_threads; ++t)
+        if (started[t]) pthread_join(th[t], NULL);
+}
+
+static PyObject *strs_from_utf8(PyObject *self, PyObject *args) {
+    unsigned long long a_text, a_off, a_na, a_objs;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKnKKi", &a_text, &a_off, &n, &a_na, &a_objs, &n_threads)) return NULL;
+    work_t w;
+    memset(&w, 0, sizeof(w));
+    w.text = (const char *)(uintptr_t)a_text;
+    w.off = (const int64_t *)(uintptr_t)a_off;
+    w.na = (const uint8_t *)(uintptr_t)a_na;
+    w.objs = (PyObject **)(uintptr_t)a_objs;
+    if (n == 0) Py_RETURN_NONE;
+    w.ascii = (uint8_t *)PyMem_RawMalloc((size_t)n);
+    if (!w.ascii) return PyErr_NoMemory();
+    Py_BEGIN_ALLOW_THREADS
+    run_phase(&w, (int64_t)n, n_threads, 0);
+    Py_END_ALLOW_THREADS
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (w.na && w.na[i]) continue;
+        const int64_t k = w.off[i + 1] - w.off[i];
+        PyObject *s = w.ascii[i] ? PyUnicode_New((Py_ssize_t)k, 127)
+                                 : PyUnicode_DecodeUTF8(w.text + w.off[i], (Py_ssize_t)k, "strict");
+        if (!s) {
+            /* objects created so far stay in the array (owned by it); the ASCII ones among them are still unfilled, so
+             * fill them before reporting */
+            for (Py_ssize_t j = i; j < n; ++j) w.ascii[j] = 0;
+            run_phase(&w, (int64_t)n, 1, 1);
+            PyMem_RawFree(w.ascii);
+            return NULL;
+        }
+        PyObject *old = w.objs[i];
+        w.objs[i] = s;
+        Py_XDECREF(old);
+    }
+    Py_BEGIN_ALLOW_THREADS
+    run_phase(&w, (int64_t)n, n_threads, 1);
+    Py_END_ALLOW_THREADS
+    PyMem_RawFree(w.ascii);
+    Py_RETURN_NONE;
+}
+
+static PyMethodDef methods[] = {
+    {"str_views", str_views, METH_VARARGS, "UTF-8 views of the str elements of an object array"},
+    {"strs_from_utf8", strs_from_utf8, METH_VARARGS, "str objects from flat UTF-8 + offsets into an object array"},
+    {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_dydpy", "pandas object column <-> flat UTF-8 buffers", -1, methods};
+
+PyMODINIT_FUNC PyInit__dydpy(void) { return PyModule_Create(&module); }

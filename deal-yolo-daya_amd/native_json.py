@@ -23,6 +23,29 @@ def enabled() -> bool:
     return os.environ.get("DYD_NATIVE_JSON", "1") != "0"
 
 
+_THREADS = None
+
+
+def host_threads() -> int:
+    """worker threads for host-side passes: DYD_HOST_THREADS, else the process's CPU share (cgroup quota when there is one —
+    a GPU box hands a 16-CPU slice of a 256-thread host to one GPU), at most 64"""
+    global _THREADS
+    if _THREADS is None:
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                quota, period = f.read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, round(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+        env = os.environ.get("DYD_HOST_THREADS")
+        if env and env.isdigit() and int(env) > 0:
+            n = int(env)
+        _THREADS = max(1, min(n, 64))
+    return _THREADS
+
+
 def cells_to_buffers(cells):
     """list / Series of cells -> (utf-8 bytes u8, offsets i64, missing u8, keep-alive object).
 
@@ -88,6 +111,7 @@ class PolygonScan(_Scan):
         self.w_val = _view(L.dyd_scan_wh_value(handle, 0), np.float64, n_cells).copy()
         self.h_val = _view(L.dyd_scan_wh_value(handle, 1), np.float64, n_cells).copy()
         self.iou_host = _view(L.dyd_scan_iou_host(handle), np.uint8, n_cells).copy()   # cells whose IoU flag the host decides
+        self.fast_cells = int(L.dyd_scan_fast_cells(handle))                           # cells the single-parse lane took
 
     def emit_buffers(self, arg4: np.ndarray, n_threads: int = 0) -> tuple:
         """Rewritten JSON text of every cell as flat utf-8 + offsets (views into the handle, valid until
@@ -97,34 +121,22 @@ class PolygonScan(_Scan):
         if arg4.size != 4 * self.n_boxes:
             raise ValueError("arg4 does not match the scan")
         out_text, out_off = C.c_void_p(), C.c_void_p()
-        _native.check(L.dyd_json_emit_polygons(self._h, self._data.ctypes.data, self._off.ctypes.data,
+        _native.check(L.dyd_json_emit_polygons(self._h, self._data.ctypes.data if self._data is not None else None,
+                                               self._off.ctypes.data if self._off is not None else None,
                                                arg4.ctypes.data if arg4.size else None, n_threads,
                                                C.byref(out_text), C.byref(out_off)), "dyd_json_emit_polygons")
         off = _view(out_off.value, np.int64, self.n_cells + 1)
         return _view(out_text.value, np.uint8, int(off[-1])), off
 
+    def emit_array(self, arg4: np.ndarray, n_threads: int = 0) -> np.ndarray:
+        """object array: rewritten JSON text (str) for regular cells, None for every other cell"""
+        text, off = self.emit_buffers(arg4, n_threads)
+        return strings_from_buffers(text, off, (self.status != OK).astype(np.uint8))
+
     def emit(self, arg4: np.ndarray, n_threads: int = 0) -> list:
         """Rewritten JSON text per cell: str for regular cells, None for undecodable / missing cells and
         for irregular ones (the caller fills those in)."""
-        import pyarrow as pa
-
-        L = _native.load_library()
-        arg4 = np.ascontiguousarray(arg4, dtype=np.int32).reshape(-1)
-        if arg4.size != 4 * self.n_boxes:
-            raise ValueError("arg4 does not match the scan")
-        out_text, out_off = C.c_void_p(), C.c_void_p()
-        _native.check(L.dyd_json_emit_polygons(self._h, self._data.ctypes.data, self._off.ctypes.data,
-                                               arg4.ctypes.data if arg4.size else None, n_threads,
-                                               C.byref(out_text), C.byref(out_off)), "dyd_json_emit_polygons")
-        off = _view(out_off.value, np.int64, self.n_cells + 1)
-        total = int(off[-1])
-        text = _view(out_text.value, np.uint8, total)
-        arr = pa.LargeStringArray.from_buffers(self.n_cells, pa.py_buffer(off), pa.py_buffer(text if total else b""))
-        out = arr.to_pylist()
-        bad = np.flatnonzero(self.status != OK)
-        for i in bad.tolist():
-            out[i] = None
-        return out
+        return self.emit_array(arg4, n_threads).tolist()
 
     def width_height(self, which: int) -> list:
         """Python values of doc.get("width") / doc.get("height") for regular cells (None elsewhere);
@@ -170,10 +182,37 @@ def scan_boxes_buffers(data, off, missing, n_threads: int = 0, keep=None) -> Box
     return BoxScan(h, len(off) - 1, (keep, data, off, missing))
 
 
+def strings_from_buffers(text, off, na=None) -> np.ndarray:
+    """object array of str (None where na) from flat utf-8 + offsets: the CPython helper when it is built, pyarrow otherwise"""
+    from . import pycells
+
+    n = len(off) - 1
+    if pycells.available():
+        return pycells.strings(text, off, na)
+    import pyarrow as pa
+
+    arr = pa.LargeStringArray.from_buffers(n, pa.py_buffer(np.ascontiguousarray(off, dtype=np.int64)),
+                                           pa.py_buffer(text if len(text) else b""))
+    out = np.empty(n, object)
+    out[:] = arr.to_pylist()
+    if na is not None:
+        out[np.asarray(na) != 0] = None
+    return out
+
+
 def scan_polygons(cells, n_threads: int = 0) -> PolygonScan:
-    data, off, missing, keep = cells_to_buffers(cells)
+    """cells: list / object ndarray / Series of annotation cells.  With the CPython helper the scanner reads the str objects'
+    own UTF-8 buffers (no copy); otherwise the cells are joined and encoded first."""
+    from . import pycells
+
     L = _native.load_library()
     h = C.c_void_p()
+    if pycells.available():
+        v = pycells.CellViews(cells.to_numpy() if hasattr(cells, "to_numpy") else cells)
+        _native.check(L.dyd_json_scan_polygons_v(v.ptr.ctypes.data, v.len.ctypes.data, v.missing.ctypes.data, len(v),
+                                                 n_threads, C.byref(h)), "dyd_json_scan_polygons_v")
+        return PolygonScan(h, len(v), v, None, None)
+    data, off, missing, keep = cells_to_buffers(cells)
     _native.check(L.dyd_json_scan_polygons(data.ctypes.data, off.ctypes.data, missing.ctypes.data, len(off) - 1,
                                            n_threads, C.byref(h)), "dyd_json_scan_polygons")
     return PolygonScan(h, len(off) - 1, keep, data, off)

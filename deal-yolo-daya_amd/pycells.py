@@ -1,0 +1,56 @@
+"""pandas object column <-> flat UTF-8 buffers without per-cell Python work.
+
+``views`` hands the native JSON scanner the address and length of every str cell's UTF-8 form (no copy: the ASCII
+text of a str object is its own buffer); ``strings`` turns emitted UTF-8 text + offsets back into str objects, the
+bytes copied by worker threads.  Both live in the small CPython extension ``_dydpy`` (csrc/pyhelpers.c); when that
+module is not built for the running interpreter the callers use the portable paths (native_json.cells_to_buffers,
+pyarrow's to_pylist), which give the same results more slowly.  Host glue only — nothing here computes."""
+from __future__ import annotations
+
+import numpy as np
+
+try:
+    from . import _dydpy
+except ImportError:                                    # not built for this interpreter
+    _dydpy = None
+
+
+def available() -> bool:
+    return _dydpy is not None
+
+
+class CellViews:
+    """UTF-8 views of an object array's str cells.  Keeps the array (and so the str objects) alive."""
+
+    def __init__(self, cells):
+        arr = cells if isinstance(cells, np.ndarray) and cells.dtype == object else None
+        if arr is None:
+            arr = np.empty(len(cells), object)
+            arr[:] = cells if not isinstance(cells, np.ndarray) else cells.tolist()
+        arr = np.ascontiguousarray(arr)
+        n = len(arr)
+        self.cells = arr
+        self.ptr = np.empty(n, np.uint64)
+        self.len = np.empty(n, np.int64)
+        self.missing = np.empty(n, np.uint8)
+        if n:
+            _dydpy.str_views(arr.ctypes.data, n, self.ptr.ctypes.data, self.len.ctypes.data, self.missing.ctypes.data)
+
+    def __len__(self):
+        return len(self.cells)
+
+
+def strings(text: np.ndarray, off: np.ndarray, na=None, n_threads: int = 0) -> np.ndarray:
+    """object array of str (None where na != 0) from flat UTF-8 ``text`` and int64 ``off`` [n+1]"""
+    from . import native_json as _nj
+
+    n = len(off) - 1
+    out = np.empty(n, object)
+    if n == 0:
+        return out
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    na_arr = None if na is None else np.ascontiguousarray(na, dtype=np.uint8)
+    _dydpy.strs_from_utf8(text.ctypes.data if text.size else 0, off.ctypes.data, n, 0 if na_arr is None else na_arr.ctypes.data,
+                          out.ctypes.data, n_threads or _nj.host_threads())
+    return out

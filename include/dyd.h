@@ -230,6 +230,13 @@ const double *dyd_scan_wh_value(const dyd_scan *scan, int which);
  * multiplies coordinate differences in CPython's exact int arithmetic; f64 follows it only while every product stays below
  * 2^53, so the fused K1+K2 flag of such a cell is not used: the host decides it from the emitted boxes (flatten.py). */
 const uint8_t *dyd_scan_iou_host(const dyd_scan *scan);
+/* polygon scan only: how many cells the single-parse lane (csrc/host_json_fast.h) took; the others went through the exact walker */
+int64_t dyd_scan_fast_cells(const dyd_scan *scan);
+/* dyd_json_scan_polygons over one (pointer, length) pair per cell instead of a flat buffer — e.g. the UTF-8 views of a DataFrame
+ * column's str objects, so that no cell is copied.  The pointers must stay valid until dyd_scan_free; dyd_json_emit_polygons may
+ * then be called with text == cell_off == NULL. */
+int dyd_json_scan_polygons_v(const uint8_t *const *cell_ptr, const int64_t *cell_len, const uint8_t *missing, int64_t n_cells,
+                             int n_threads, dyd_scan **out);
 /* YOLO step (utils.py:681-710, processor.py:1006): per cell the (min x, min y, max x, max y) of every named object
  * with a non-empty ptList, in dyd_scan_xy as box4, and dyd_scan_sel[b] = 1 when the object's name equals the row's
  * label value (label_text / label_off: one label per cell).  Undecodable cells give no boxes, like the reference's

@@ -421,3 +421,72 @@ def test_relabel_rules():
     assert before == "　c2 , c1；zz|c1；b,a；c3" and after == "g1,zz；a,b；中" and renamed
     assert (tot.total_objects, tot.missing_name_objects, tot.total_labels, tot.replaced_labels, tot.replaced_objects) == (4, 1, 7, 4, 2)
     assert list(tot.unmatched.items()) == [("zz", 1), ("b", 1), ("a", 1)]
+
+
+def _random_number_token(r):
+    """number spellings around every rule of the single-parse lane (csrc/host_json_fast.h): trailing / leading zeros, 15..20
+    significant digits, fixed / exponent notation boundaries of float.__repr__, big ints"""
+    kind = r.random()
+    sign = "-" if r.random() < 0.3 else ""
+    digits = lambda n, first="123456789": (r.choice(first) + "".join(r.choice("0123456789") for _ in range(n - 1))) if n else ""  # noqa: E731
+    if kind < 0.25:
+        return sign + (digits(r.randint(1, 22)) if r.random() < 0.9 else "0")
+    if kind < 0.8:
+        ip = "0" if r.random() < 0.3 else digits(r.randint(1, 18))
+        fr = "0" * r.choice([0, 0, 1, 2, 3, 4, 5, 8]) + "".join(r.choice("0123456789") for _ in range(r.randint(0, 18)))
+        fr = (fr or "0") + "0" * r.choice([0, 0, 0, 1, 2, 5])
+        return f"{sign}{ip}.{fr}"
+    mant = digits(r.randint(1, 17))
+    if r.random() < 0.5:
+        mant += "." + "".join(r.choice("0123456789") for _ in range(r.randint(1, 6)))
+    return f"{sign}{mant}{r.choice('eE')}{r.choice(['', '+', '-'])}{r.randint(0, 30)}"
+
+
+def test_fast_lane_reprints_numbers_like_cpython(oracle_backend):
+    r = random.Random(11)
+    cells = []
+    for _ in range(4000):
+        pts = ", ".join('{"x": %s, "y": %s}' % (_random_number_token(r), _random_number_token(r)) for _ in range(r.randint(1, 4)))
+        cells.append('{"width": %s, "objects": [{"polygon": {"ptList": [%s]}, "score": %s}], "k": [%s, %s]}'
+                     % (_random_number_token(r), pts, _random_number_token(r), _random_number_token(r), _random_number_token(r)))
+    scan = nj.scan_polygons(cells)
+    assert scan.fast_cells > 2000                      # the rest holds ints beyond 2^53 among its coordinates (irregular)
+    scan.close()
+    for start in range(0, len(cells), 500):            # smaller batches so that a raising cell does not hide the others
+        batch = cells[start:start + 500]
+        texts, widths, heights = P.replace_ptlist_cells(batch, oracle_backend)
+        for cell, got, gw in zip(batch, texts, widths):
+            assert got == osteps.replace_cell(cell), cell
+            want_w = json.loads(cell)["width"]
+            assert _same(gw, want_w) and type(gw) is type(want_w), cell
+
+
+def test_fast_lane_and_exact_walker_agree(oracle_backend, monkeypatch):
+    """the same fuzzed cells through the single-parse lane and with DYD_JSON_FAST=0 (every cell through the exact walker)"""
+    cells = [Gen(900 + s).cell() for s in range(3000)]
+    for c in list(cells[:300]):
+        cells.append(json.dumps(json.loads(c)) if _decodes(c) else c)      # canonically spelled cells: the lane's home ground
+
+    def run():
+        scan = nj.scan_polygons(cells)
+        box, arg4 = oracle_backend.bbox_minmax(scan.xy, scan.pt_off)
+        res = (scan.status.copy(), scan.xy.copy(), scan.pt_off.copy(), scan.cell_box_off.copy(), scan.iou_host.copy(),
+               scan.w_kind.copy(), scan.h_kind.copy(), scan.w_val.copy(), scan.h_val.copy(), scan.emit(arg4), scan.fast_cells)
+        scan.close()
+        return res
+
+    fast = run()
+    monkeypatch.setenv("DYD_JSON_FAST", "0")
+    exact = run()
+    assert fast[-1] > 800 and exact[-1] == 0
+    for a, b in zip(fast[:-2], exact[:-2]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert fast[-2] == exact[-2]
+
+
+def _decodes(c):
+    try:
+        json.loads(c)
+        return True
+    except Exception:  # noqa: BLE001
+        return False

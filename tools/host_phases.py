@@ -4,7 +4,7 @@
     python tools/host_phases.py --rows 50000 [--threads 8]
 
 The device stage is left out (K1's arg indices come from the C oracle, measurement aid only), so the numbers
-are the host floor of the DataFrame -> DataFrame path: str -> utf-8 buffers, native scan, native emit,
+are the host floor of the DataFrame -> DataFrame path: UTF-8 views of the str cells + native scan, native emit,
 utf-8 -> str objects.
 """
 import argparse
@@ -36,11 +36,8 @@ def main():
     for rep in range(args.repeat):
         ph = {}
         a = time.perf_counter()
-        data, off, missing, keep = nj.cells_to_buffers(cells)
-        ph["str->utf8"] = time.perf_counter() - a
-        a = time.perf_counter()
-        scan = nj.scan_polygons_buffers(data, off, missing, args.threads)
-        ph["scan"] = time.perf_counter() - a
+        scan = nj.scan_polygons(cells, args.threads)
+        ph["views+scan"] = time.perf_counter() - a
         a = time.perf_counter()
         _, arg4 = olib.bbox_minmax(scan.xy, scan.pt_off)
         ph["(oracle K1)"] = time.perf_counter() - a
@@ -50,9 +47,9 @@ def main():
         a = time.perf_counter()
         out = scan.emit(arg4, args.threads)
         ph["emit+str objects"] = time.perf_counter() - a
-        host = ph["str->utf8"] + ph["scan"] + ph["emit+str objects"]
+        host = ph["views+scan"] + ph["emit+str objects"]
         print(f"rep {rep}: " + "  ".join(f"{k} {v * 1e3:.0f} ms" for k, v in ph.items())
-              + f"  | host floor {args.rows / host / 1e3:.1f} k rows/s; in {len(data) / 1e6:.0f} MB, out {len(text) / 1e6:.0f} MB")
+              + f"  | host floor {args.rows / host / 1e3:.1f} k rows/s; out {len(text) / 1e6:.0f} MB")
         scan.close()
         del out
 
