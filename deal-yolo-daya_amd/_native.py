@@ -97,6 +97,8 @@ SIGNATURES = {
     "dyd_scan_fast_cells": (C.c_int64, [C.c_void_p]),
     "dyd_json_scan_polygons_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "dyd_scan_free": (None, [C.c_void_p]),
+    "dyd_synth_json": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                 C.POINTER(C.c_void_p), C.c_void_p]),
     "dyd_json_scan_labelled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                          C.POINTER(C.c_void_p)]),
     "dyd_scan_sel": (C.c_void_p, [C.c_void_p]),

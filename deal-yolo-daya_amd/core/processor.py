@@ -713,24 +713,38 @@ def filter_by_box_count_and_iou(
 # two stages) and one native emit.  Results are those of the two reference steps in sequence, including the row whose
 # polygon has no valid point: it is emitted with null coordinates and ends the row's IoU box list (:254-255, :364-365).
 def _replace_iou_cells_native(cells, min_boxes, iou_threshold, be, totals):
+    """one batch: native scan -> fused K1+K2 -> native emit.  -> (texts object array, widths, heights, high bool array);
+    widths / heights are numpy columns when every cell is plain (PolygonScan.wh_column), else per-cell lists"""
+    import time as _t
+    t0 = _t.perf_counter()
     try:
         scan = _nj.scan_polygons(cells)
     except UnicodeEncodeError:                         # a lone surrogate somewhere: the two steps in sequence, CPython flatten
         totals["python_cells"] += len(cells)
-        texts, widths, heights = _replace_cells_python(cells, be, totals)
-        return texts, widths, heights, _iou_mask_python(texts, min_boxes, iou_threshold, be, totals)
+        texts, widths, heights = _replace_cells_python(list(cells), be, totals)
+        arr = np.empty(len(texts), object)
+        arr[:] = texts
+        return arr, widths, heights, _iou_mask_python(texts, min_boxes, iou_threshold, be, totals)
+    t1 = _t.perf_counter()
     irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
     totals["python_cells"] += int(len(irregular))
     # irregular cells first: they are the only ones that can raise, and they must raise before any output
     py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
+    t2 = _t.perf_counter()
     arg4, high = be.bbox_iou_fused(scan.xy, scan.pt_off, scan.cell_box_off, min_boxes, iou_threshold)
+    t3 = _t.perf_counter()
     high = high.astype(bool)
-    texts = scan.emit(arg4)
-    widths, heights = scan.width_height(0), scan.width_height(1)
+    texts = scan.emit_array(arg4)
+    t4 = _t.perf_counter()
+    for k, v in (("s_scan", t1 - t0), ("s_python_cells", t2 - t1), ("s_device", t3 - t2), ("s_emit", t4 - t3)):
+        totals[k] = totals.get(k, 0.0) + v
+    plain = len(irregular) == 0
+    widths, heights = (scan.wh_column(0), scan.wh_column(1)) if plain else (scan.width_height(0), scan.width_height(1))
     for col, key in ((widths, "width"), (heights, "height")):
-        for i, v in enumerate(col):
-            if v is Ellipsis:
-                col[i] = json.loads(cells[i]).get(key)
+        if isinstance(col, list):
+            for i, v in enumerate(col):
+                if v is Ellipsis:                      # rare value kinds (str / container / huge int): ask CPython
+                    col[i] = json.loads(cells[i]).get(key)
     high[scan.status != _nj.OK] = False                # no bbox text -> a NaN cell -> no boxes (:344-345)
     for i in np.flatnonzero((scan.iou_host != 0) & (scan.status == _nj.OK)).tolist():   # ints beyond 2^25: CPython decides
         high[i] = _iou_mask_python([texts[i]], min_boxes, iou_threshold, be, totals)[0]
@@ -740,8 +754,38 @@ def _replace_iou_cells_native(cells, min_boxes, iou_threshold, be, totals):
     totals["boxes"] += scan.n_boxes
     totals["points"] += int(scan.xy.shape[0])
     totals["fused_launches"] += 1
+    totals["fast_cells"] += scan.fast_cells
     scan.close()
     return texts, widths, heights, high
+
+
+def _join_columns(parts):
+    """per-batch column values (numpy arrays or lists) -> one value for ``frame[col] = ...``"""
+    if len(parts) == 1:
+        return parts[0]
+    if all(isinstance(p, np.ndarray) for p in parts) and len({p.dtype for p in parts}) == 1:
+        return np.concatenate(parts)
+    out = []
+    for p in parts:
+        out.extend(p.tolist() if isinstance(p, np.ndarray) else p)
+    return out
+
+
+def _replace_and_filter_arrays(cells, min_boxes, iou_threshold, be, totals):
+    """cells: object ndarray / list.  -> (texts object array, widths, heights, high) over all batches"""
+    if not _nj.enabled():                              # DYD_NATIVE_JSON=0: the two steps in sequence on the CPython flatten
+        totals["python_cells"] = len(cells)
+        texts, widths, heights = _replace_cells_python(list(cells), be, totals)
+        arr = np.empty(len(texts), object)
+        arr[:] = texts
+        return arr, widths, heights, _iou_mask_python(texts, min_boxes, iou_threshold, be, totals)
+    t_p, w_p, h_p, m_p = [], [], [], []
+    for start in range(0, len(cells), _NATIVE_CHUNK_CELLS):
+        t, w, h, m = _replace_iou_cells_native(cells[start:start + _NATIVE_CHUNK_CELLS], min_boxes, iou_threshold, be, totals)
+        t_p.append(t); w_p.append(w); h_p.append(h); m_p.append(m)
+    if not t_p:
+        return np.empty(0, object), [], [], np.zeros(0, bool)
+    return np.concatenate(t_p), _join_columns(w_p), _join_columns(h_p), np.concatenate(m_p)
 
 
 def replace_and_filter_cells(cells, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
@@ -751,33 +795,32 @@ def replace_and_filter_cells(cells, min_boxes: int = 2, iou_threshold: float = 0
     be = _backend(backend)
     cells = list(cells)
     totals = {"cells": len(cells), "boxes": 0, "points": 0, "host_boxes": 0, "host_rows": 0, "python_cells": 0,
-              "fused_launches": 0}
-    texts, widths, heights, parts = [], [], [], []
-    if _nj.enabled():
-        for start in range(0, len(cells), _NATIVE_CHUNK_CELLS):
-            t, w, h, m = _replace_iou_cells_native(cells[start:start + _NATIVE_CHUNK_CELLS], min_boxes, iou_threshold, be, totals)
-            texts.extend(t); widths.extend(w); heights.extend(h); parts.append(m)
-    else:                                              # DYD_NATIVE_JSON=0: the two steps in sequence on the CPython flatten
-        totals["python_cells"] = len(cells)
-        texts, widths, heights = _replace_cells_python(cells, be, totals)
-        parts.append(_iou_mask_python(texts, min_boxes, iou_threshold, be, totals))
-    high = np.concatenate(parts) if parts else np.zeros(0, bool)
+              "fused_launches": 0, "fast_cells": 0}
+    texts, widths, heights, high = _replace_and_filter_arrays(cells, min_boxes, iou_threshold, be, totals)
     if stats is not None:
         stats.update(totals)
-    return texts, widths, heights, high
+    return (texts.tolist(), widths.tolist() if isinstance(widths, np.ndarray) else widths,
+            heights.tolist() if isinstance(heights, np.ndarray) else heights, high)
 
 
 def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
                              stats: Optional[dict] = None):
     """In-memory twin of replace_ptlist -> iou_filter run back to back:
-    -> (kept frame with the three new columns, excluded rows, HIGH rows of kept, other rows of kept)."""
-    kept = df.dropna(subset=[ANNOTATION_COL]).copy()               # :249
-    excluded = df[df[ANNOTATION_COL].isna()].copy()                # :250
-    texts, widths, heights, high = replace_and_filter_cells(kept[ANNOTATION_COL].tolist(), min_boxes, iou_threshold,
-                                                            backend, stats)
+    -> (kept frame with the three new columns, excluded rows, HIGH rows of kept, other rows of kept).
+    The annotation cells are read in place (UTF-8 views of the column's str objects) and the new column's str objects are
+    created natively, so no per-cell Python work remains for regular cells."""
+    be = _backend(backend)
+    na = df[ANNOTATION_COL].isna()
+    kept = df[~na].copy()                                          # == dropna(subset=[col]).copy() (:249)
+    excluded = df[na].copy()                                       # :250
+    totals = {"cells": len(kept), "boxes": 0, "points": 0, "host_boxes": 0, "host_rows": 0, "python_cells": 0,
+              "fused_launches": 0, "fast_cells": 0}
+    texts, widths, heights, high = _replace_and_filter_arrays(kept[ANNOTATION_COL].to_numpy(), min_boxes, iou_threshold, be, totals)
     kept[BBOX_COL] = pd.Series(texts, index=kept.index, dtype=object)
     kept["width"] = widths
     kept["height"] = heights
+    if stats is not None:
+        stats.update(totals)
     return kept, excluded, kept[high], kept[~high]
 
 

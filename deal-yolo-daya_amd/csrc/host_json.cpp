@@ -1286,6 +1286,60 @@ int dyd_json_emit_polygons(dyd_scan *h, const uint8_t *text, const int64_t *cell
     return DYD_OK;
 }
 
+// ---- synthetic annotation cells (measurement / test aid) ------------------------------------------------------
+// The JSON text json.dumps(..., ensure_ascii=False) gives for the rows of a SynthTable (synth.py: row_json), written by
+// all cores, so that bench.py and the parity tests can build million-row JSON tables in seconds instead of minutes:
+//   {"width": W, "height": H, "objects": [{"id": k, "name": "c<label>", "polygon": {"ptList": [{"x": .., "y": ..}, ...]},
+//   "type": "polygon"}, ...]}   — coordinates of an int_row printed as ints, the others as float repr.
+int dyd_synth_json(const double *xy, const int32_t *pt_off, const int32_t *box_off, const int32_t *label, const uint8_t *int_row,
+                   int64_t n_rows, int64_t width, int64_t height, int n_threads, uint8_t **out_text, int64_t *out_off) {
+    if (!out_text || !out_off || n_rows < 0 || (n_rows > 0 && (!pt_off || !box_off || !label || !int_row))) return DYD_ERR_INVALID;
+    *out_text = nullptr;
+    if (n_threads <= 0) n_threads = default_threads();
+    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(n_threads, 64), n_rows / 64));
+    std::vector<Raw<char>> parts((size_t)n_threads);
+    std::vector<int64_t> lens((size_t)n_rows, 0);
+    if (!parallel_index_safe(n_threads, [&](int t) {
+            Raw<char> &o = parts[(size_t)t];
+            std::string tmp;
+            char head[96];
+            const int hl = snprintf(head, sizeof(head), "{\"width\": %lld, \"height\": %lld, \"objects\": [", (long long)width, (long long)height);
+            const int64_t lo = n_rows * t / n_threads, hi = n_rows * (t + 1) / n_threads;
+            for (int64_t r = lo; r < hi; ++r) {
+                const size_t mark = o.n;
+                o.put(head, (size_t)hl);
+                const bool as_int = int_row[r] != 0;
+                for (int32_t b = box_off[r]; b < box_off[r + 1]; ++b) {
+                    char buf[96];
+                    const int k = snprintf(buf, sizeof(buf), "%s{\"id\": %d, \"name\": \"c%d\", \"polygon\": {\"ptList\": [", b > box_off[r] ? ", " : "",
+                                           (int)(b - box_off[r]), (int)label[b]);
+                    o.put(buf, (size_t)k);
+                    for (int32_t p = pt_off[b]; p < pt_off[b + 1]; ++p) {
+                        o.put(p > pt_off[b] ? ", {\"x\": " : "{\"x\": ", p > pt_off[b] ? 8 : 6);
+                        fj_put_coord(o, xy[2 * (size_t)p], as_int, tmp);
+                        o.put(", \"y\": ", 7);
+                        fj_put_coord(o, xy[2 * (size_t)p + 1], as_int, tmp);
+                        o.push('}');
+                    }
+                    o.put("]}, \"type\": \"polygon\"}", 22);
+                }
+                o.put("]}", 2);
+                lens[(size_t)r] = (int64_t)(o.n - mark);
+            }
+        }))
+        return DYD_ERR_OOM;
+    size_t total = 0;
+    std::vector<size_t> base((size_t)n_threads, 0);
+    for (int t = 0; t < n_threads; ++t) { base[(size_t)t] = total; total += parts[(size_t)t].n; }
+    uint8_t *buf = static_cast<uint8_t *>(malloc(total ? total : 1));
+    if (!buf) return DYD_ERR_OOM;
+    parallel_index_safe(n_threads, [&](int t) { if (parts[(size_t)t].n) memcpy(buf + base[(size_t)t], parts[(size_t)t].p, parts[(size_t)t].n); });
+    out_off[0] = 0;
+    for (int64_t r = 0; r < n_rows; ++r) out_off[r + 1] = out_off[r] + lens[(size_t)r];
+    *out_text = buf;
+    return DYD_OK;
+}
+
 void dyd_scan_free(dyd_scan *h) { delete h; }
 
 // Scan bbox-JSON cells for the IoU step (processor.py:341-366): two-point boxes per row with the

@@ -138,6 +138,20 @@ class PolygonScan(_Scan):
         for irregular ones (the caller fills those in)."""
         return self.emit_array(arg4, n_threads).tolist()
 
+    def wh_column(self, which: int):
+        """doc.get("width") / doc.get("height") of every cell as ONE column value for ``frame[col] = ...``: a numpy array
+        when the cells hold only ints / floats / nothing (int64 when all are ints, float64 with NaN otherwise — the dtypes
+        pandas infers from the reference's list, processor.py:295-296), else the per-cell list of width_height()."""
+        kind = self.w_kind if which == 0 else self.h_kind
+        val = self.w_val if which == 0 else self.h_val
+        if self.n_cells == 0 or (kind == 3).any() or not kind.any():
+            return self.width_height(which)
+        if (kind == 1).all():
+            return val.astype(np.int64)
+        out = val.copy()
+        out[kind == 0] = np.nan
+        return out
+
     def width_height(self, which: int) -> list:
         """Python values of doc.get("width") / doc.get("height") for regular cells (None elsewhere);
         kind 3 (string / container / huge int) is returned as the marker ``Ellipsis`` for the caller."""

@@ -156,8 +156,46 @@ def row_json(t: SynthTable, r: int) -> str:
     return json.dumps({"width": t.width, "height": t.height, "objects": objs}, ensure_ascii=False)
 
 
+def json_buffers(t: SynthTable, n_threads: int = 0):
+    """(utf-8 bytes u8, offsets i64 [n+1]) of every row's JSON cell, written natively by all cores (dyd_synth_json: host code of
+    libdyd_gfx950.so, no GPU involved) — byte for byte what row_json gives."""
+    import ctypes as C
+
+    from . import _native
+
+    L = _native.load_library()
+    xy = np.ascontiguousarray(t.xy, dtype=np.float64)
+    pt_off = np.ascontiguousarray(t.pt_off, dtype=np.int32)
+    box_off = np.ascontiguousarray(t.box_off, dtype=np.int32)
+    label = np.ascontiguousarray(t.label, dtype=np.int32)
+    int_row = np.ascontiguousarray(t.int_row, dtype=np.uint8)
+    off = np.zeros(t.n_rows + 1, np.int64)
+    text = C.c_void_p()
+    _native.check(L.dyd_synth_json(xy.ctypes.data, pt_off.ctypes.data, box_off.ctypes.data, label.ctypes.data, int_row.ctypes.data,
+                                   t.n_rows, t.width, t.height, n_threads, C.byref(text), off.ctypes.data), "dyd_synth_json")
+    try:
+        data = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(max(int(off[-1]), 1),))[:int(off[-1])].copy()
+    finally:
+        L.dyd_host_free(text)
+    return data, off
+
+
+def json_cells(t: SynthTable) -> np.ndarray:
+    """object array of the rows' JSON cells (str): native writer + native str creation when the library is built, the
+    per-row Python rendering otherwise"""
+    try:
+        from . import native_json
+
+        data, off = json_buffers(t)
+        return native_json.strings_from_buffers(data, off)
+    except Exception:  # noqa: BLE001 - library not built: the portable rendering
+        out = np.empty(t.n_rows, object)
+        out[:] = [row_json(t, r) for r in range(t.n_rows)]
+        return out
+
+
 def to_frame(t: SynthTable):
-    """The JSON-string DataFrame of the same table (use for n_rows <= ~1e6)."""
+    """The JSON-string DataFrame of the same table."""
     import pandas as pd
 
-    return pd.DataFrame({"source": urls(t), ANN_COL: [row_json(t, r) for r in range(t.n_rows)]})
+    return pd.DataFrame({"source": urls(t), ANN_COL: json_cells(t)})

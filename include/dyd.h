@@ -245,6 +245,10 @@ int dyd_json_scan_labelled(const uint8_t *text, const int64_t *cell_off, const u
                            const uint8_t *label_text, const int64_t *label_off, int n_threads, dyd_scan **out);
 const uint8_t *dyd_scan_sel(const dyd_scan *scan);             /* [n_boxes] (labelled scan only) */
 void dyd_scan_free(dyd_scan *scan);
+/* measurement / test aid (host, multithreaded): the annotation cells of a synthetic table as json.dumps would write them
+ * (deal-yolo-daya_amd/synth.py: row_json) — flat utf-8 in *out_text (release with dyd_host_free) and offsets [n_rows+1]. */
+int dyd_synth_json(const double *xy, const int32_t *pt_off, const int32_t *box_off, const int32_t *label, const uint8_t *int_row,
+                   int64_t n_rows, int64_t width, int64_t height, int n_threads, uint8_t **out_text, int64_t *out_off);
 
 /* ---- native expansion of the split step (HOST code, multithreaded) -----------------------------------
  * Replaces the per-row Python of split_dataset_by_rules (processor.py:712-792; utils.py:645-662): every row

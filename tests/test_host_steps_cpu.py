@@ -157,6 +157,9 @@ def run_chain_golden(backend, tmp_path):
         want_hi = pd.read_csv(Q("hi.csv"), encoding="utf-8-sig", dtype={"source": str})["source"].tolist()
         assert high["source"].tolist() == want_hi and len(high) + len(other) == len(kept) == g["result"]["filtered_rows"]
         assert kept[P.BBOX_COL].isna().sum() == 2 and len(excluded) == 1
+        okept, _, oexc = osteps.replace_frame(df)                      # values AND dtypes of the three new columns
+        pd.testing.assert_frame_equal(kept, okept)
+        pd.testing.assert_frame_equal(excluded, oexc)
     # the end-to-end fixture (240 rows through the reference): filtered -> processed / excluded / high / other, byte for byte
     write_csv_text(Q("filtered.csv"), golden_csv_text("e2e_filtered.csv.gz"))
     P.LAST_IO_PATH.clear()
@@ -187,6 +190,13 @@ def run_chain_golden(backend, tmp_path):
         ohi, olo = osteps.iou_filter_frame(oproj, mb, thr)
         assert high["source"].tolist() == ohi["source"].tolist() and other["source"].tolist() == olo["source"].tolist(), (mb, thr)
         assert high[P.BBOX_COL].tolist() == ohi[osteps.NEW_COL].tolist()
+    # width / height columns: all ints -> int64, ints and gaps -> float64, nothing at all -> object, a string among them -> object
+    for ws in ([640, 480, 1], [640, None, 1.5], [None, None, None], [640, "640", None], [2 ** 60, 1, 2]):
+        cells = [json.dumps({"objects": [], **({"width": w, "height": w} if w is not None else {})}) for w in ws]
+        df = pd.DataFrame({"source": ["a", "b", "c"], P.ANNOTATION_COL: cells})
+        kept, _, _, _ = P.replace_and_filter_frame(df, 2, 0.98, backend)
+        okept, _, _ = osteps.replace_frame(df)
+        pd.testing.assert_frame_equal(kept, okept)
 
 
 # ---------------------------------------------------------------------------------- CPU runs

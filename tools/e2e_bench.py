@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Host-inclusive throughput of the replace + IoU steps, DataFrame in -> frames out (SURVEY §8d region 2): one native scan,
+one fused K1+K2 launch, one native emit.  Prints one JSON line per repetition with the phase split.
+
+    python tools/e2e_bench.py --rows 1000000 --reps 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--check", type=int, default=2000, help="rows compared with the CPU port of the reference (0 = none)")
+    args = ap.parse_args()
+
+    import pandas as pd
+    from deal_yolo_daya_amd import _native, native_json, synth
+    from deal_yolo_daya_amd.core import processor as P
+
+    _native.lib()
+    t0 = time.perf_counter()
+    parts = []
+    for ci, s in enumerate(range(0, args.rows, 250_000)):
+        t = synth.generate(min(250_000, args.rows - s), seed=synth.SEED + ci)
+        parts.append(pd.DataFrame({"source": synth.urls(t), synth.ANN_COL: synth.json_cells(t)}))
+        del t
+    df = pd.concat(parts, ignore_index=True)
+    del parts
+    n_bytes = int(df[synth.ANN_COL].str.len().sum())
+    print(f"# table: {len(df)} rows, {n_bytes / 1e9:.2f} GB of JSON, generated in {time.perf_counter() - t0:.0f}s; "
+          f"host threads {native_json.host_threads()}", file=sys.stderr, flush=True)
+    for rep in range(args.reps):
+        stats = {}
+        a = time.perf_counter()
+        kept, excluded, high, other = P.replace_and_filter_frame(df, 2, 0.98, stats=stats)
+        dt = time.perf_counter() - a
+        out_bytes = int(kept[P.BBOX_COL].str.len().sum()) if rep == 0 else None
+        print(json.dumps({"rows": len(df), "seconds": round(dt, 3), "rows_per_s": round(len(df) / dt), "high": len(high),
+                          "phases_s": {k: round(v, 3) for k, v in stats.items() if k.startswith("s_")},
+                          "fast_cells": stats.get("fast_cells"), "python_cells": stats.get("python_cells"),
+                          "out_bytes": out_bytes, "kernel_ms": round(_native.last_kernel_ms(), 3)}), flush=True)
+    if args.check:
+        from oracle import steps as osteps
+        sub = df.iloc[:args.check]
+        kept, _, high, other = P.replace_and_filter_frame(sub, 2, 0.98)
+        okept, oproj, _ = osteps.replace_frame(sub)
+        ohi, olo = osteps.iou_filter_frame(oproj, 2, 0.98)
+        pd.testing.assert_frame_equal(kept, okept)
+        assert high["source"].tolist() == ohi["source"].tolist() and other["source"].tolist() == olo["source"].tolist()
+        print(f"# first {args.check} rows identical to the CPU port of the reference", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
