@@ -755,7 +755,10 @@ def _replace_iou_cells_native(cells, min_boxes, iou_threshold, be, totals):
     totals["points"] += int(scan.xy.shape[0])
     totals["fused_launches"] += 1
     totals["fast_cells"] += scan.fast_cells
+    t5 = _t.perf_counter()
     scan.close()
+    totals["s_fixups"] = totals.get("s_fixups", 0.0) + (t5 - t4)
+    totals["s_release"] = totals.get("s_release", 0.0) + (_t.perf_counter() - t5)
     return texts, widths, heights, high
 
 
@@ -809,19 +812,26 @@ def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold
     -> (kept frame with the three new columns, excluded rows, HIGH rows of kept, other rows of kept).
     The annotation cells are read in place (UTF-8 views of the column's str objects) and the new column's str objects are
     created natively, so no per-cell Python work remains for regular cells."""
+    import time as _t
     be = _backend(backend)
+    t0 = _t.perf_counter()
     na = df[ANNOTATION_COL].isna()
     kept = df[~na].copy()                                          # == dropna(subset=[col]).copy() (:249)
     excluded = df[na].copy()                                       # :250
     totals = {"cells": len(kept), "boxes": 0, "points": 0, "host_boxes": 0, "host_rows": 0, "python_cells": 0,
               "fused_launches": 0, "fast_cells": 0}
+    t1 = _t.perf_counter()
     texts, widths, heights, high = _replace_and_filter_arrays(kept[ANNOTATION_COL].to_numpy(), min_boxes, iou_threshold, be, totals)
+    t2 = _t.perf_counter()
     kept[BBOX_COL] = pd.Series(texts, index=kept.index, dtype=object)
     kept["width"] = widths
     kept["height"] = heights
+    out = (kept, excluded, kept[high], kept[~high])
+    totals["s_frame_in"] = t1 - t0
+    totals["s_frame_out"] = _t.perf_counter() - t2
     if stats is not None:
         stats.update(totals)
-    return kept, excluded, kept[high], kept[~high]
+    return out
 
 
 def _as_reread(core, names):

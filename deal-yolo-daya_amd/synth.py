@@ -126,6 +126,75 @@ def generate(n_rows: int, seed: int = SEED, boxes_per_row: int | None = None,
                       url_id=url_id)
 
 
+def generate_device(n_rows: int, seed: int, device, boxes_per_row: int | None = None, max_boxes: int = 32,
+                    dup_prob: float = 0.05, tie_prob: float = 0.001) -> dict:
+    """The same table shape as ``generate`` drawn ON the device with torch (for the 10M-row bench tables, where the numpy
+    generator would take minutes): identical distributions and planted rows (near-duplicate last box, exact-tie pair,
+    integer-valued half), a different random stream.  -> dict of device tensors xy [P,2] f64, pt_off [B+1] i32,
+    box_off [N+1] i32, label [B] i32, int_row [N] bool, url_id [N] i64."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    kw = {"generator": g, "device": device}
+    if boxes_per_row is None:
+        nb = torch.randint(1, max_boxes + 1, (n_rows,), dtype=torch.int64, **kw)
+    else:
+        nb = torch.full((n_rows,), boxes_per_row, dtype=torch.int64, device=device)
+    box_off = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
+    box_off[1:] = torch.cumsum(nb, 0)
+    B = int(box_off[-1])
+    int_row = torch.rand(n_rows, **kw) < 0.5
+    dup_row = (torch.rand(n_rows, **kw) < dup_prob) & (nb >= 2)
+    tie_row = (torch.rand(n_rows, **kw) < tie_prob) & (nb >= 2) & ~dup_row
+    npts = torch.randint(3, 13, (B,), dtype=torch.int64, **kw)
+    last_box, first_box = box_off[1:] - 1, box_off[:-1]
+    npts[last_box[dup_row]] = npts[first_box[dup_row]]
+    npts[last_box[tie_row]] = 4
+    npts[last_box[tie_row] - 1] = 4
+    pt_off = torch.zeros(B + 1, dtype=torch.int64, device=device)
+    pt_off[1:] = torch.cumsum(npts, 0)
+    P = int(pt_off[-1])
+    if P >= 2 ** 31:
+        raise ValueError("point count exceeds int32 offsets; generate in chunks")
+    box_of_pt = torch.repeat_interleave(torch.arange(B, device=device), npts)
+    centre = torch.rand((B, 2), dtype=torch.float64, **kw) * torch.tensor([1920.0, 1080.0], dtype=torch.float64, device=device)
+    xy = centre[box_of_pt] + (torch.rand((P, 2), dtype=torch.float64, **kw) * 100.0 - 50.0)
+    del centre
+    if bool(dup_row.any()):
+        src, dst = first_box[dup_row], last_box[dup_row]
+        cnt = npts[src]
+        k = torch.arange(int(cnt.sum()), device=device) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+        s_idx = torch.repeat_interleave(pt_off[src], cnt) + k
+        d_idx = torch.repeat_interleave(pt_off[dst], cnt) + k
+        seg = torch.repeat_interleave(torch.arange(len(src), device=device), cnt)
+        ymin = torch.full((len(src),), float("inf"), dtype=torch.float64, device=device).scatter_reduce(0, seg, xy[s_idx, 1], "amin")
+        shrink = torch.rand(len(src), dtype=torch.float64, **kw) * 0.03
+        xy[d_idx, 0] = xy[s_idx, 0]
+        xy[d_idx, 1] = ymin[seg] + (xy[s_idx, 1] - ymin[seg]) * (1.0 - shrink[seg])
+    int_pt = int_row[torch.repeat_interleave(torch.arange(n_rows, device=device), nb)][box_of_pt]
+    del box_of_pt
+    xy = torch.where(int_pt[:, None], torch.round(xy), torch.round(xy * 100.0) / 100.0)
+    del int_pt
+    if bool(tie_row.any()):
+        lb = last_box[tie_row]
+        a = torch.tensor([[0, 0], [100, 0], [100, 100], [0, 100]], dtype=torch.float64, device=device)
+        b = torch.tensor([[0, 0], [100, 0], [100, 98], [0, 98]], dtype=torch.float64, device=device)
+        four = torch.arange(4, device=device)
+        xy[(pt_off[lb - 1][:, None] + four).reshape(-1)] = a.repeat(len(lb), 1)
+        xy[(pt_off[lb][:, None] + four).reshape(-1)] = b.repeat(len(lb), 1)
+    label = torch.randint(0, N_LABELS, (B,), dtype=torch.int64, **kw).to(torch.int32)
+    url_id = torch.randint(0, max(1, int(0.9 * n_rows)) + 1, (n_rows,), dtype=torch.int64, **kw)
+    return {"xy": xy, "pt_off": pt_off.to(torch.int32), "box_off": box_off.to(torch.int32), "label": label,
+            "int_row": int_row, "url_id": url_id}
+
+
+def table_from_device(d: dict) -> SynthTable:
+    """host copy of a generate_device result (e.g. to render its JSON cells)"""
+    c = {k: v.cpu().numpy() for k, v in d.items()}
+    return SynthTable(n_rows=len(c["int_row"]), xy=c["xy"], pt_off=c["pt_off"], box_off=c["box_off"], label=c["label"],
+                      int_row=c["int_row"], url_id=c["url_id"])
+
+
 def urls(t: SynthTable) -> list:
     return [f"http://img.example/{k}.jpg" for k in t.url_id.tolist()]
 
