@@ -176,11 +176,13 @@ def full_pipeline(tab, dev, L, ck, sp):
     n_val = torch.tensor([int(s * 0.1) for s in sizes], dtype=torch.int64, device=dev)
     split = torch.empty(B, dtype=torch.uint8, device=dev)
     pos = torch.empty(B, dtype=torch.int64, device=dev)
-    if hasattr(L, "dyd_split_ids_seeded_dev"):
-        sizes_t = torch.tensor(sizes, dtype=torch.int64, device=dev)
-        ms = timeit(lambda: ck(L.dyd_split_ids_seeded_dev(cat.data_ptr(), B, 42, sizes_t.data_ptr(), n_train.data_ptr(), n_val.data_ptr(),
-                                                          2, split.data_ptr(), pos.data_ptr(), sp), "k6 seeded"))
-        stage("permutation on the device + K6 split ids (records = boxes)", 21 * B, ms, records=B, permutation="device")
+    if hasattr(L, "dyd_split_ids_seeded_dev") and os.environ.get("DYD_BENCH_HOST_PERM") != "1":
+        h_sizes = np.asarray(sizes, np.int64)
+        h_tr, h_va = n_train.cpu().numpy(), n_val.cpu().numpy()
+        ms = timeit(lambda: ck(L.dyd_split_ids_seeded_dev(cat.data_ptr(), B, 42, h_sizes.ctypes.data, h_tr.ctypes.data, h_va.ctypes.data,
+                                                          2, None, split.data_ptr(), pos.data_ptr(), sp), "k6 seeded"))
+        stage("K8 permutations (MT19937 stream + rejection resolve + radix sort, on the device) + K6 split ids (records = boxes)", 21 * B, ms,
+              records=B, permutation="device")
     else:
         th = time.perf_counter()
         perm_np = np.concatenate([_native.mt19937_permutation(42, s) for s in sizes])

@@ -77,6 +77,11 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_split_ids_sharded_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_mt19937_permutation_dev": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dyd_split_ids_seeded": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_void_p]),
+    "dyd_split_ids_seeded_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_yolo_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "dyd_yolo_lines_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
@@ -314,6 +319,45 @@ def mt19937_permutation(seed: int, n: int) -> np.ndarray:
     out = np.empty(int(n), np.int64)
     check(load_library().dyd_mt19937_permutation(int(seed), int(n), _ptr(out)), "dyd_mt19937_permutation")
     return out
+
+
+def mt19937_permutation_device(seed: int, n: int, want_inverse: bool = False):
+    """K8: the same permutation computed in parallel on the GPU (n <= 2^30) -> perm [, inverse] as int64 host arrays"""
+    if not (0 <= int(seed) <= 2 ** 32 - 1):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    L = lib()
+    n = int(n)
+    nbytes = 8 * max(n, 1)
+    d_perm, d_inv = C.c_void_p(), C.c_void_p()
+    check(L.dyd_malloc(C.byref(d_perm), nbytes), "dyd_malloc")
+    check(L.dyd_malloc(C.byref(d_inv), nbytes), "dyd_malloc")
+    try:
+        check(L.dyd_mt19937_permutation_dev(int(seed), n, d_perm, d_inv, None), "dyd_mt19937_permutation_dev")
+        perm, inv = np.empty(n, np.int64), np.empty(n, np.int64)
+        if n:
+            check(L.dyd_d2h(_ptr(perm), d_perm, 8 * n), "dyd_d2h")
+            check(L.dyd_d2h(_ptr(inv), d_inv, 8 * n), "dyd_d2h")
+    finally:
+        L.dyd_free(d_perm)
+        L.dyd_free(d_inv)
+    return (perm, inv) if want_inverse else perm
+
+
+def split_ids_seeded(cat, seed: int, sizes, n_train, n_val):
+    """K8 + K6 over host arrays: (split u8, pos i64); the categories' permutations are made on the device from `seed`"""
+    if not (0 <= int(seed) <= 2 ** 32 - 1):
+        raise ValueError("Seed must be between 0 and 2**32 - 1")
+    cat = np.ascontiguousarray(cat, dtype=np.int32)
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    n_train = np.ascontiguousarray(n_train, dtype=np.int64)
+    n_val = np.ascontiguousarray(n_val, dtype=np.int64)
+    if not (len(sizes) == len(n_train) == len(n_val)):
+        raise ValueError("sizes / n_train / n_val sizes disagree")
+    split = np.empty(len(cat), np.uint8)
+    pos = np.empty(len(cat), np.int64)
+    check(lib().dyd_split_ids_seeded(_ptr(cat), len(cat), int(seed), _ptr(sizes), _ptr(n_train), _ptr(n_val), len(sizes),
+                                     _ptr(split), _ptr(pos)), "dyd_split_ids_seeded")
+    return split, pos
 
 
 def split_ids(cat, perm_concat, cat_off, n_train, n_val):

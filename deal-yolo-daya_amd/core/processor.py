@@ -1089,15 +1089,18 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
     sizes = np.bincount(cat_arr, minlength=n_cat).astype(np.int64) if n_cat else np.zeros(0, np.int64)
     cat_off = np.zeros(n_cat + 1, np.int64)
     np.cumsum(sizes, out=cat_off[1:])
-    perms = [be.mt19937_permutation(random_seed, int(s)) for s in sizes]      # same seed per category (:800)
     cuts = [split_cut_sizes(int(s), train_ratio, val_ratio, test_ratio) for s in sizes]
     n_train = np.asarray([c[0] for c in cuts], np.int64)
     n_val = np.asarray([c[1] for c in cuts], np.int64)
-    if len(cat_arr):
+    if not len(cat_arr):
+        split, pos = np.zeros(0, np.uint8), np.zeros(0, np.int64)
+    elif hasattr(be, "split_ids_seeded"):
+        # K8 + K6: the permutations (same seed per category, :800) are made on the device and never leave it
+        split, pos = be.split_ids_seeded(cat_arr, random_seed, sizes, n_train, n_val)
+    else:
+        perms = [be.mt19937_permutation(random_seed, int(s)) for s in sizes]
         split, pos = be.split_ids(cat_arr, np.concatenate(perms) if perms else np.zeros(0, np.int64), cat_off,
                                   n_train, n_val)
-    else:
-        split, pos = np.zeros(0, np.uint8), np.zeros(0, np.int64)
 
     # ---- emit: per-category frames in shuffled order, cut by split id ------------------------
     out_cats, cat_counts = {}, {}

@@ -16,6 +16,8 @@
 // per category (chunked: shuffle scan inside 4096-tile chunks, then the few chunk totals); pass C replays the tile 64 rows at a time: lanes
 // holding the same category are found with ballots, a lane's rank is counter + popcount of the
 // lower lanes of its ballot.  Categories are processed in windows of K6_CATS so any n_cat fits.
+#include <vector>
+
 #include "dyd_common.h"
 
 namespace dyd {
@@ -226,14 +228,16 @@ __global__ __launch_bounds__(K6_BLOCK) void k6_unclassified(const int32_t *__res
 static int g_k6_variant = 1;
 void set_k6_variant(int v) { g_k6_variant = v ? 1 : 0; }
 
+// inv_ready: the inverse permutations are already there as 32-bit positions (K8 writes them directly); then `perm` is unused
 static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, const int64_t *cat_off,
                         const int64_t *n_train, const int64_t *n_val, int32_t n_cat, int64_t total,
-                        const int64_t *rank_base, uint8_t *out_split, int64_t *out_pos, hipStream_t st) {
+                        const int64_t *rank_base, uint8_t *out_split, int64_t *out_pos, hipStream_t st,
+                        const uint32_t *inv_ready = nullptr) {
     const int64_t n_tiles = ceil_div(n, K6_TILE);
     const int64_t blocks = ceil_div(n_tiles, K6_WAVES);
     const int32_t win = n_cat < K6_CATS ? n_cat : K6_CATS;
-    const bool narrow = g_k6_variant != 0;   // 32-bit inverse table (n < 2^32 is required at the entry points)
-    const size_t inv_bytes = (((size_t)(total > 0 ? total : 1) * (narrow ? 4 : 8)) + 15) & ~(size_t)15;
+    const bool narrow = g_k6_variant != 0 || inv_ready;   // 32-bit inverse table (n < 2^32 is required at the entry points)
+    const size_t inv_bytes = inv_ready ? 16 : (((size_t)(total > 0 ? total : 1) * (narrow ? 4 : 8)) + 15) & ~(size_t)15;
     const size_t hist_bytes = (((size_t)(win > 0 ? win : 1) * (size_t)n_tiles * 4) + 15) & ~(size_t)15;
     const int64_t n_chunks = ceil_div(n_tiles, K6_SCAN_CHUNK);
     const size_t tot_bytes = (size_t)(win > 0 ? win : 1) * (size_t)n_chunks * 8;
@@ -249,7 +253,8 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
                            out_split, out_pos);
         DYD_HIP(hipGetLastError());
     }
-    if (total > 0) {
+    if (inv_ready) inv = reinterpret_cast<int64_t *>(const_cast<uint32_t *>(inv_ready));
+    if (total > 0 && !inv_ready) {
         DYD_HIP(hipMemsetAsync(inv, 0, inv_bytes, st));
         if (narrow)
             hipLaunchKernelGGL(k6_invert32, dim3((unsigned)ceil_div(total, K6_BLOCK)), dim3(K6_BLOCK), 0, st, perm, cat_off, n_cat,
@@ -281,11 +286,103 @@ static int split_launch(const int32_t *cat, int64_t n, const int64_t *perm, cons
     return DYD_OK;
 }
 
+int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *const *inv32, int64_t *const *inv64,
+                    int64_t *const *perm64, hipStream_t st);
+
+// K6 with the permutations made on the device (K8): sizes / cuts are HOST arrays (a handful of numbers the caller has anyway:
+// it computed the cuts from the sizes, reference :801-802), everything else stays on the device.
+static int split_seeded(const int32_t *cat, int64_t n, uint32_t seed, const int64_t *sizes, const int64_t *n_train, const int64_t *n_val,
+                        int32_t n_cat, const int64_t *rank_base_host, uint8_t *out_split, int64_t *out_pos, hipStream_t st) {
+    std::vector<int64_t> off((size_t)n_cat + 1, 0);
+    for (int32_t c = 0; c < n_cat; ++c) {
+        if (sizes[c] < 0) { set_error("invalid argument: negative category size"); return DYD_ERR_INVALID; }
+        off[(size_t)c + 1] = off[(size_t)c] + sizes[c];
+    }
+    const int64_t total = off[(size_t)n_cat];
+    if (total >= (1LL << 32)) { set_error("invalid argument: more than 2^32 records"); return DYD_ERR_INVALID; }
+    DevBuf d_inv, d_small;
+    int rc;
+    if ((rc = d_inv.alloc(4 * (size_t)(total > 0 ? total : 1))) || (rc = d_small.alloc(8 * (size_t)(4 * n_cat + 1)))) return rc;
+    uint32_t *inv = d_inv.as<uint32_t>();
+    int64_t *d_off = d_small.as<int64_t>(), *d_tr = d_off + n_cat + 1, *d_va = d_tr + n_cat, *d_rb = d_va + n_cat;
+    DYD_HIP(hipMemcpyAsync(d_off, off.data(), 8 * (size_t)(n_cat + 1), hipMemcpyHostToDevice, st));
+    if (n_cat) {
+        DYD_HIP(hipMemcpyAsync(d_tr, n_train, 8 * (size_t)n_cat, hipMemcpyHostToDevice, st));
+        DYD_HIP(hipMemcpyAsync(d_va, n_val, 8 * (size_t)n_cat, hipMemcpyHostToDevice, st));
+        if (rank_base_host) DYD_HIP(hipMemcpyAsync(d_rb, rank_base_host, 8 * (size_t)n_cat, hipMemcpyHostToDevice, st));
+    }
+    // big categories on the device (one shared generator stream: every category uses the same seed), small ones with the
+    // sequential host loop (a few dozen kernel launches would cost more than they do)
+    constexpr int64_t kHostBelow = 1 << 15;
+    std::vector<int64_t> big_sizes;
+    std::vector<uint32_t *> big_inv;
+    std::vector<int64_t> perm;
+    std::vector<uint32_t> small_inv;
+    for (int32_t c = 0; c < n_cat; ++c) {
+        if (sizes[c] >= kHostBelow) {
+            big_sizes.push_back(sizes[c]);
+            big_inv.push_back(inv + off[(size_t)c]);
+        } else if (sizes[c] > 0) {
+            perm.resize((size_t)sizes[c]);
+            small_inv.resize((size_t)sizes[c]);
+            rc = dyd_mt19937_permutation(seed, sizes[c], perm.data());
+            if (rc) return rc;
+            for (int64_t k = 0; k < sizes[c]; ++k) small_inv[(size_t)perm[(size_t)k]] = (uint32_t)k;
+            DYD_HIP(hipMemcpyAsync(inv + off[(size_t)c], small_inv.data(), 4 * (size_t)sizes[c], hipMemcpyHostToDevice, st));
+            DYD_HIP(hipStreamSynchronize(st));   // small_inv is reused
+        }
+    }
+    if (!big_sizes.empty()) {
+        rc = k8_permutations(seed, big_sizes.data(), (int)big_sizes.size(), big_inv.data(), nullptr, nullptr, st);
+        if (rc) return rc;
+    }
+    rc = split_launch(cat, n, nullptr, d_off, d_tr, d_va, n_cat, total, rank_base_host ? d_rb : nullptr, out_split, out_pos, st, inv);
+    if (rc) return rc;
+    DYD_HIP(hipStreamSynchronize(st));   // the tables above are freed on return
+    return DYD_OK;
+}
+
 }  // namespace dyd
 
 using namespace dyd;
 
 extern "C" {
+
+int dyd_split_ids_seeded_dev(const int32_t *cat, int64_t n, uint32_t seed, const int64_t *cat_sizes_host, const int64_t *n_train_host,
+                             const int64_t *n_val_host, int32_t n_cat, const int64_t *cat_rank_base_host_or_null, uint8_t *out_split,
+                             int64_t *out_pos, void *stream) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0 && n_cat >= 0, "negative size");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(cat && out_split && out_pos, "null pointer");
+    DYD_REQUIRE(n_cat == 0 || (cat_sizes_host && n_train_host && n_val_host), "null pointer");
+    DYD_REQUIRE(n < (1LL << 32), "n too large");
+    return split_seeded(cat, n, seed, cat_sizes_host, n_train_host, n_val_host, n_cat, cat_rank_base_host_or_null, out_split, out_pos,
+                        pick_stream(stream));
+}
+
+int dyd_split_ids_seeded(const int32_t *cat, int64_t n, uint32_t seed, const int64_t *cat_sizes, const int64_t *n_train,
+                         const int64_t *n_val, int32_t n_cat, uint8_t *out_split, int64_t *out_pos) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0 && n_cat >= 0, "negative size");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(cat && out_split && out_pos, "null pointer");
+    DYD_REQUIRE(n_cat == 0 || (cat_sizes && n_train && n_val), "null pointer");
+    DYD_REQUIRE(n < (1LL << 32), "n too large");
+    DevBuf d_cat, d_split, d_pos;
+    int rc;
+    if ((rc = d_cat.alloc(4 * (size_t)n)) || (rc = d_split.alloc((size_t)n)) || (rc = d_pos.alloc(8 * (size_t)n))) return rc;
+    hipStream_t st = ctx().stream;
+    DYD_HIP(hipMemcpyAsync(d_cat.p, cat, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    KernelTimer t(st);
+    rc = split_seeded(d_cat.as<int32_t>(), n, seed, cat_sizes, n_train, n_val, n_cat, nullptr, d_split.as<uint8_t>(), d_pos.as<int64_t>(), st);
+    if (rc) return rc;
+    t.finish();
+    DYD_HIP(hipMemcpyAsync(out_split, d_split.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(out_pos, d_pos.p, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    return DYD_OK;
+}
 
 int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_concat, const int64_t *cat_off,
                       const int64_t *n_train, const int64_t *n_val, int32_t n_cat, uint8_t *out_split,

@@ -1,0 +1,394 @@
+// k8_perm.hip — K8: numpy's legacy RandomState(seed).permutation(n) on the device, in parallel, bit for bit.
+//
+// Replaces the shuffle inside DataFrame.sample(frac=1, random_state=seed) (reference core/processor.py:800): MT19937 seeded
+// by init_genrand, then a reversed Fisher-Yates whose partner for step i = n-1 .. 1 is a 32-bit output masked to the next
+// 2^k-1 >= i and REJECTED while it exceeds i.  Written as a loop it is sequential three times over — the generator's
+// recurrence, the rejection (which draw belongs to which step depends on every earlier rejection) and the swap chain (165 M
+// dependent cache misses on the host: 1.4 s for configs[2]'s two categories).  None of the three needs to be:
+//
+//   stream    MT19937 regenerates its 624-word state in place, but every new word is an XOR of at most three OLD-state
+//             terms plus old-state twists (s'[k] = F(k)^s[k+397] | F(k)^F(k-227)^s[k+170] | F(k)^F(k-227)^F(k-454)^s[k-57],
+//             F(k) = twist(s[k], s[k+1])), so one workgroup produces a whole block per barrier: k8_mt_stream;
+//   resolve   c(t) = number of accepted draws before draw t obeys c(t+1) = c(t) + [ (d[t] & mask(i)) <= i ], i = n-1-c(t).
+//             Iterating c <- scan(flags(c)) from an analytic first guess converges to THE sequential solution (the correct
+//             prefix grows every round; in practice the error falls like (t/mask)^r / r!): a handful of device-wide scans;
+//   shuffle   the FINAL position of every value follows from the partners H[] alone.  Slot j is touched by the steps that
+//             target it, L_j = {i : H[i] = j} (all >= j), and by its own step j, which carries its content on to H[j]; after
+//             step j the slot is final.  So value v either is fetched by the first step that targets slot v before step v
+//             runs (max(L_v) > v: final position max(L_v)), or rides its own step to slot H[v], where the next smaller
+//             member of L_{H[v]} fetches it for good — or, if there is none, that slot's own step carries it one hop
+//             further, and so on (a hop survives with probability ~1/2: chains are a few hops long).  One stable radix sort
+//             of (H[i], i) lays every L_j out in order; "next smaller member" is then the neighbour in the sorted array.
+//
+// K6 wants exactly this INVERSE (shuffled position of the record with in-category rank v), so its former permutation
+// inversion — a 165 M-word random scatter, 64 % of K6 — disappears with the host loop.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "dyd_common.h"
+
+namespace dyd {
+
+constexpr int K8_MT_N = 624;
+constexpr int K8_MT_THREADS = 640;   // 10 waves, lanes 624..639 idle
+
+__device__ __forceinline__ uint32_t k8_twist(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t k8_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// out[0 .. n_blocks*624): the generator's outputs from the first draw on (numpy draws its first word after one refill of
+// the seeded state).  ONE workgroup: a block of 624 words per barrier.
+__global__ __launch_bounds__(K8_MT_THREADS) void k8_mt_stream(uint32_t seed, int64_t n_blocks, uint32_t *__restrict__ out) {
+    __shared__ uint32_t st[2][K8_MT_N];
+    const int k = threadIdx.x;
+    if (k == 0) {   // init_genrand
+        uint32_t s = seed;
+        st[0][0] = s;
+        for (int i = 1; i < K8_MT_N; ++i) {
+            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i;
+            st[0][i] = s;
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const uint32_t *s = st[cur];
+        uint32_t v = 0;
+        if (k < K8_MT_N) {
+            if (k < 227) {
+                v = k8_twist(s[k], s[k + 1]) ^ s[k + 397];
+            } else if (k < 454) {
+                v = k8_twist(s[k], s[k + 1]) ^ k8_twist(s[k - 227], s[k - 226]) ^ s[k + 170];
+            } else if (k < 623) {
+                v = k8_twist(s[k], s[k + 1]) ^ k8_twist(s[k - 227], s[k - 226]) ^ k8_twist(s[k - 454], s[k - 453]) ^ s[k - 57];
+            } else {   // k == 623 twists with the NEW word 0
+                const uint32_t n0 = k8_twist(s[0], s[1]) ^ s[397];
+                v = k8_twist(s[623], n0) ^ k8_twist(s[396], s[397]) ^ k8_twist(s[169], s[170]) ^ s[566];
+            }
+            st[cur ^ 1][k] = v;
+            out[b * K8_MT_N + k] = k8_temper(v);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__device__ __forceinline__ uint32_t k8_mask(uint32_t i) {   // smallest 2^k - 1 >= i
+    return i ? (0xffffffffu >> __builtin_clz(i)) : 0u;
+}
+
+// is draw t accepted, given that c draws before it were?  (steps still to do: i = n-1-c down to 1)
+struct K8Flag {
+    const uint32_t *d;
+    const uint32_t *c_prev;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t t) const {
+        const uint32_t c = c_prev[t];
+        if (c >= n - 1u) return 0u;
+        const uint32_t i = n - 1u - c;
+        return ((d[t] & k8_mask(i)) <= i) ? 1u : 0u;
+    }
+};
+
+// first guess of c(t): inside an octave of mask+1 = M the step index decays like i+1 ~ (i_s+1) exp(-(t-t_s)/M)
+struct K8Octaves {
+    int count;
+    double t_s[34], i_s1[34], m[34];   // octave k starts at draw t_s with i+1 = i_s1
+};
+__global__ __launch_bounds__(256) void k8_guess(K8Octaves oc, uint32_t n, int64_t n_draws, uint32_t *__restrict__ c0) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_draws) return;
+    int k = 0;
+    while (k + 1 < oc.count && (double)t >= oc.t_s[k + 1]) ++k;
+    double i1 = oc.i_s1[k] * exp(-((double)t - oc.t_s[k]) / oc.m[k]);
+    if (i1 < 1.0) i1 = 1.0;
+    double c = (double)n - i1;
+    if (c < 0.0) c = 0.0;
+    if (c > (double)(n - 1u)) c = (double)(n - 1u);
+    c0[t] = (uint32_t)c;
+}
+
+// first index in [lo, n) where the two count arrays differ (0xffffffff: none) — everything before it is final
+__global__ __launch_bounds__(256) void k8_first_diff(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int64_t lo, int64_t n,
+                                                     uint32_t *__restrict__ res) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    uint32_t first = 0xffffffffu;
+    for (int64_t t = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride)
+        if (a[t] != b[t]) { first = (uint32_t)t; break; }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_down((int)first, d);
+        first = o < first ? o : first;
+    }
+    if ((threadIdx.x & 63) == 0 && first != 0xffffffffu) atomicMin(res, first);
+}
+// res[1] = the (exact) count at that index: the next round's scan starts there
+__global__ void k8_pick(const uint32_t *__restrict__ c_new, uint32_t *__restrict__ res) {
+    if (threadIdx.x == 0) res[1] = (res[0] != 0xffffffffu) ? c_new[res[0]] : 0u;
+}
+
+// partners: key[i] = H[i] for the step every accepted draw belongs to; key[0] = 0 (step 0 does not exist: a no-op)
+__global__ __launch_bounds__(256) void k8_partners(const uint32_t *__restrict__ d, const uint32_t *__restrict__ c, uint32_t n,
+                                                   int64_t lo, int64_t hi, uint32_t *__restrict__ key) {
+    const int64_t t = lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) key[0] = 0u;
+    if (t >= hi) return;
+    const uint32_t ct = c[t];
+    if (ct >= n - 1u) return;
+    const uint32_t i = n - 1u - ct;
+    const uint32_t v = d[t] & k8_mask(i);
+    if (v <= i) key[i] = v;
+}
+
+// last[x] = the largest step that targets slot x (0xffffffff: none); pos[i] = where step i sits in the sorted order
+__global__ __launch_bounds__(256) void k8_last(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ is, uint32_t n,
+                                               uint32_t *__restrict__ last, uint32_t *__restrict__ pos) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t h = hs[k], i = is[k];
+    pos[i] = (uint32_t)k;
+    if (k + 1 == n || hs[k + 1] != h) last[h] = i;
+}
+
+// inv[v] = final position of value v (see the header); optionally perm[inv[v]] = v as int64
+__global__ __launch_bounds__(256) void k8_inverse(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ is,
+                                                  const uint32_t *__restrict__ last, const uint32_t *__restrict__ pos, uint32_t n,
+                                                  uint32_t *__restrict__ inv32, int64_t *__restrict__ inv64,
+                                                  int64_t *__restrict__ perm64) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t v = is[k];
+    const uint32_t lv = last[v];
+    uint32_t where;
+    if (lv != 0xffffffffu && lv > v) {
+        where = lv;                                   // fetched by the first step that targets slot v
+    } else {
+        uint32_t kk = (uint32_t)k;                    // v rides step T = is[kk] to slot hs[kk]
+        while (true) {
+            const uint32_t slot = hs[kk];
+            if (kk > 0 && hs[kk - 1] == slot) { where = is[kk - 1]; break; }   // the next smaller step targeting that slot
+            if (is[kk] == slot) { where = slot; break; }                      // H[T] == T: it never left
+            kk = pos[slot];                                                   // the slot's own step carries it on
+        }
+    }
+    if (inv32) inv32[v] = where;
+    if (inv64) inv64[v] = (int64_t)where;
+    if (perm64) perm64[where] = (int64_t)v;
+}
+
+__global__ __launch_bounds__(256) void k8_identity(uint32_t n, uint32_t *inv32, int64_t *inv64, int64_t *perm64) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    if (inv32) inv32[k] = (uint32_t)k;
+    if (inv64) inv64[k] = k;
+    if (perm64) perm64[k] = k;
+}
+
+// expected number of draws of a permutation of n (continuous model) and the octave table of the first guess
+static double expected_draws(uint32_t n, K8Octaves *oc) {
+    double t = 0.0;
+    int cnt = 0;
+    uint32_t i = n - 1;   // first step
+    while (i >= 1) {
+        uint32_t mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const double M = (double)mask + 1.0;
+        const uint32_t lo = (mask >> 1) + 1;   // the octave's last step: 2^(k-1)
+        if (oc && cnt < 34) { oc->t_s[cnt] = t; oc->i_s1[cnt] = (double)i + 1.0; oc->m[cnt] = M; ++cnt; }
+        t += M * log(((double)i + 1.5) / ((double)lo + 0.5));   // sum_{j=lo}^{i} M/(j+1)
+        if (lo <= 1) break;
+        i = lo - 1;
+    }
+    if (oc) oc->count = cnt;
+    return t;
+}
+
+struct PermScratch {
+    uint32_t *d = nullptr;          // tempered stream
+    int64_t n_draws = 0;            // words of d (multiple of 624)
+    uint32_t seed = 0;
+    bool valid = false;
+};
+
+// One permutation of n (2 <= n <= 2^30) from a stream that is already on the device.  Scratch layout inside `work`:
+// cA, cB [draws] | key, hs, is, last [n] | rocprim temp.  Returns DYD_ERR_RANGE when the stream was too short (caller
+// regenerates a longer one).
+static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) {
+    size_t scan_tmp = 0, sort_tmp = 0;
+    K8Flag f{nullptr, nullptr, n};
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), f);
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, in, (uint32_t *)nullptr, 0u, (size_t)draws, rocprim::plus<uint32_t>());
+    (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::make_counting_iterator<uint32_t>(0u),
+                                    (uint32_t *)nullptr, (size_t)n, 0u, 32u);
+    size_t tmp = scan_tmp > sort_tmp ? scan_tmp : sort_tmp;
+    tmp = (tmp + 255) & ~(size_t)255;
+    if (tmp_bytes_out) *tmp_bytes_out = tmp;
+    const size_t a = (((size_t)draws * 4) + 255) & ~(size_t)255, b = (((size_t)n * 4) + 255) & ~(size_t)255;
+    return 2 * a + 5 * b + tmp + 256;
+}
+
+static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n, void *work, uint32_t *inv32, int64_t *inv64,
+                            int64_t *perm64, hipStream_t st, int *rounds_out) {
+    K8Octaves oc;
+    const double e = expected_draws(n, &oc);
+    int64_t draws = (int64_t)(e * 1.002 + 8.0 * sqrt(2.0 * (double)n) + 4096.0);
+    if (draws > n_draws_avail) draws = n_draws_avail;
+    size_t tmp_bytes = 0;
+    (void)perm_work_bytes(n, draws, &tmp_bytes);
+    const size_t a = (((size_t)draws * 4) + 255) & ~(size_t)255, b = (((size_t)n * 4) + 255) & ~(size_t)255;
+    char *w = static_cast<char *>(work);
+    uint32_t *cA = reinterpret_cast<uint32_t *>(w), *cB = reinterpret_cast<uint32_t *>(w + a);
+    uint32_t *key = reinterpret_cast<uint32_t *>(w + 2 * a), *hs = reinterpret_cast<uint32_t *>(w + 2 * a + b);
+    uint32_t *is = reinterpret_cast<uint32_t *>(w + 2 * a + 2 * b), *last = reinterpret_cast<uint32_t *>(w + 2 * a + 3 * b);
+    uint32_t *pos = reinterpret_cast<uint32_t *>(w + 2 * a + 4 * b);
+    void *tmp = w + 2 * a + 5 * b;
+    uint32_t *res = reinterpret_cast<uint32_t *>(w + 2 * a + 5 * b + tmp_bytes);
+    const unsigned gn = (unsigned)ceil_div((int64_t)n, 256);
+
+    hipLaunchKernelGGL(k8_guess, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, oc, n, draws, cA);
+    DYD_HIP(hipGetLastError());
+    // Picard rounds over the not yet final suffix [lo, draws): cB[t] = c_lo + sum of flags(cA) on [lo, t).  Whatever lies before
+    // the first difference is final (its flags were computed from exact counts), so the partners of that stretch are written
+    // at once and the next round starts there.
+    int rounds = 0;
+    int64_t lo = 0;
+    uint32_t c_lo = 0;
+    while (lo < draws) {
+        K8Flag f{d, cA, n};
+        auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>((uint32_t)lo), f);
+        size_t tb = tmp_bytes;
+        DYD_HIP(rocprim::exclusive_scan(tmp, tb, in, cB + lo, c_lo, (size_t)(draws - lo), rocprim::plus<uint32_t>(), st));
+        DYD_HIP(hipMemsetAsync(res, 0xff, 4, st));
+        const int64_t span = draws - lo;
+        const unsigned gd = (unsigned)(ceil_div(span, 256) < 2048 ? ceil_div(span, 256) : 2048);
+        hipLaunchKernelGGL(k8_first_diff, dim3(gd), dim3(256), 0, st, cA, cB, lo, draws, res);
+        DYD_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k8_pick, dim3(1), dim3(64), 0, st, cB, res);
+        DYD_HIP(hipGetLastError());
+        uint32_t host[2] = {0, 0};
+        DYD_HIP(hipMemcpyAsync(host, res, 8, hipMemcpyDeviceToHost, st));
+        DYD_HIP(hipStreamSynchronize(st));
+        ++rounds;
+        const int64_t first = (host[0] == 0xffffffffu) ? draws : (int64_t)host[0];
+        if (first > lo) {   // cB is exact on [lo, first]: those draws' steps are known
+            hipLaunchKernelGGL(k8_partners, dim3((unsigned)ceil_div(first - lo, 256)), dim3(256), 0, st, d, cB, n, lo, first, key);
+            DYD_HIP(hipGetLastError());
+        }
+        if (first >= draws) break;
+        lo = first;
+        c_lo = host[1];
+        uint32_t *t2 = cA; cA = cB; cB = t2;   // cA = the newest counts (exact up to lo, the best guess beyond)
+        if (rounds > 100000) { set_error("K8: the rejection resolve did not settle"); return DYD_ERR_HIP; }
+    }
+    if (rounds_out) *rounds_out = rounds;
+    // enough draws?  the last draw's count (+ its own flag) must reach n-1 accepted  (cB holds the final counts of the tail)
+    uint32_t c_last = 0, d_last = 0;
+    DYD_HIP(hipMemcpyAsync(&c_last, cB + (draws - 1), 4, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(&d_last, d + (draws - 1), 4, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    {
+        uint32_t acc = c_last;
+        if (c_last < n - 1u) {
+            const uint32_t i = n - 1u - c_last;
+            uint32_t mask = i;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            if ((d_last & mask) <= i) ++acc;
+        }
+        if (acc < n - 1u) return DYD_ERR_RANGE;
+    }
+    unsigned bits = 1;
+    while (bits < 32 && (1ull << bits) < (unsigned long long)n) ++bits;
+    size_t tb = tmp_bytes;
+    DYD_HIP(rocprim::radix_sort_pairs(tmp, tb, key, hs, rocprim::make_counting_iterator<uint32_t>(0u), is, (size_t)n, 0u, bits, st));
+    DYD_HIP(hipMemsetAsync(last, 0xff, (size_t)n * 4, st));
+    hipLaunchKernelGGL(k8_last, dim3(gn), dim3(256), 0, st, hs, is, n, last, pos);
+    DYD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k8_inverse, dim3(gn), dim3(256), 0, st, hs, is, last, pos, n, inv32, inv64, perm64);
+    DYD_HIP(hipGetLastError());
+    return DYD_OK;
+}
+
+static int g_k8_last_rounds = 0;
+
+// permutations of several sizes from ONE seed (every category of the split is shuffled with the same random_state,
+// reference :800, so they share the stream).  inv32[c] / inv64[c] / perm64[c] may be null.
+int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *const *inv32, int64_t *const *inv64,
+                    int64_t *const *perm64, hipStream_t st) {
+    int64_t n_max = 0;
+    for (int c = 0; c < n_sizes; ++c) {
+        if (sizes[c] < 0 || sizes[c] > (1LL << 30)) { set_error("K8: permutation size %lld outside [0, 2^30]", (long long)sizes[c]); return DYD_ERR_RANGE; }
+        if (sizes[c] > n_max) n_max = sizes[c];
+    }
+    for (int c = 0; c < n_sizes; ++c)
+        if (sizes[c] <= 1 && sizes[c] > 0) {
+            hipLaunchKernelGGL(k8_identity, dim3(1), dim3(256), 0, st, (uint32_t)sizes[c], inv32 ? inv32[c] : nullptr,
+                               inv64 ? inv64[c] : nullptr, perm64 ? perm64[c] : nullptr);
+            DYD_HIP(hipGetLastError());
+        }
+    if (n_max <= 1) return DYD_OK;
+    double margin = 1.004;
+    for (int attempt = 0; attempt < 4; ++attempt, margin *= 1.5) {
+        const double e = expected_draws((uint32_t)n_max, nullptr);
+        int64_t draws = (int64_t)(e * margin + 16.0 * sqrt(2.0 * (double)n_max) + 8192.0);
+        const int64_t n_blocks = ceil_div(draws, K8_MT_N);
+        draws = n_blocks * K8_MT_N;
+        const size_t d_bytes = (((size_t)draws * 4) + 255) & ~(size_t)255;
+        size_t work = 0;
+        for (int c = 0; c < n_sizes; ++c)
+            if (sizes[c] > 1) {
+                const size_t wb = perm_work_bytes((uint32_t)sizes[c], draws, nullptr);
+                if (wb > work) work = wb;
+            }
+        void *scr = nullptr;
+        int rc = get_scratch(d_bytes + work, &scr, st);
+        if (rc) return rc;
+        uint32_t *d = static_cast<uint32_t *>(scr);
+        hipLaunchKernelGGL(k8_mt_stream, dim3(1), dim3(K8_MT_THREADS), 0, st, seed, n_blocks, d);
+        DYD_HIP(hipGetLastError());
+        bool short_stream = false;
+        for (int c = 0; c < n_sizes && !short_stream; ++c) {
+            if (sizes[c] <= 1) continue;
+            rc = perm_from_stream(d, draws, (uint32_t)sizes[c], static_cast<char *>(scr) + d_bytes, inv32 ? inv32[c] : nullptr,
+                                  inv64 ? inv64[c] : nullptr, perm64 ? perm64[c] : nullptr, st, &g_k8_last_rounds);
+            if (rc == DYD_ERR_RANGE) short_stream = true;
+            else if (rc) { release_scratch(st); return rc; }
+        }
+        release_scratch(st);
+        if (!short_stream) return DYD_OK;
+    }
+    set_error("K8: the generator stream stayed too short");
+    return DYD_ERR_HIP;
+}
+
+int k8_last_rounds() { return g_k8_last_rounds; }
+
+}  // namespace dyd
+
+using namespace dyd;
+
+extern "C" {
+
+int dyd_mt19937_permutation_dev(uint32_t seed, int64_t n, int64_t *out_perm_or_null, int64_t *out_inverse_or_null, void *stream) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0, "n < 0");
+    DYD_REQUIRE(n <= (1LL << 30), "n above 2^30: use dyd_mt19937_permutation");
+    if (n == 0 || (!out_perm_or_null && !out_inverse_or_null)) return DYD_OK;
+    int64_t *inv = out_inverse_or_null, *perm = out_perm_or_null;
+    return k8_permutations(seed, &n, 1, nullptr, &inv, &perm, pick_stream(stream));
+}
+
+}  // extern "C"

@@ -168,6 +168,23 @@ int dyd_split_ids_dev(const int32_t *cat, int64_t n, const int64_t *cat_perm_con
                       const int64_t *cat_off, const int64_t *n_train, const int64_t *n_val,
                       int32_t n_cat, uint8_t *out_split, int64_t *out_pos, void *stream);
 
+/* ---- K8: the permutation itself on the device ------------------------------------------------------------------
+ * numpy's legacy RandomState(seed).permutation(n) (what DataFrame.sample(frac=1, random_state=seed) shuffles with, :800) computed
+ * in parallel on the GPU, identical to dyd_mt19937_permutation element for element: MT19937 stream by one workgroup, the masked
+ * rejection resolved by iterated device-wide scans, the Fisher-Yates swap chain replaced by a closed form over one radix sort
+ * (csrc/k8_perm.hip).  out_perm[k] = the value at shuffled position k, out_inverse[v] = the shuffled position of value v; either
+ * may be NULL.  n <= 2^30.  Synchronous (it reads back a few words between rounds). */
+int dyd_mt19937_permutation_dev(uint32_t seed, int64_t n, int64_t *out_perm_or_null, int64_t *out_inverse_or_null, void *stream);
+/* K6 with the permutations made by K8 from `seed` (every category is shuffled with the same random_state, :800): no permutation
+ * array crosses the boundary and no inversion pass is needed (K8 yields the inverse K6 looks positions up in).  cat_sizes /
+ * n_train / n_val (and cat_rank_base for a shard, see dyd_split_ids_sharded_dev) are HOST arrays [n_cat]; cat / out_* as in
+ * dyd_split_ids (device pointers for _dev, host pointers otherwise).  Synchronous. */
+int dyd_split_ids_seeded(const int32_t *cat, int64_t n, uint32_t seed, const int64_t *cat_sizes, const int64_t *n_train,
+                         const int64_t *n_val, int32_t n_cat, uint8_t *out_split, int64_t *out_pos);
+int dyd_split_ids_seeded_dev(const int32_t *cat, int64_t n, uint32_t seed, const int64_t *cat_sizes_host, const int64_t *n_train_host,
+                             const int64_t *n_val_host, int32_t n_cat, const int64_t *cat_rank_base_host_or_null, uint8_t *out_split,
+                             int64_t *out_pos, void *stream);
+
 /* multi-GPU K6: the rank holds a contiguous shard of the expanded rows; cat_rank_base[c] = number
  * of rows of category c held by lower ranks (from one allgather of per-rank category counts),
  * cat_off / perm / n_train / n_val describe the GLOBAL categories. */
