@@ -388,7 +388,11 @@ int dyd_mt19937_permutation_dev(uint32_t seed, int64_t n, int64_t *out_perm_or_n
     DYD_REQUIRE(n <= (1LL << 30), "n above 2^30: use dyd_mt19937_permutation");
     if (n == 0 || (!out_perm_or_null && !out_inverse_or_null)) return DYD_OK;
     int64_t *inv = out_inverse_or_null, *perm = out_perm_or_null;
-    return k8_permutations(seed, &n, 1, nullptr, &inv, &perm, pick_stream(stream));
+    hipStream_t st = pick_stream(stream);
+    const int rc = k8_permutations(seed, &n, 1, nullptr, &inv, &perm, st);
+    if (rc) return rc;
+    DYD_HIP(hipStreamSynchronize(st));   // "synchronous": the caller may read the arrays on any stream
+    return DYD_OK;
 }
 
 }  // extern "C"

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 
 def test_device_permutation_golden(native):
     g = load_golden("perm_cases.json")
-    for case in g["permutations"]:
+    for case in g["perms"]:
         perm, inv = native.mt19937_permutation_device(case["seed"], case["n"], want_inverse=True)
-        assert perm.tolist() == case["perm"], (case["seed"], case["n"])
+        assert perm.tolist() == case["order"], (case["seed"], case["n"])
         assert np.array_equal(inv[perm], np.arange(case["n"]))
 
 
