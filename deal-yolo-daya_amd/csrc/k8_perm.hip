@@ -34,6 +34,9 @@
 
 #include "dyd_common.h"
 
+#define K8_JUMP_QUALIFIER __device__ const
+#include "k8_jump_table.h"
+
 namespace dyd {
 
 constexpr int K8_MT_N = 624;
@@ -51,37 +54,80 @@ __device__ __forceinline__ uint32_t k8_temper(uint32_t y) {
     return y;
 }
 
-// out[0 .. n_blocks*624): the generator's outputs from the first draw on (numpy draws its first word after one refill of
-// the seeded state).  ONE workgroup: a block of 624 words per barrier.
-__global__ __launch_bounds__(K8_MT_THREADS) void k8_mt_stream(uint32_t seed, int64_t n_blocks, uint32_t *__restrict__ out) {
+__device__ __forceinline__ uint32_t k8_untemper(uint32_t y) {
+    y ^= y >> 18;
+    y ^= (y << 15) & 0xefc60000u;
+    uint32_t t = y;
+    for (int r = 0; r < 4; ++r) t = y ^ ((t << 7) & 0x9d2c5680u);
+    y = t;
+    t = y;
+    for (int r = 0; r < 2; ++r) t = y ^ (t >> 11);
+    return t;
+}
+
+// One block step of the generator for the workgroup's thread k: the new state word from the OLD state (see the header).
+__device__ __forceinline__ uint32_t k8_next_word(const uint32_t *s, int k) {
+    if (k < 227) return k8_twist(s[k], s[k + 1]) ^ s[k + 397];
+    if (k < 454) return k8_twist(s[k], s[k + 1]) ^ k8_twist(s[k - 227], s[k - 226]) ^ s[k + 170];
+    if (k < 623) return k8_twist(s[k], s[k + 1]) ^ k8_twist(s[k - 227], s[k - 226]) ^ k8_twist(s[k - 454], s[k - 453]) ^ s[k - 57];
+    const uint32_t n0 = k8_twist(s[0], s[1]) ^ s[397];   // k == 623 twists with the NEW word 0
+    return k8_twist(s[623], n0) ^ k8_twist(s[396], s[397]) ^ k8_twist(s[169], s[170]) ^ s[566];
+}
+
+// raw word x[m] of the sequence: the seeded state for m < 624, else the untempered draw m - 624 (already generated)
+__device__ __forceinline__ uint32_t k8_raw(const uint32_t *__restrict__ seeded, const uint32_t *__restrict__ out, int64_t m) {
+    return m < K8_MT_N ? seeded[m] : k8_untemper(out[m - K8_MT_N]);
+}
+
+// The stream in parallel.  MT19937's raw words obey a linear recurrence over GF(2), so the state J words ahead is a fixed,
+// seed-independent XOR-combination of the words that follow the current state: x[J + k] = XOR_{i in g_J} x[i + k] with
+// g_J = x^J mod the characteristic polynomial (k8_jump_table.h, made by tools/make_mt_jump_table.py and checked there against
+// numpy).  Workgroup w of pass p therefore builds the state of chunk c = p*W + w directly — from the first 19937 + 624 words of
+// the sequence with g_{cJ} in pass 0, from the first words of chunk c - W with g_{WJ} afterwards — and generates its own
+// K8_JUMP_BLOCKS blocks, a block of 624 words per barrier.  `head` runs first, as one workgroup, to put those first words there.
+__global__ __launch_bounds__(K8_MT_THREADS) void k8_mt_stream(uint32_t seed, int pass, int head, int64_t total_blocks,
+                                                              uint32_t *__restrict__ seeded, uint32_t *__restrict__ out) {
     __shared__ uint32_t st[2][K8_MT_N];
     const int k = threadIdx.x;
-    if (k == 0) {   // init_genrand
-        uint32_t s = seed;
-        st[0][0] = s;
-        for (int i = 1; i < K8_MT_N; ++i) {
-            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i;
-            st[0][i] = s;
-        }
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int64_t b = 0; b < n_blocks; ++b) {
-        const uint32_t *s = st[cur];
-        uint32_t v = 0;
-        if (k < K8_MT_N) {
-            if (k < 227) {
-                v = k8_twist(s[k], s[k + 1]) ^ s[k + 397];
-            } else if (k < 454) {
-                v = k8_twist(s[k], s[k + 1]) ^ k8_twist(s[k - 227], s[k - 226]) ^ s[k + 170];
-            } else if (k < 623) {
-                v = k8_twist(s[k], s[k + 1]) ^ k8_twist(s[k - 227], s[k - 226]) ^ k8_twist(s[k - 454], s[k - 453]) ^ s[k - 57];
-            } else {   // k == 623 twists with the NEW word 0
-                const uint32_t n0 = k8_twist(s[0], s[1]) ^ s[397];
-                v = k8_twist(s[623], n0) ^ k8_twist(s[396], s[397]) ^ k8_twist(s[169], s[170]) ^ s[566];
+    const int64_t chunk = head ? 0 : (int64_t)pass * K8_JUMP_W + blockIdx.x;
+    const int64_t b0 = chunk * K8_JUMP_BLOCKS;                 // first block of the chunk
+    int64_t nb = head ? 33 : K8_JUMP_BLOCKS;                   // blocks to generate
+    if (b0 + nb > total_blocks) nb = total_blocks - b0;
+    if (nb <= 0) return;
+    if (chunk == 0) {
+        if (k == 0) {   // init_genrand
+            uint32_t s = seed;
+            st[0][0] = s;
+            for (int i = 1; i < K8_MT_N; ++i) {
+                s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i;
+                st[0][i] = s;
             }
+        }
+        __syncthreads();
+        if (head && k < K8_MT_N) seeded[k] = st[0][k];
+    } else {
+        const uint32_t *g = k8_jump_table[pass == 0 ? chunk - 1 : K8_JUMP_W - 1];
+        const int64_t base = (pass == 0 ? 0 : (chunk - K8_JUMP_W) * (int64_t)K8_JUMP_BLOCKS * K8_MT_N) + k;
+        uint32_t acc = 0;
+        if (k < K8_MT_N)
+            for (int wd = 0; wd < K8_MT_N; ++wd) {
+                uint32_t bits = g[wd];   // the same word for every lane
+                while (bits) {
+                    const int bit = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    acc ^= k8_raw(seeded, out, base + wd * 32 + bit);
+                }
+            }
+        if (k < K8_MT_N) st[0][k] = acc;
+        __syncthreads();
+    }
+    int cur = 0;
+    uint32_t *dst = out + b0 * K8_MT_N;
+    for (int64_t b = 0; b < nb; ++b) {
+        if (k < K8_MT_N) {
+            const uint32_t v = k8_next_word(st[cur], k);
             st[cur ^ 1][k] = v;
-            out[b * K8_MT_N + k] = k8_temper(v);
+            dst[b * K8_MT_N + k] = k8_temper(v);
         }
         __syncthreads();
         cur ^= 1;
@@ -346,7 +392,7 @@ int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *
         int64_t draws = (int64_t)(e * margin + 16.0 * sqrt(2.0 * (double)n_max) + 8192.0);
         const int64_t n_blocks = ceil_div(draws, K8_MT_N);
         draws = n_blocks * K8_MT_N;
-        const size_t d_bytes = (((size_t)draws * 4) + 255) & ~(size_t)255;
+        const size_t d_bytes = ((((size_t)draws * 4) + 255) & ~(size_t)255) + 4096;   // + the seeded state
         size_t work = 0;
         for (int c = 0; c < n_sizes; ++c)
             if (sizes[c] > 1) {
@@ -357,8 +403,17 @@ int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *
         int rc = get_scratch(d_bytes + work, &scr, st);
         if (rc) return rc;
         uint32_t *d = static_cast<uint32_t *>(scr);
-        hipLaunchKernelGGL(k8_mt_stream, dim3(1), dim3(K8_MT_THREADS), 0, st, seed, n_blocks, d);
+        uint32_t *seeded = reinterpret_cast<uint32_t *>(static_cast<char *>(scr) + d_bytes - 4096);   // 624 words behind the stream
+        // the first 33 blocks by one workgroup, then every pass of K8_JUMP_W chunks in parallel (a pass reads the one before)
+        hipLaunchKernelGGL(k8_mt_stream, dim3(1), dim3(K8_MT_THREADS), 0, st, seed, 0, 1, n_blocks, seeded, d);
         DYD_HIP(hipGetLastError());
+        const int64_t n_chunks = ceil_div(n_blocks, (int64_t)K8_JUMP_BLOCKS);
+        for (int64_t p = 0; p * K8_JUMP_W < n_chunks; ++p) {
+            const int64_t left = n_chunks - p * K8_JUMP_W;
+            hipLaunchKernelGGL(k8_mt_stream, dim3((unsigned)(left < K8_JUMP_W ? left : K8_JUMP_W)), dim3(K8_MT_THREADS), 0, st, seed, (int)p, 0,
+                               n_blocks, seeded, d);
+            DYD_HIP(hipGetLastError());
+        }
         bool short_stream = false;
         for (int c = 0; c < n_sizes && !short_stream; ++c) {
             if (sizes[c] <= 1) continue;
