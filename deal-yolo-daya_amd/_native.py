@@ -53,6 +53,7 @@ SIGNATURES = {
     "dyd_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dyd_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "dyd_sync": (C.c_int, [C.c_void_p]),
+    "dyd_device_status": (C.c_int, [C.c_void_p]),
     "dyd_last_kernel_ms": (C.c_double, []),
     "dyd_bbox_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dyd_bbox_minmax_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -46,6 +46,7 @@ ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference pr
 BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
 _CHUNK_CELLS = 1 << 18                               # cells flattened per device batch (Python path)
 LAST_IO_PATH = {}                                    # step -> "native" | "pandas": which CSV path the last call took
+VERIFY_EVENTS = []                                   # (step, column, detail): verify=True found a 128-bit hash collision
 _NATIVE_CHUNK_CELLS = 1 << 21                        # cells per native scan (2M rows ~ 0.26 G points at 124 pts/row)
 
 
@@ -170,6 +171,9 @@ def merge_all_csv_in_folder(
     total_bytes = sum(f.stat().st_size for f in csv_files)
     completed_bytes = 0
     LAST_IO_PATH["merge"] = {}
+    if _fc.enabled():
+        from .. import _native as _nat
+        _nat.load_library()            # a missing / unloadable library is a build problem: raise it here, not as 读取失败 per file
 
     for file_idx, csv_file in enumerate(csv_files, start=1):
         try:
@@ -211,8 +215,13 @@ def merge_all_csv_in_folder(
 
 
 # =============================================================================== a1  dedup
-def dedup_keep_mask(col: pd.Series, keep="first", backend=None) -> np.ndarray:
-    """Boolean keep-mask of ``drop_duplicates(keep=keep)`` on one key column: K3 hash, K4 mask."""
+def dedup_keep_mask(col: pd.Series, keep="first", backend=None, verify: bool = False) -> np.ndarray:
+    """Boolean keep-mask of ``drop_duplicates(keep=keep)`` on one key column: K3 hash, K4 mask.
+
+    Equality is equality of 128-bit hashes (MurmurHash3 x64_128 of the cell's canonical bytes; two different values collide
+    with probability ~1e-23 at 1e8 rows).  ``verify=True`` proves that none did: equal values always hash alike, so the hashes
+    are faithful iff there are exactly as many distinct hashes as distinct values (``Series.nunique``); if not, the mask is
+    recomputed by pandas' own value comparison and VERIFY_EVENTS records it."""
     if keep not in ("first", "last", False):
         raise ValueError('keep must be either "first", "last" or False')       # pandas' own message
     be = _backend(backend)
@@ -222,7 +231,13 @@ def dedup_keep_mask(col: pd.Series, keep="first", backend=None) -> np.ndarray:
     h = be.hash128(data, off)
     if na.any():
         h[na] = _fl.NA_KEY                              # all missing cells are one key (NaN == NaN)
-    return be.dedup(h, keep).astype(bool)
+    mask = be.dedup(h, keep).astype(bool)
+    if verify:
+        distinct_hashes = int(mask.sum()) if keep in ("first", "last") else int(be.dedup(h, "first").sum())
+        if distinct_hashes != int(col.nunique(dropna=False)):
+            VERIFY_EVENTS.append(("dedup", str(col.name), distinct_hashes))
+            mask = ~col.duplicated(keep=keep).to_numpy()
+    return mask
 
 
 def dedup_frame(df: pd.DataFrame, keep="first", backend=None) -> pd.DataFrame:
@@ -287,8 +302,11 @@ def deduplicate_csv_by_source(
 
 
 # =============================================================================== a2  reference filter
-def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None) -> np.ndarray:
-    """``main.astype(str).isin(set(ref.dropna().astype(str)))`` (:194-198): K3 on both, K5."""
+def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None, verify: bool = False) -> np.ndarray:
+    """``main.astype(str).isin(set(ref.dropna().astype(str)))`` (:194-198): K3 on both, K5.
+
+    ``verify=True``: a value of the reference set always hits (equal strings hash alike), so only a HIT can be wrong; the
+    hit rows are re-checked by value against the reference strings (pandas' isin on that subset)."""
     be = _backend(backend)
     if len(main_col) == 0:
         return np.zeros(0, bool)
@@ -296,7 +314,14 @@ def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None) -> np.nd
     rd, ro = _fl.column_str_bytes(ref_col, drop_na=True)
     hm = be.hash128(md, mo)
     hr = be.hash128(rd, ro) if len(ro) > 1 else np.zeros((0, 2), np.uint64)
-    return be.isin(hm, hr).astype(bool)
+    hit = be.isin(hm, hr).astype(bool)
+    if verify and hit.any():
+        rows = np.flatnonzero(hit)
+        true_hit = main_col.iloc[rows].astype(str).isin(set(ref_col.dropna().astype(str))).to_numpy()
+        if not true_hit.all():
+            VERIFY_EVENTS.append(("ref_filter", str(main_col.name), int((~true_hit).sum())))
+            hit[rows[~true_hit]] = False
+    return hit
 
 
 def ref_filter_frame(df_main: pd.DataFrame, df_ref: pd.DataFrame, compare_col: str = "source",

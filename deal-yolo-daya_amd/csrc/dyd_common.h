@@ -29,6 +29,9 @@ struct Context {
     size_t scratch_bytes = 0;
     hipEvent_t scratch_ev = nullptr;  // recorded after the last kernel that used the scratch
     bool scratch_used = false;
+    // one word on the device that kernels OR their failure bits into (K4: 1 = hash table full, 2 = an inserted key was not
+    // found again); host-pointer entry points read and clear it before they return, `_dev` callers ask dyd_device_status
+    int *dev_status = nullptr;
 };
 
 Context &ctx();
@@ -40,6 +43,8 @@ int ensure_init();
 // previous user of the scratch; call release_scratch(st) after the last launch that touches it.
 int get_scratch(size_t bytes, void **out, hipStream_t st);
 void release_scratch(hipStream_t st);
+// reads and clears the device status word after synchronising `st`; returns DYD_OK or DYD_ERR_HIP with the message set
+int take_device_status(hipStream_t st, const char *what);
 // `_dev` entry points launch on exactly the hipStream_t they are given (NULL = HIP's null stream,
 // which is also torch's default stream); the library's own stream serves the host-pointer calls.
 inline hipStream_t pick_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

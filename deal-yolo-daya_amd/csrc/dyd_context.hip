@@ -46,6 +46,7 @@ static int init_locked(int device) {
     if (c.ready) {  // rebinding to another device: drop the old context first
         (void)hipSetDevice(c.device);
         if (c.scratch) (void)hipFree(c.scratch);
+        if (c.dev_status) (void)hipFree(c.dev_status);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
         if (c.scratch_ev) (void)hipEventDestroy(c.scratch_ev);
@@ -67,6 +68,8 @@ static int init_locked(int device) {
     DYD_HIP(hipEventCreate(&c.ev0));
     DYD_HIP(hipEventCreate(&c.ev1));
     DYD_HIP(hipEventCreateWithFlags(&c.scratch_ev, hipEventDisableTiming));
+    DYD_HIP(hipMalloc(reinterpret_cast<void **>(&c.dev_status), 16));
+    DYD_HIP(hipMemset(c.dev_status, 0, 16));
     c.ready = true;
     return DYD_OK;
 }
@@ -112,11 +115,29 @@ int get_scratch(size_t bytes, void **out, hipStream_t st) {
     return DYD_OK;
 }
 
+int take_device_status(hipStream_t st, const char *what) {
+    Context &c = ctx();
+    int bits = 0;
+    DYD_HIP(hipMemcpyAsync(&bits, c.dev_status, 4, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    if (bits == 0) return DYD_OK;
+    DYD_HIP(hipMemsetAsync(c.dev_status, 0, 4, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    set_error("%s: device-side failure%s%s (status 0x%x) — the result must not be used", what,
+              (bits & 1) ? ", hash table full" : "", (bits & 2) ? ", an inserted key was not found again" : "", bits);
+    return DYD_ERR_HIP;
+}
+
 }  // namespace dyd
 
 using namespace dyd;
 
 extern "C" {
+
+int dyd_device_status(void *stream) {
+    DYD_API_ENTER();
+    return take_device_status(pick_stream(stream), "dyd_device_status");
+}
 
 int dyd_init(int device_or_minus1) {
     std::lock_guard<std::recursive_mutex> lock(api_mutex());
@@ -130,6 +151,7 @@ void dyd_shutdown(void) {
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     if (c.scratch) (void)hipFree(c.scratch);
+    if (c.dev_status) (void)hipFree(c.dev_status);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     if (c.scratch_ev) (void)hipEventDestroy(c.scratch_ev);

@@ -309,11 +309,16 @@ int dyd_csv_extract(dyd_csv *h, int32_t c, const uint8_t **bytes, const int64_t 
         cs.na.resize((size_t)n);
         int T = (int)std::min<int64_t>(std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency())), std::max<int64_t>(1, n / 2048));
         // pass 1: the unescaped length of every cell (a doubled quote inside a quoted field counts once)
+        int worker_oom = 0;
         auto run = [&](auto fn) {
-            if (T <= 1) { fn(0); return; }
+            auto guarded = [&](int t) {
+                try { fn(t); } catch (const std::bad_alloc &) { __atomic_store_n(&worker_oom, 1, __ATOMIC_RELAXED); }
+            };
+            if (T <= 1) { guarded(0); return; }
             std::vector<std::thread> th;
-            for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
+            for (int t = 0; t < T; ++t) th.emplace_back(guarded, t);
             for (auto &x : th) x.join();
+            if (worker_oom) throw std::bad_alloc();
         };
         std::vector<int64_t> part_bytes((size_t)T, 0);
         run([&](int t) {
@@ -478,7 +483,9 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
     if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n_out / 512));
     std::vector<std::string> parts((size_t)n_threads);
+    int oom = 0;   // a worker that runs out of memory must not end the process: report DYD_ERR_OOM after the join
     auto work = [&](int t) {
+      try {
         std::string &o = parts[(size_t)t];
         const int64_t lo = n_out * t / n_threads, hi = n_out * (t + 1) / n_threads;
         char nb[32];
@@ -500,7 +507,11 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
                         break;
                     case 2: {
                         const double v = static_cast<const double *>(col.data)[r];
-                        if (v == v) dyd_host::append_py_float_public(o, v);
+                        // a float cell is str(float): "inf" / "-inf" (json.dumps' "Infinity" spelling is for JSON text only)
+                        if (v == v) {
+                            if (std::isinf(v)) o += (v < 0 ? "-inf" : "inf");
+                            else dyd_host::append_py_float_public(o, v);
+                        }
                         break;
                     }
                     case 3:
@@ -512,6 +523,9 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
             if (n_cols == 1 && o.size() == mark) o += "\"\"";  // csv.writer: a lone empty field is written as ""
             o += '\n';
         }
+      } catch (const std::bad_alloc &) {
+        __atomic_store_n(&oom, 1, __ATOMIC_RELAXED);
+      }
     };
     try {
         if (n_threads <= 1) {
@@ -524,6 +538,7 @@ int dyd_csv_write(const char *path, const uint8_t *header, int64_t header_len, c
     } catch (const std::bad_alloc &) {
         return DYD_ERR_OOM;
     }
+    if (oom) return DYD_ERR_OOM;
     if (mode == 1) {  // used by the Python wrapper's self-check
         size_t total = (size_t)header_len;
         for (auto &s : parts) total += s.size();

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__re
                                                              const int32_t *__restrict__ box_off, int64_t n_rows,
                                                              int32_t min_boxes, double thr, double *out_box4,
                                                              int32_t *__restrict__ out_arg4,
-                                                             uint8_t *__restrict__ out_high) {
+                                                             uint8_t *__restrict__ out_high, unsigned long long *bigq) {
     using Slice = typename std::conditional<FILTER, WaveLdsF<WROWS, WCAP>, WaveLdsT<WROWS, WCAP>>::type;
     constexpr size_t kLds = sizeof(double2) * CHUNK > sizeof(Slice) * K2_WAVES ? sizeof(double2) * CHUNK
                                                                               : sizeof(Slice) * K2_WAVES;
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__re
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
     Slice *S = reinterpret_cast<Slice *>(s_raw);
     if constexpr (FILTER)
-        k2f_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
+        k2f_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave], bigq);
     else
-        k2_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave]);
+        k2_wave_rows<false, WROWS, WCAP>(out_box4, box_off, r0, nr, min_boxes, thr, out_high, nullptr, S[wave], bigq);
 }
 
 // wave-autonomous variant: boxes go from K1 to K2 through LDS, no workgroup barrier (k12_wave.h)
@@ -68,13 +68,13 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
                                                             const int32_t *__restrict__ box_off, int64_t n_rows,
                                                             int32_t min_boxes, double thr, double *out_box4,
                                                             int32_t *__restrict__ out_arg4,
-                                                            uint8_t *__restrict__ out_high) {
+                                                            uint8_t *__restrict__ out_high, unsigned long long *bigq) {
     __shared__ WaveFuse s_all[WPB];
     const int wave = threadIdx.x >> 6;
     const int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * KW_ROWS;
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
-    k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave]);
+    k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave], bigq);
 }
 
 // K2 alone with the wave kernel's pair stage: a wave owns 16 rows, walks them in tiles of whole rows with at most 64 boxes (one
@@ -83,13 +83,14 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
 // so tables with many of them stay with the tile kernels (launch_k2 decides by the mean).
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k2_wave64_kernel(const double *box4, const int32_t *__restrict__ box_off, int64_t n_rows,
-                                                             int32_t min_boxes, double thr, uint8_t *__restrict__ out_high) {
+                                                             int32_t min_boxes, double thr, uint8_t *__restrict__ out_high,
+                                                             unsigned long long *bigq) {
     __shared__ WaveFuse s_all[WPB];
     const int wave = threadIdx.x >> 6;
     const int64_t r0 = ((int64_t)blockIdx.x * WPB + wave) * KW_ROWS;
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
-    k12_wave_rows<true>(nullptr, nullptr, box_off, r0, nr, min_boxes, thr, const_cast<double *>(box4), nullptr, out_high, s_all[wave]);
+    k12_wave_rows<true>(nullptr, nullptr, box_off, r0, nr, min_boxes, thr, const_cast<double *>(box4), nullptr, out_high, s_all[wave], bigq);
 }
 
 // Chain semantics for the variants whose pair stage reads the boxes back from memory (workgroup tiles, the
@@ -153,13 +154,13 @@ static int launch_null_fix(const int32_t *arg4, const double *box4, const int32_
 }
 
 int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
-                     hipStream_t st) {
+                     unsigned long long *bigq, hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KW_ROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
         return DYD_ERR_RANGE;
     }
-    hipLaunchKernelGGL(k2_wave64_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, box4, row_off, n_rows, min_boxes, thr, out_high);
+    hipLaunchKernelGGL(k2_wave64_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, box4, row_off, n_rows, min_boxes, thr, out_high, bigq);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
@@ -167,7 +168,7 @@ int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows,
 template <int CHUNK, int WROWS, int WCAP, bool FILTER = false>
 static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
                         int32_t min_boxes, double thr, double *out_box4, int32_t *out_arg4, uint8_t *out_high,
-                        hipStream_t st) {
+                        unsigned long long *bigq, hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
@@ -175,7 +176,7 @@ static int launch_fused(const double *xy, const int32_t *pt_off, const int32_t *
     }
     hipLaunchKernelGGL((k12_fused_kernel<CHUNK, WROWS, WCAP, FILTER>), dim3((unsigned)blocks), dim3(K1_BLOCK), 0, st,
                        reinterpret_cast<const double2 *>(xy), pt_off, box_off, n_rows, min_boxes, thr, out_box4,
-                       out_arg4, out_high);
+                       out_arg4, out_high, bigq);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
@@ -184,11 +185,15 @@ int launch_k1(const double *xy, const int32_t *pt_off, int64_t n_boxes, int64_t 
               hipStream_t st);
 bool k1_wants_groups(int64_t n_boxes, int64_t n_points);
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above = 0x7fffffff, int64_t n_boxes = -1);
+              uint8_t *out_high, double *out_max, hipStream_t st, int64_t n_boxes = -1);
+int acquire_bigq(unsigned long long **q, hipStream_t st);
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, const unsigned long long *bigq, int32_t min_boxes, double thr,
+                       uint8_t *out_high, double *out_max, hipStream_t st);
 void set_k1_variant(int v);
 void set_k2_variant(int v);
 void set_k7_variant(int v);
 void set_k6_variant(int v);
+void set_k4_capacity_shift(int v);
 void set_k7_trace(void *p);
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
@@ -218,9 +223,15 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     if (g_fused_variant == 1 || (g_fused_variant < 0 && k1_wants_groups(n_boxes, n_points))) {
         int rc = launch_k1(xy, pt_off, n_boxes, n_points, out_box4, out_arg4, st);
         if (rc) return rc;
-        rc = launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st, 0x7fffffff, n_boxes);
+        rc = launch_k2(out_box4, box_off, n_rows, min_boxes, thr, out_high, nullptr, st, n_boxes);
         if (rc) return rc;
         return launch_null_fix(out_arg4, out_box4, box_off, n_rows, n_boxes, min_boxes, thr, out_high, st);
+    }
+    // rows of thousands of boxes are queued by the main kernel and paired by k2_big_rows_kernel behind it (k2_wave.h)
+    unsigned long long *bigq = nullptr;
+    {
+        const int rcq = acquire_bigq(&bigq, st);
+        if (rcq) return rcq;
     }
     int v = g_fused_variant;
     // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
@@ -237,27 +248,31 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         const double2 *xy2 = reinterpret_cast<const double2 *>(xy);
         if (wpb == 4)
             hipLaunchKernelGGL(k12_wave_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
-                               thr, out_box4, out_arg4, out_high);
+                               thr, out_box4, out_arg4, out_high, bigq);
         else if (wpb == 2)
             hipLaunchKernelGGL(k12_wave_kernel<2>, dim3((unsigned)blocks), dim3(128), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
-                               thr, out_box4, out_arg4, out_high);
+                               thr, out_box4, out_arg4, out_high, bigq);
         else
             hipLaunchKernelGGL(k12_wave_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
-                               thr, out_box4, out_arg4, out_high);
+                               thr, out_box4, out_arg4, out_high, bigq);
         DYD_HIP(hipGetLastError());
-        return DYD_OK;
+        const int rcb = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
+        release_scratch(st);
+        return rcb;
     }
     int rc;
     if (v == 5)
-        rc = launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+        rc = launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 6)
-        rc = launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+        rc = launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 2)
-        rc = launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+        rc = launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 3)
-        rc = launch_fused<1024, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+        rc = launch_fused<1024, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else
-        rc = launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, st);
+        rc = launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
+    if (!rc) rc = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
+    release_scratch(st);
     if (rc) return rc;
     return launch_null_fix(out_arg4, out_box4, box_off, n_rows, n_boxes, min_boxes, thr, out_high, st);
 }
@@ -313,6 +328,10 @@ int dyd_set_option(const char *key, int64_t value) {
     }
     if (!strcmp(key, "k6_variant")) {
         set_k6_variant((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "k4_capacity_shift")) {   // test hook: undersized hash table (the failure path must surface)
+        set_k4_capacity_shift((int)value);
         return DYD_OK;
     }
     if (!strcmp(key, "k7_variant")) {

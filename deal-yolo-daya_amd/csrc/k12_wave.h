@@ -84,7 +84,7 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                                               const int32_t *__restrict__ box_off, int64_t r0, int nr,
                                               int32_t min_boxes, double thr, double *out_box4,
                                               int32_t *__restrict__ out_arg4, uint8_t *__restrict__ out_high,
-                                              WaveFuse &S) {
+                                              WaveFuse &S, unsigned long long *bigq = nullptr) {
     const int lane = threadIdx.x & 63;
     int32_t my_off = 0;
     if (lane <= nr) {
@@ -117,6 +117,10 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                     if (em != 0ull && g + (__ffsll((long long)em) - 1) < n_eff) n_eff = g + (__ffsll((long long)em) - 1);
                 }
                 n = n_eff;  // the row's IoU list ends at its first empty polygon
+            }
+            if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // thousands of boxes: k2_big_rows_kernel pairs them (k2_wave.h)
+                ra += 1;
+                continue;
             }
             // this wave re-reads its own stores below: wait for them and drop any stale L1 lines
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

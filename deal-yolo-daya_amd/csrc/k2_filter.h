@@ -93,7 +93,7 @@ template <bool WANT_MAX, int WROWS, int WCAP>
 __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t *__restrict__ row_off, int64_t r0,
                                               int nr, int32_t min_boxes, double thr, uint8_t *__restrict__ out_high,
                                               double *__restrict__ out_max, WaveLdsF<WROWS, WCAP> &S,
-                                             int32_t skip_above = 0x7fffffff) {
+                                             unsigned long long *bigq = nullptr) {
     static_assert(WROWS < 63 && WCAP <= 65535, "rows map to lanes, box ids to 16 bits");
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t 
         if (taken == 0) {
             // ---- one row larger than the LDS tile: partner tiles of f32 boxes stream through LDS -----
             const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (n > skip_above) {   // a row of thousands of boxes: left to k2_big_rows_kernel, which spreads it over the grid
+            if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // left to k2_big_rows_kernel, which spreads it over the grid
                 ra += 1;
                 continue;
             }

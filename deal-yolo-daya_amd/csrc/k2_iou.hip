@@ -37,13 +37,13 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_iou_kernel(const double *__restri
                                                           const int32_t *__restrict__ row_off,
                                                           int64_t n_rows, int32_t min_boxes, double thr,
                                                           uint8_t *__restrict__ out_high,
-                                                          double *__restrict__ out_max, int32_t skip_above) {
+                                                          double *__restrict__ out_max, unsigned long long *bigq) {
     __shared__ WaveLdsT<WROWS, WCAP> s_all[K2_WAVES];
     const int wave = threadIdx.x >> 6;
     const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * WROWS;
     if (r0 >= n_rows) return;  // whole wave leaves; no workgroup barrier exists in this kernel
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
-    k2_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave], skip_above);
+    k2_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave], bigq);
 }
 
 // the same kernel with the f32 reject filter in front of the exact test (k2_filter.h)
@@ -52,18 +52,18 @@ __global__ __launch_bounds__(K2_BLOCK) void k2f_iou_kernel(const double *__restr
                                                            const int32_t *__restrict__ row_off,
                                                            int64_t n_rows, int32_t min_boxes, double thr,
                                                            uint8_t *__restrict__ out_high,
-                                                           double *__restrict__ out_max, int32_t skip_above) {
+                                                           double *__restrict__ out_max, unsigned long long *bigq) {
     __shared__ WaveLdsF<WROWS, WCAP> s_all[K2_WAVES];
     const int wave = threadIdx.x >> 6;
     const int64_t r0 = ((int64_t)blockIdx.x * K2_WAVES + wave) * WROWS;
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < WROWS) ? (int)(n_rows - r0) : WROWS;
-    k2f_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave], skip_above);
+    k2f_wave_rows<WANT_MAX, WROWS, WCAP>(box4, row_off, r0, nr, min_boxes, thr, out_high, out_max, s_all[wave], bigq);
 }
 
 template <int WROWS, int WCAP>
 static int launch_k2f_t(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-                        uint8_t *out_high, double *out_max, int32_t skip_above, hipStream_t st) {
+                        uint8_t *out_high, double *out_max, unsigned long long *bigq, hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
@@ -71,17 +71,17 @@ static int launch_k2f_t(const double *box4, const int32_t *row_off, int64_t n_ro
     }
     if (out_max)
         hipLaunchKernelGGL((k2f_iou_kernel<true, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, bigq);
     else
         hipLaunchKernelGGL((k2f_iou_kernel<false, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, bigq);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
 
 template <int WROWS, int WCAP>
 static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-                       uint8_t *out_high, double *out_max, int32_t skip_above, hipStream_t st) {
+                       uint8_t *out_high, double *out_max, unsigned long long *bigq, hipStream_t st) {
     const int64_t blocks = ceil_div(n_rows, (int64_t)K2_WAVES * WROWS);
     if (blocks > 0x7fffffffLL) {
         set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
@@ -89,10 +89,10 @@ static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_row
     }
     if (out_max)
         hipLaunchKernelGGL((k2_iou_kernel<true, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, bigq);
     else
         hipLaunchKernelGGL((k2_iou_kernel<false, WROWS, WCAP>), dim3((unsigned)blocks), dim3(K2_BLOCK), 0, st, box4,
-                           row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above);
+                           row_off, n_rows, min_boxes, thr, out_high, out_max, bigq);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
@@ -104,31 +104,50 @@ static int g_k2_variant = -1;
 void set_k2_variant(int v) { g_k2_variant = v; }
 
 int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
-                     hipStream_t st);   // k12_fused.hip
+                     unsigned long long *bigq, hipStream_t st);   // k12_fused.hip
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, const unsigned long long *bigq, int32_t min_boxes, double thr,
+                       uint8_t *out_high, double *out_max, hipStream_t st);
 
+// the pair stage alone: main kernel (rows of thousands of boxes go to `bigq`) — the caller launches k2_big_rows behind it
+static int launch_k2_main(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
+                          uint8_t *out_high, double *out_max, hipStream_t st, unsigned long long *bigq, int64_t n_boxes) {
+    // sparse tables (at most 32 boxes per image on average, no diagnostic maximum): the wave kernel's pair stage
+    if ((g_k2_variant < 0 || g_k2_variant == 4) && !out_max && (g_k2_variant == 4 || (n_boxes >= 0 && n_boxes <= 32 * n_rows)))
+        return launch_k2_wave64(box4, row_off, n_rows, min_boxes, thr, out_high, bigq, st);
+    if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
+    if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
+    if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
+    return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
+}
+
+// a queue for the rows of thousands of boxes, from the context's scratch (the caller releases the scratch after its last launch)
+int acquire_bigq(unsigned long long **q, hipStream_t st) {
+    void *scr = nullptr;
+    int rc = get_scratch(K2_BIGQ_BYTES, &scr, st);
+    if (rc) return rc;
+    *q = static_cast<unsigned long long *>(scr);
+    DYD_HIP(hipMemsetAsync(scr, 0, 8, st));
+    return DYD_OK;
+}
+
+// K2 over device arrays: main kernel, then the queued big rows spread over the grid
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
-              uint8_t *out_high, double *out_max, hipStream_t st, int32_t skip_above, int64_t n_boxes) {
+              uint8_t *out_high, double *out_max, hipStream_t st, int64_t n_boxes) {
     if (n_rows == 0) return DYD_OK;
-    // sparse tables (at most 32 boxes per image on average, no diagnostic maximum, no rows handed to the big-row kernel): the
-    // wave kernel's pair stage
-    if ((g_k2_variant < 0 || g_k2_variant == 4) && !out_max && skip_above == 0x7fffffff &&
-        (g_k2_variant == 4 || (n_boxes >= 0 && n_boxes <= 32 * n_rows)))
-        return launch_k2_wave64(box4, row_off, n_rows, min_boxes, thr, out_high, st);
-    if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
-    if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
-    if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
-    return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, skip_above, st);
+    unsigned long long *q = nullptr;
+    int rc = acquire_bigq(&q, st);
+    if (rc) return rc;
+    rc = launch_k2_main(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st, q, n_boxes);
+    if (!rc) rc = launch_k2_big_rows(box4, row_off, q, min_boxes, thr, out_high, out_max, st);
+    release_scratch(st);
+    return rc;
 }
 
 // ---- rows of thousands of boxes ---------------------------------------------------------------------------------
-// The tile kernels keep a row on ONE wave: 1000 boxes take 1.4 ms there, 10 000 boxes 120 ms, 50 000 boxes 3 s
-// (tools/bigrow_probe.py).  The host entry point therefore hands rows of more than K2_BIG_ROW boxes (when there are few of them) to this kernel (the
-// tile kernel skips them): a row's pairs are cut into items of 64 boxes x K2_BIG_CHUNK partners, the items of all big rows are
-// numbered in one sequence, and wave w of the grid takes the items w, w + W, ...  Within an item lane l holds box i0 + l and
-// meets the partners j > i of its chunk, 64 at a time through LDS, always as (lower index, higher index) — the reference's
-// argument order, so rows with NaN corners need no special path.
-constexpr int32_t K2_BIG_ROW = 256;      // rows above this many boxes (the tile kernels hold 128 / 256 per tile)
-constexpr int32_t K2_BIG_LIST = 2048;    // at most this many of them
+// The rows the main kernel queued (k2_wave.h): a row's pairs are cut into items of 64 boxes x K2_BIG_CHUNK partners, the items of
+// all queued rows are numbered in one sequence, and wave w of the grid takes the items w, w + W, ...  Within an item lane l holds
+// box i0 + l and meets the partners j > i of its chunk, 64 at a time through LDS, always as (lower index, higher index) — the
+// reference's argument order, so rows with NaN corners need no special path.  An empty queue costs one load per wave.
 constexpr int32_t K2_BIG_CHUNK = 4096;
 
 struct alignas(16) BigRowLds {
@@ -138,7 +157,7 @@ struct alignas(16) BigRowLds {
 template <bool WANT_MAX>
 __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__restrict__ box4,
                                                                const int32_t *__restrict__ row_off,
-                                                               const int64_t *__restrict__ big_rows, int32_t n_big,
+                                                               const unsigned long long *__restrict__ bigq,
                                                                int32_t min_boxes, double thr,
                                                                uint8_t *__restrict__ out_high,
                                                                unsigned long long *__restrict__ out_max_bits) {
@@ -149,10 +168,12 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
     const bool zero_hits = (0.0 >= thr);
     const double thr_lo = (thr > 0.0) ? thr * 0.999 : 0.0;
     int64_t item = 0;   // running number of the items, the same in every wave
+    const unsigned long long pushed = bigq[0];
+    const int32_t n_big = pushed < (unsigned long long)K2_BIG_LIST ? (int32_t)pushed : K2_BIG_LIST;
     for (int32_t k = 0; k < n_big; ++k) {
-        const int64_t r = big_rows[k];
+        const int64_t r = (int64_t)bigq[1 + 2 * k];
         const int64_t base = row_off[r];
-        const int32_t n = (int32_t)(row_off[r + 1] - base);
+        const int32_t n = (int32_t)bigq[2 + 2 * k];   // boxes to pair: the row's, or its prefix before an empty polygon (fused path)
         if (!WANT_MAX && n < min_boxes) continue;
         bool hit = false;
         double mx = 0.0;
@@ -204,15 +225,14 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
     }
 }
 
-int launch_k2_big_rows(const double *box4, const int32_t *row_off, const int64_t *big_rows, int32_t n_big, int32_t min_boxes,
-                       double thr, uint8_t *out_high, double *out_max, hipStream_t st) {
-    if (n_big == 0) return DYD_OK;
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, const unsigned long long *bigq, int32_t min_boxes, double thr,
+                       uint8_t *out_high, double *out_max, hipStream_t st) {
     const unsigned blocks = (unsigned)ctx().num_cu * 4;   // 16 waves per CU, striding over the items
     if (out_max)
-        hipLaunchKernelGGL(k2_big_rows_kernel<true>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, big_rows, n_big, min_boxes, thr,
+        hipLaunchKernelGGL(k2_big_rows_kernel<true>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, bigq, min_boxes, thr,
                            out_high, reinterpret_cast<unsigned long long *>(out_max));
     else
-        hipLaunchKernelGGL(k2_big_rows_kernel<false>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, big_rows, n_big, min_boxes, thr,
+        hipLaunchKernelGGL(k2_big_rows_kernel<false>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, bigq, min_boxes, thr,
                            out_high, (unsigned long long *)nullptr);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
@@ -231,7 +251,7 @@ int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_row
     if (n_rows == 0) return DYD_OK;
     DYD_REQUIRE(row_off && out_high, "null pointer");
     DYD_REQUIRE((reinterpret_cast<uintptr_t>(box4) & 15) == 0, "box4 must be 16-byte aligned");
-    return launch_k2(box4, row_off, n_rows, min_boxes, thr, out_high, out_max_iou_or_null, pick_stream(stream), 0x7fffffff, n_boxes);
+    return launch_k2(box4, row_off, n_rows, min_boxes, thr, out_high, out_max_iou_or_null, pick_stream(stream), n_boxes);
 }
 
 int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
@@ -253,30 +273,9 @@ int dyd_iou_any_ge(const double *box4, const int32_t *row_off, int64_t n_rows, i
     hipStream_t st = ctx().stream;
     if (nb) DYD_HIP(hipMemcpyAsync(d_box.p, box4, 32 * (size_t)nb, hipMemcpyHostToDevice, st));
     DYD_HIP(hipMemcpyAsync(d_off.p, row_off, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice, st));
-    // rows of thousands of boxes go to their own kernel, which spreads each of them over the grid
-    // (every wave of that kernel walks the whole list, so the list is kept short: when a table has thousands of such rows
-    // the threshold doubles until at most K2_BIG_LIST are left — many big rows keep the tile kernel's waves busy anyway)
-    int32_t big_above = K2_BIG_ROW;
-    std::vector<int64_t> big;
-    while (true) {
-        big.clear();
-        for (int64_t i = 0; i < n_rows && (int64_t)big.size() <= K2_BIG_LIST; ++i)
-            if (row_off[i + 1] - row_off[i] > big_above) big.push_back(i);
-        if ((int64_t)big.size() <= K2_BIG_LIST || big_above > (1 << 29)) break;
-        big_above *= 2;
-    }
-    if ((int64_t)big.size() > K2_BIG_LIST) big.clear();
-    DevBuf d_big;
-    if (!big.empty()) {
-        if ((rc = d_big.alloc(8 * big.size()))) return rc;
-        DYD_HIP(hipMemcpyAsync(d_big.p, big.data(), 8 * big.size(), hipMemcpyHostToDevice, st));
-    }
     KernelTimer t(st);
     rc = launch_k2(d_box.as<double>(), d_off.as<int32_t>(), n_rows, min_boxes, thr, d_high.as<uint8_t>(),
-                   out_max_iou_or_null ? d_max.as<double>() : nullptr, st, big.empty() ? 0x7fffffff : big_above, nb);
-    if (rc) return rc;
-    rc = launch_k2_big_rows(d_box.as<double>(), d_off.as<int32_t>(), d_big.as<int64_t>(), (int32_t)big.size(), min_boxes, thr,
-                            d_high.as<uint8_t>(), out_max_iou_or_null ? d_max.as<double>() : nullptr, st);
+                   out_max_iou_or_null ? d_max.as<double>() : nullptr, st, nb);
     if (rc) return rc;
     t.finish();
     DYD_HIP(hipMemcpyAsync(out_high, d_high.p, (size_t)n_rows, hipMemcpyDeviceToHost, st));

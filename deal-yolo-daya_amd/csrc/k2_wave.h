@@ -16,6 +16,29 @@ struct Corners {
     double x1, y1, x2, y2;
 };
 
+// Rows of thousands of boxes.  The tile kernels keep a row on ONE wave: 1000 boxes take 1.4 ms there, 10 000 boxes 120 ms,
+// 50 000 boxes 3 s.  A wave that meets a row of more than K2_BIG_ROW boxes therefore pushes it onto a small queue in device
+// memory — q[0] = number of pushes, then (row, boxes to pair) per entry — and moves on; k2_big_rows_kernel, launched behind the
+// main kernel on the same stream, spreads every queued row over the whole grid.  When the queue is full (K2_BIG_LIST rows) the
+// row stays with its wave as before: a table with thousands of such rows keeps the tile kernel's waves busy anyway.
+constexpr int32_t K2_BIG_ROW = 256;      // rows above this many boxes (the tile kernels hold 128 / 256 per tile)
+constexpr int32_t K2_BIG_LIST = 2048;    // queue capacity
+constexpr size_t K2_BIGQ_BYTES = 8 * (1 + 2 * (size_t)K2_BIG_LIST);
+
+__device__ __forceinline__ bool bigq_push(unsigned long long *q, int64_t row, int32_t n) {   // wave-uniform call
+    if (!q) return false;
+    unsigned long long idx = 0;
+    if ((threadIdx.x & 63) == 0) idx = atomicAdd(&q[0], 1ull);
+    idx = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(idx >> 32)) << 32) |
+          (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+    if (idx >= (unsigned long long)K2_BIG_LIST) return false;
+    if ((threadIdx.x & 63) == 0) {
+        q[1 + 2 * idx] = (unsigned long long)row;
+        q[2 + 2 * idx] = (unsigned long long)(unsigned)n;
+    }
+    return true;
+}
+
 // per-wave LDS slice: WROWS image rows, at most WCAP boxes staged at a time
 template <int WROWS, int WCAP>
 struct alignas(16) WaveLdsT {
@@ -125,7 +148,7 @@ template <bool WANT_MAX, int WROWS = K2_WROWS, int WCAP = K2_WCAP>
 __device__ __forceinline__ void k2_wave_rows(const double *box4, const int32_t *__restrict__ row_off, int64_t r0,
                                              int nr, int32_t min_boxes, double thr, uint8_t *__restrict__ out_high,
                                              double *__restrict__ out_max, WaveLdsT<WROWS, WCAP> &S,
-                                             int32_t skip_above = 0x7fffffff) {
+                                             unsigned long long *bigq = nullptr) {
     static_assert(WROWS < 63 && WCAP <= 65535, "rows map to lanes, box ids to 16 bits");
     const int lane = threadIdx.x & 63;
     // lane L (L <= nr) keeps row_off[r0 + L] in a register and in LDS
@@ -154,7 +177,7 @@ __device__ __forceinline__ void k2_wave_rows(const double *box4, const int32_t *
         if (taken == 0) {
             // ---- one row larger than the LDS tile: stream partner tiles through LDS ----------
             const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (n > skip_above) {   // a row of thousands of boxes: left to k2_big_rows_kernel, which spreads it over the grid
+            if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // left to k2_big_rows_kernel, which spreads it over the grid
                 ra += 1;
                 continue;
             }

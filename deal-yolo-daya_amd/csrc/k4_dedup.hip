@@ -67,7 +67,7 @@ __global__ __launch_bounds__(K4_BLOCK) void k4_insert(const ulonglong2 *__restri
             }
             slot = (slot + 1) & mask;
         }
-        if (!placed) *err = 1;  // table full: cannot happen with capacity >= 2n
+        if (!placed) atomicOr(err, 1);  // table full: cannot happen with capacity >= 2n
     }
     // fold the lanes that share a slot (row indices grow with the lane: the lowest / highest lane of a group holds its min / max)
     unsigned long long todo = __ballot(update);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(K4_BLOCK) void k4_resolve(const ulonglong2 *__restr
         slot = (slot + 1) & mask;
     }
     out_keep[t] = 0;
-    *err = 2;  // a key that was inserted must be found
+    atomicOr(err, 2);  // a key that was inserted must be found
 }
 
 __global__ __launch_bounds__(K4_BLOCK) void k5_probe(const ulonglong2 *__restrict__ keys, int64_t n,
@@ -149,13 +149,19 @@ __global__ __launch_bounds__(K4_BLOCK) void k5_probe(const ulonglong2 *__restric
     out_mask[i] = found;
 }
 
+// dyd_set_option("k4_capacity_shift", k): the table is made 2^k times SMALLER than it should be — only so that a test can
+// watch the failure path (a full table must surface as an error, never as a wrong mask)
+static int g_k4_capacity_shift = 0;
+void set_k4_capacity_shift(int v) { g_k4_capacity_shift = v < 0 ? 0 : v; }
+
 static uint64_t table_capacity(int64_t n) {
     uint64_t cap = 1024;
     while (cap < 2 * (uint64_t)n) cap <<= 1;
-    return cap;
+    cap >>= g_k4_capacity_shift;
+    return cap < 2 ? 2 : cap;
 }
 
-// scratch layout: [tab: cap x i64][cnt: cap x u32][err: 16 B]
+// scratch layout: [tab: cap x i64][cnt: cap x u32]; failures go to the context's device status word
 static int dedup_launch(const uint64_t *h, int64_t n_all, int64_t first, int64_t n_local, int keep_mode,
                         uint8_t *out_keep, hipStream_t st) {
     const uint64_t cap = table_capacity(n_all);
@@ -165,9 +171,9 @@ static int dedup_launch(const uint64_t *h, int64_t n_all, int64_t first, int64_t
     if (rc) return rc;
     long long *tab = static_cast<long long *>(scr);
     unsigned int *cnt = reinterpret_cast<unsigned int *>(static_cast<char *>(scr) + tab_bytes);
-    int *err = reinterpret_cast<int *>(static_cast<char *>(scr) + tab_bytes + cnt_bytes);
+    int *err = ctx().dev_status;
     DYD_HIP(hipMemsetAsync(tab, 0xFF, tab_bytes, st));
-    DYD_HIP(hipMemsetAsync(cnt, 0, cnt_bytes + 16, st));
+    if (cnt_bytes) DYD_HIP(hipMemsetAsync(cnt, 0, cnt_bytes, st));
     const ulonglong2 *keys = reinterpret_cast<const ulonglong2 *>(h);
     hipLaunchKernelGGL(k4_insert, dim3((unsigned)ceil_div(n_all, K4_BLOCK)), dim3(K4_BLOCK), 0, st, keys, n_all,
                        tab, cnt, cap - 1, keep_mode, err);
@@ -193,9 +199,8 @@ static int isin_launch(const uint64_t *h, int64_t n, const uint64_t *ref_h, int6
     int rc = get_scratch(cap * 8 + 16, &scr, st);
     if (rc) return rc;
     long long *tab = static_cast<long long *>(scr);
-    int *err = reinterpret_cast<int *>(static_cast<char *>(scr) + cap * 8);
+    int *err = ctx().dev_status;
     DYD_HIP(hipMemsetAsync(tab, 0xFF, cap * 8, st));
-    DYD_HIP(hipMemsetAsync(err, 0, 16, st));
     const ulonglong2 *rk = reinterpret_cast<const ulonglong2 *>(ref_h);
     hipLaunchKernelGGL(k4_insert, dim3((unsigned)ceil_div(r, K4_BLOCK)), dim3(K4_BLOCK), 0, st, rk, r, tab,
                        (unsigned int *)nullptr, cap - 1, DYD_KEEP_FIRST, err);
@@ -258,8 +263,7 @@ int dyd_dedup(const uint64_t *h, int64_t n, int keep_mode, uint8_t *out_keep) {
     if (rc) return rc;
     t.finish();
     DYD_HIP(hipMemcpyAsync(out_keep, d_keep.p, (size_t)n, hipMemcpyDeviceToHost, st));
-    DYD_HIP(hipStreamSynchronize(st));
-    return DYD_OK;
+    return take_device_status(st, "dyd_dedup");
 }
 
 int dyd_isin_dev(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, uint8_t *out_mask, void *stream) {
@@ -289,8 +293,7 @@ int dyd_isin(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, uin
     if (rc) return rc;
     t.finish();
     DYD_HIP(hipMemcpyAsync(out_mask, d_m.p, (size_t)n, hipMemcpyDeviceToHost, st));
-    DYD_HIP(hipStreamSynchronize(st));
-    return DYD_OK;
+    return take_device_status(st, "dyd_isin");
 }
 
 }  // extern "C"

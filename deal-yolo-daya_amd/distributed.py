@@ -109,7 +109,7 @@ class HipOps:
         flag = torch.zeros(max(n, 1), dtype=torch.uint8, device=self.device)[:n]
         total = C.c_int64()
         args = (box4.data_ptr(), row_off.data_ptr(), sel.data_ptr() if sel is not None else None, width.data_ptr(),
-                height.data_ptr(), class_id.data_ptr(), n, int(box4.shape[0]), toff.data_ptr(), flag.data_ptr())
+                height.data_ptr(), class_id.data_ptr(), n, int(box4.numel()) // 4, toff.data_ptr(), flag.data_ptr())   # box4 may come flat
         self.native.check(self.L.dyd_yolo_lines_dev(*args, None, 0, C.byref(total), self._stream()), "dyd_yolo_lines_dev")
         text = torch.empty(max(total.value, 1), dtype=torch.uint8, device=self.device)
         if total.value:

@@ -256,20 +256,45 @@ def column_key_bytes(col: pd.Series) -> tuple:
         v[na] = 0.0
         raw = np.ascontiguousarray(v).view(np.uint8)
         return raw, np.arange(len(col) + 1, dtype=np.int64) * 8, na
+    # object column.  The usual case — every present cell is a str (URLs) — needs no per-cell Python: pyarrow walks the
+    # objects in C and hands back the flat utf-8 buffer (missing cells come out empty; the caller gives them NA_KEY).
+    try:
+        import pyarrow as pa
+        arr = pa.array(col.to_numpy(), type=pa.large_string(), from_pandas=True)
+        bufs = arr.buffers()
+        off = np.frombuffer(bufs[1], dtype=np.int64, count=len(arr) + 1)
+        data = np.frombuffer(bufs[2], dtype=np.uint8, count=int(off[-1])) if bufs[2] is not None else np.zeros(0, np.uint8)
+        return data, off, na
+    except ImportError:
+        pass
+    except Exception:  # noqa: BLE001 - pa.ArrowInvalid / ArrowTypeError: some cell is not a str -> the tagged spelling below
+        pass
+    # Mixed column.  A str keeps its plain utf-8 bytes (the same key as on the fast path above — shards of one table must
+    # agree); every other value is tagged with a 0xFF byte, which no utf-8 text contains, so "1.0" the string and 1.0 the
+    # number stay apart.
     vals = col.tolist()
-    texts = []
+    plain = all(m or type(v) is str or isinstance(v, (bool, int, float)) for v, m in zip(vals, na.tolist()))
+    ids = {}                 # any other hashable: one id per equality class, by Python's own hash / == (what pandas' object
+    cells = []               # table uses, so 1 == 1.0 == Decimal(1) fall together); an unhashable cell raises TypeError like pandas
     for v, missing in zip(vals, na.tolist()):
         if missing:
-            texts.append("")
+            cells.append(b"")
         elif type(v) is str:
-            texts.append("s" + v)
-        elif isinstance(v, (bool, int, float)):
-            # 1 == 1.0 == True hash alike in pandas' object table
-            texts.append("n" + repr(float(v)) if not (isinstance(v, int) and abs(v) > 2 ** 53) else "i" + repr(int(v)))
+            cells.append(v.encode("utf-8"))
+        elif plain:
+            # 1 == 1.0 == True hash alike in pandas' object table; an int that no float equals keeps its own spelling
+            try:
+                as_float = float(v)
+                exact = not isinstance(v, int) or int(as_float) == v
+            except OverflowError:
+                exact = False
+            cells.append((b"\xffn" + repr(as_float).encode()) if exact else (b"\xffi" + repr(int(v)).encode()))
         else:
-            raise NotImplementedError(f"unsupported key type {type(v).__name__} in column {col.name!r}")
-    data, off = _strings_to_bytes(texts)
-    return data, off, na
+            cells.append(b"\xffo%d" % ids.setdefault(v, len(ids)))
+    off = np.zeros(len(cells) + 1, np.int64)
+    np.cumsum([len(c) for c in cells], out=off[1:])
+    blob = b"".join(cells)
+    return (np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(0, np.uint8)), off, na
 
 
 def column_str_bytes(col: pd.Series, drop_na: bool = False) -> tuple:

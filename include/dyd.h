@@ -61,6 +61,10 @@ int dyd_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int dyd_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int dyd_memset(void *dst_dev, int byte, size_t bytes);
 int dyd_sync(void *stream);
+/* Device-side failures (K4 / K5: hash table full, an inserted key not found again) are recorded in one status word on the device.
+ * Host-pointer entry points check it themselves and return DYD_ERR_HIP; a caller of the asynchronous `_dev` twins asks here once its
+ * launches are queued: synchronises `stream`, returns DYD_OK or DYD_ERR_HIP (message in dyd_last_error) and clears the word. */
+int dyd_device_status(void *stream);
 /* elapsed ms of the kernels launched by the calling thread's most recent non-_dev
  * entry point (hipEvent pair around the kernel launches only, staging excluded) */
 double dyd_last_kernel_ms(void);

@@ -258,3 +258,21 @@ def test_steps_on_a_crlf_file_write_what_the_pandas_path_writes(oracle_backend, 
             assert P.LAST_IO_PATH["replace"] == "native" and P.LAST_IO_PATH["dedup"] == "native"
         outs[mode] = [open(Q(n), "rb").read() for n in ("dedup", "proc", "exc")]
     assert outs["1"] == outs["0"]
+
+
+def test_writer_non_finite_floats_like_pandas(tmp_path):
+    """str(float) cells: inf / -inf / exponent spellings in the MIDDLE of a column (beyond the rows write_table samples)"""
+    n = 400
+    vals = np.linspace(0.5, 99.5, n)
+    vals[100], vals[150], vals[200], vals[250], vals[300] = np.inf, -np.inf, 1e16, 1e-7, np.nan
+    vals[110], vals[111] = 123456789012345680.0, -0.0
+    df = pd.DataFrame({"source": [f"s{i}" for i in range(n)], "v": vals, "k": np.arange(n)})
+    want = df.to_csv(index=False).encode("utf-8")
+    out = str(tmp_path / "o.csv")
+    assert fastcsv.write_table(out, list(df.columns), [df[c] for c in df.columns], n, encoding="utf-8")
+    with open(out, "rb") as f:
+        assert f.read() == want
+    rows = np.array([300, 100, 150, 3, 200, 250, 110, 111])
+    assert fastcsv.write_table(out, list(df.columns), [df[c] for c in df.columns], n, rows=rows, encoding="utf-8")
+    with open(out, "rb") as f:
+        assert f.read() == df.iloc[rows].to_csv(index=False).encode("utf-8")

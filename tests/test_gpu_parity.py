@@ -424,3 +424,28 @@ def test_k2_rows_of_thousands_of_boxes(native, sizes, thr, min_boxes):
     assert np.array_equal(got, want)
     assert np.array_equal(gmx.view(np.uint64), wmx.view(np.uint64))
     assert np.array_equal(native.iou_any_ge(box, off, min_boxes, thr), want)
+
+
+def test_a_full_hash_table_is_an_error_not_a_wrong_mask(native):
+    """K4 / K5 record device-side failures in the status word: the host-pointer entries return an error, a `_dev` caller
+    finds it in dyd_device_status (csrc/k4_dedup.hip: table full).  dyd_set_option("k4_capacity_shift") undersizes the table."""
+    import torch
+
+    L = native.lib()
+    rng = np.random.default_rng(3)
+    h = rng.integers(0, 2 ** 63, size=(50_000, 2), dtype=np.uint64)
+    native.check(L.dyd_set_option(b"k4_capacity_shift", 3), "opt")          # 131072 slots / 8 = 16384 < 50000 keys
+    try:
+        with pytest.raises(native.NativeError, match="hash table full"):
+            native.dedup(h, "first")
+        with pytest.raises(native.NativeError, match="hash table full"):
+            native.isin(h[:100], h)
+        t = torch.from_numpy(h.view(np.int64)).to("cuda:0")
+        keep = torch.empty(len(h), dtype=torch.uint8, device="cuda:0")
+        native.check(L.dyd_dedup_dev(t.data_ptr(), len(h), 0, keep.data_ptr(), None), "dyd_dedup_dev")    # queued: no error yet
+        assert L.dyd_device_status(None) != 0 and b"hash table full" in L.dyd_last_error()
+        assert L.dyd_device_status(None) == 0                                                          # read once, then cleared
+    finally:
+        native.check(L.dyd_set_option(b"k4_capacity_shift", 0), "opt")
+    assert np.array_equal(native.dedup(h, "first"), olib.dedup(h, 0))
+    assert L.dyd_device_status(None) == 0

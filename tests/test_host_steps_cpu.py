@@ -349,3 +349,55 @@ def test_exception_messages_match_the_reference(oracle_backend, tmp_path):
                 assert [type(info.value).__name__, str(info.value).replace(str(tmp_path), "<TMP>")] == g[name], (name, native_csv)
         finally:
             os.environ.pop("DYD_NATIVE_CSV", None)
+
+
+def test_key_columns_of_any_hashable_match_pandas(oracle_backend):
+    """drop_duplicates accepts any hashable cell (reference processor.py:140): str, numbers that compare equal across types,
+    tuples, Decimal, None / NaN — the keep-mask must be pandas' own for every keep mode; an unhashable cell raises TypeError"""
+    from decimal import Decimal
+    cols = [
+        ["a", "b", "a", np.nan, "b", np.nan, "c"],             # read_csv marks every missing cell with NaN
+        ["1.0", 1.0, 1, True, "1", 2, 2.0, "n1.0"],
+        [(1, 2), (1, 2), "x", (2, 1), Decimal(1), 1, 1.0, None, frozenset([1]), frozenset([1])],
+        [2 ** 60, 2 ** 60 + 1, float(2 ** 60), "s", "s"],
+    ]
+    for vals in cols:
+        col = pd.Series(vals, dtype=object, name="source")
+        for keep in ("first", "last", False):
+            want = ~col.duplicated(keep=keep).to_numpy()
+            assert np.array_equal(P.dedup_keep_mask(col, keep, oracle_backend), want), (vals, keep)
+            assert np.array_equal(P.dedup_keep_mask(col, keep, oracle_backend, verify=True), want), (vals, keep)
+    with pytest.raises(TypeError):
+        P.dedup_keep_mask(pd.Series(["a", [1, 2]], dtype=object, name="source"), "first", oracle_backend)
+
+
+def test_verify_mode_catches_a_hash_collision(oracle_backend):
+    """a backend whose hash maps two different URLs to one key: without verify the second row is dropped, with verify the
+    collision is detected (fewer distinct hashes than distinct values) and the exact masks come back"""
+    class Colliding:
+        def __getattr__(self, name):
+            return getattr(oracle_backend, name)
+
+        def hash128(self, data, off):
+            h = oracle_backend.hash128(data, off)
+            h[1] = h[0]                                  # rows 0 and 1 collide
+            return h
+
+    main = pd.Series(["http://a/1.jpg", "http://a/2.jpg", "http://a/3.jpg", "http://a/1.jpg"], name="source")
+    be = Colliding()
+    assert P.dedup_keep_mask(main, "first", be).tolist() == [True, False, True, False]           # the collision swallowed row 1
+    P.VERIFY_EVENTS.clear()
+    assert P.dedup_keep_mask(main, "first", be, verify=True).tolist() == [True, True, True, False]
+    assert P.dedup_keep_mask(main, False, be, verify=True).tolist() == [False, True, True, False]
+    assert len(P.VERIFY_EVENTS) == 2 and P.VERIFY_EVENTS[0][0] == "dedup"
+    ref = pd.Series(["http://a/1.jpg"], name="source")
+
+    class CollidingRef(Colliding):
+        def hash128(self, data, off):
+            h = oracle_backend.hash128(data, off)
+            if len(h) == 4:
+                h[1] = h[0]
+            return h
+
+    assert P.ref_hit_mask(main, ref, CollidingRef()).tolist() == [True, True, False, True]
+    assert P.ref_hit_mask(main, ref, CollidingRef(), verify=True).tolist() == [True, False, False, True]
