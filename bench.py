@@ -200,6 +200,82 @@ def full_pipeline(tab, dev, L, ck, sp):
             "rows": N, "total_ms": round(total, 3), "rows_per_s": N / total * 1e3, "stages": stages}
 
 
+def sharded_dedup(rows, rank, world, dev, reps=3):
+    """configs[3]'s exchange on this rank's `rows` rows of a world*rows table: K3 hash of the URL column, K4 on the shard,
+    ONE all-gather of the locally unique 16-B keys (RCCL over xGMI), K5 probe of the local survivors against the lower ranks'
+    keys; then the reference filter (reference keys sharded, gathered once, K5).  Wall-clock per stage with a device
+    synchronisation on both sides, the collective on its own; median of `reps`."""
+    import torch
+    import torch.distributed as dist
+    from deal_yolo_daya_amd import distributed as D
+
+    ops = D.HipOps(dev)
+    N = rows * world
+    g = torch.Generator(device=dev).manual_seed(900 + rank)
+    ids = torch.randint(0, int(0.9 * N) + 1, (rows,), generator=g, device=dev, dtype=torch.int64)     # ~40 % duplicates globally
+    prefix, suffix = b"http://img.example/", b".jpg"
+    width = len(prefix) + 10 + len(suffix)
+
+    def url_bytes(v):
+        n = v.numel()
+        out = torch.empty((n, width), dtype=torch.uint8, device=dev)
+        out[:, :len(prefix)] = torch.tensor(list(prefix), dtype=torch.uint8, device=dev)
+        out[:, len(prefix) + 10:] = torch.tensor(list(suffix), dtype=torch.uint8, device=dev)
+        v = v.clone()
+        for k in range(9, -1, -1):
+            out[:, len(prefix) + k] = (v % 10 + 48).to(torch.uint8)
+            v //= 10
+        return out.reshape(-1), torch.arange(n + 1, device=dev, dtype=torch.int64) * width
+
+    data, off = url_bytes(ids)
+    ref_all = torch.arange(0, int(0.9 * N) + 1, 10, device=dev, dtype=torch.int64)
+    rlo, rhi = D.shard_bounds(int(ref_all.numel()), world, rank)
+    rdata, roff = url_bytes(ref_all[rlo:rhi])
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    runs = []
+    for _ in range(reps + 1):
+        t = {}
+        sync(); a = time.perf_counter()
+        h = ops.hash128(data, off)
+        sync(); t["k3_ms"] = (time.perf_counter() - a) * 1e3
+        tm = {}
+        a = time.perf_counter()
+        keep = D.dedup_keys_sharded(h, "first", ops, timings=tm)
+        sync(); t["dedup_total_ms"] = (time.perf_counter() - a) * 1e3
+        t["dedup_allgather_ms"] = tm["collective_s"] * 1e3
+        t["gathered_keys"], t["local_unique_keys"] = tm["gathered_keys"], tm["local_unique_keys"]
+        a = time.perf_counter()
+        hr = ops.hash128(rdata, roff)
+        sync(); b = time.perf_counter()
+        all_ref, _ = D.all_gather_rows(hr)
+        sync(); c = time.perf_counter()
+        hit = ops.isin(h, all_ref)
+        ops.check_status()
+        sync(); d = time.perf_counter()
+        t["ref_k3_ms"], t["ref_allgather_ms"], t["ref_k5_ms"] = (b - a) * 1e3, (c - b) * 1e3, (d - c) * 1e3
+        t["kept_local"], t["ref_hits_local"] = int(keep.sum().item()), int(hit.sum().item())
+        runs.append(t)
+    runs = runs[1:]
+    med = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
+    tot = torch.tensor([med["kept_local"], med["ref_hits_local"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        if dist.get_backend() == "gloo":
+            tc = tot.cpu(); dist.all_reduce(tc); tot = tc
+        else:
+            dist.all_reduce(tot)
+    step_ms = med["k3_ms"] + med["dedup_total_ms"] + med["ref_k3_ms"] + med["ref_allgather_ms"] + med["ref_k5_ms"]
+    return {"config": "configs[3] exchange: sharded URL dedup + reference filter, rows sharded contiguously, one all-gather of the "
+                      "locally unique keys (dedup) and one of the reference keys",
+            "rows_per_gpu": rows, "rows_total": N, "world": world, "backend": dist.get_backend() if world > 1 else "single process",
+            "stages_ms_rank0": {k: round(v, 3) for k, v in med.items() if k.endswith("_ms")},
+            "allgather_bytes_dedup": int(med["gathered_keys"]) * 16, "local_unique_keys_rank0": int(med["local_unique_keys"]),
+            "kept_rows_total": int(tot[0].item()), "ref_hits_total": int(tot[1].item()),
+            "step_ms_rank0": round(step_ms, 3), "rows_per_s": N / step_ms * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +289,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100000, help="largest CPU-baseline sample (0 = skip); 10000 rows are timed as well")
     ap.add_argument("--host-rows", type=int, default=1_000_000, help="rows of the host-inclusive DataFrame run (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = also time configs[2]'s full pipeline per stage (c3, N=1)")
+    ap.add_argument("--exchange", type=int, default=1,
+                    help="1 = at N > 1 also time configs[3]'s sharded dedup / reference filter with its all-gathers (after the K steps)")
     args = ap.parse_args()
 
     import torch
@@ -308,9 +386,15 @@ def main():
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if dist.get_backend() == "gloo":
+            tc = tt.cpu(); dist.all_reduce(tc, op=dist.ReduceOp.MAX); tt = tc
+        else:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     high_rows = int(out_high.sum().item())
+    exchange = None
+    if world > 1 and args.exchange:      # every rank takes part; rank 0 reports
+        exchange = sharded_dedup(rows, rank, world, dev)
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
@@ -354,6 +438,7 @@ def main():
         line["cpu_baseline"] = None
         line["host_inclusive"] = None
         line["full_pipeline"] = None
+        line["sharded_exchange"] = exchange
         if world == 1:
             if args.pipeline and args.workload == "c3":
                 line["full_pipeline"] = full_pipeline({"N": N, "B": B, "P": P, "label": label, "fused": fused}, dev, L, ck, sp)

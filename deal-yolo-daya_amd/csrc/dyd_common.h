@@ -32,6 +32,12 @@ struct Context {
     // one word on the device that kernels OR their failure bits into (K4: 1 = hash table full, 2 = an inserted key was not
     // found again); host-pointer entry points read and clear it before they return, `_dev` callers ask dyd_device_status
     int *dev_status = nullptr;
+    // queue for image rows of thousands of boxes (k2_wave.h), shared by the K2 / fused entry points
+    void *bigq = nullptr;
+    hipEvent_t bigq_ev = nullptr;
+    hipStream_t bigq_stream = nullptr;
+    bool bigq_busy = false, bigq_dirty = false;
+    int bigq_turn = 0;
 };
 
 Context &ctx();

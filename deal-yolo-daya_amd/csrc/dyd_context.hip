@@ -47,6 +47,8 @@ static int init_locked(int device) {
         (void)hipSetDevice(c.device);
         if (c.scratch) (void)hipFree(c.scratch);
         if (c.dev_status) (void)hipFree(c.dev_status);
+        if (c.bigq) (void)hipFree(c.bigq);
+        if (c.bigq_ev) (void)hipEventDestroy(c.bigq_ev);
         if (c.ev0) (void)hipEventDestroy(c.ev0);
         if (c.ev1) (void)hipEventDestroy(c.ev1);
         if (c.scratch_ev) (void)hipEventDestroy(c.scratch_ev);
@@ -152,6 +154,8 @@ void dyd_shutdown(void) {
     (void)hipDeviceSynchronize();
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.dev_status) (void)hipFree(c.dev_status);
+    if (c.bigq) (void)hipFree(c.bigq);
+    if (c.bigq_ev) (void)hipEventDestroy(c.bigq_ev);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     if (c.scratch_ev) (void)hipEventDestroy(c.scratch_ev);

@@ -187,7 +187,8 @@ bool k1_wants_groups(int64_t n_boxes, int64_t n_points);
 int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr,
               uint8_t *out_high, double *out_max, hipStream_t st, int64_t n_boxes = -1);
 int acquire_bigq(unsigned long long **q, hipStream_t st);
-int launch_k2_big_rows(const double *box4, const int32_t *row_off, const unsigned long long *bigq, int32_t min_boxes, double thr,
+void release_bigq(hipStream_t st);
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, unsigned long long *bigq, int32_t min_boxes, double thr,
                        uint8_t *out_high, double *out_max, hipStream_t st);
 void set_k1_variant(int v);
 void set_k2_variant(int v);
@@ -257,7 +258,7 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
                                thr, out_box4, out_arg4, out_high, bigq);
         DYD_HIP(hipGetLastError());
         const int rcb = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
-        release_scratch(st);
+        if (!rcb) release_bigq(st);
         return rcb;
     }
     int rc;
@@ -272,8 +273,8 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     else
         rc = launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     if (!rc) rc = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
-    release_scratch(st);
     if (rc) return rc;
+    release_bigq(st);
     return launch_null_fix(out_arg4, out_box4, box_off, n_rows, n_boxes, min_boxes, thr, out_high, st);
 }
 

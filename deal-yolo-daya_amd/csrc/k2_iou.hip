@@ -105,7 +105,7 @@ void set_k2_variant(int v) { g_k2_variant = v; }
 
 int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
                      unsigned long long *bigq, hipStream_t st);   // k12_fused.hip
-int launch_k2_big_rows(const double *box4, const int32_t *row_off, const unsigned long long *bigq, int32_t min_boxes, double thr,
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, unsigned long long *bigq, int32_t min_boxes, double thr,
                        uint8_t *out_high, double *out_max, hipStream_t st);
 
 // the pair stage alone: main kernel (rows of thousands of boxes go to `bigq`) — the caller launches k2_big_rows behind it
@@ -120,14 +120,31 @@ static int launch_k2_main(const double *box4, const int32_t *row_off, int64_t n_
     return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
 }
 
-// a queue for the rows of thousands of boxes, from the context's scratch (the caller releases the scratch after its last launch)
+// The context's queue for rows of thousands of boxes (zeroed once; k2_big_rows_kernel leaves it empty again).  A launch on
+// another stream than the previous user's waits for that user's big-row kernel first: the queue is one per context.
 int acquire_bigq(unsigned long long **q, hipStream_t st) {
-    void *scr = nullptr;
-    int rc = get_scratch(K2_BIGQ_BYTES, &scr, st);
-    if (rc) return rc;
-    *q = static_cast<unsigned long long *>(scr);
-    DYD_HIP(hipMemsetAsync(scr, 0, 8, st));
+    Context &c = ctx();
+    if (!c.bigq) {
+        DYD_HIP(hipMalloc(&c.bigq, 2 * K2_BIGQ_BYTES));
+        DYD_HIP(hipMemset(c.bigq, 0, 2 * K2_BIGQ_BYTES));
+        DYD_HIP(hipEventCreateWithFlags(&c.bigq_ev, hipEventDisableTiming));
+    }
+    if (c.bigq_busy && c.bigq_stream != st) DYD_HIP(hipStreamWaitEvent(st, c.bigq_ev, 0));
+    if (c.bigq_dirty) {   // a launch between acquire and drain failed last time: start from two empty queues
+        DYD_HIP(hipMemsetAsync(c.bigq, 0, 2 * K2_BIGQ_BYTES, st));
+        c.bigq_dirty = false;
+    }
+    c.bigq_turn ^= 1;
+    c.bigq_dirty = true;   // until release_bigq: the drain kernel is what leaves the queues clean
+    *q = static_cast<unsigned long long *>(c.bigq) + (c.bigq_turn ? K2_BIGQ_BYTES / 8 : 0);
     return DYD_OK;
+}
+void release_bigq(hipStream_t st) {
+    Context &c = ctx();
+    c.bigq_stream = st;
+    c.bigq_busy = true;
+    c.bigq_dirty = false;
+    (void)hipEventRecord(c.bigq_ev, st);
 }
 
 // K2 over device arrays: main kernel, then the queued big rows spread over the grid
@@ -139,7 +156,7 @@ int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_
     if (rc) return rc;
     rc = launch_k2_main(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, st, q, n_boxes);
     if (!rc) rc = launch_k2_big_rows(box4, row_off, q, min_boxes, thr, out_high, out_max, st);
-    release_scratch(st);
+    if (!rc) release_bigq(st);
     return rc;
 }
 
@@ -158,6 +175,7 @@ template <bool WANT_MAX>
 __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__restrict__ box4,
                                                                const int32_t *__restrict__ row_off,
                                                                const unsigned long long *__restrict__ bigq,
+                                                               unsigned long long *__restrict__ bigq_other,
                                                                int32_t min_boxes, double thr,
                                                                uint8_t *__restrict__ out_high,
                                                                unsigned long long *__restrict__ out_max_bits) {
@@ -170,6 +188,10 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
     int64_t item = 0;   // running number of the items, the same in every wave
     const unsigned long long pushed = bigq[0];
     const int32_t n_big = pushed < (unsigned long long)K2_BIG_LIST ? (int32_t)pushed : K2_BIG_LIST;
+    // two queues take turns: this launch empties the OTHER one (its last user's drain has finished — same stream, or waited for),
+    // so the next launch finds an empty queue without a memset in front of it
+    if (blockIdx.x == 0 && threadIdx.x == 0) bigq_other[0] = 0ull;
+    if (n_big == 0) return;
     for (int32_t k = 0; k < n_big; ++k) {
         const int64_t r = (int64_t)bigq[1 + 2 * k];
         const int64_t base = row_off[r];
@@ -225,14 +247,16 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
     }
 }
 
-int launch_k2_big_rows(const double *box4, const int32_t *row_off, const unsigned long long *bigq, int32_t min_boxes, double thr,
+int launch_k2_big_rows(const double *box4, const int32_t *row_off, unsigned long long *bigq, int32_t min_boxes, double thr,
                        uint8_t *out_high, double *out_max, hipStream_t st) {
-    const unsigned blocks = (unsigned)ctx().num_cu * 4;   // 16 waves per CU, striding over the items
+    const unsigned blocks = (unsigned)ctx().num_cu * 2;   // 8 waves per CU, striding over the items (an empty queue is the usual case)
+    unsigned long long *base = static_cast<unsigned long long *>(ctx().bigq);
+    unsigned long long *other = (bigq == base) ? base + K2_BIGQ_BYTES / 8 : base;
     if (out_max)
-        hipLaunchKernelGGL(k2_big_rows_kernel<true>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, bigq, min_boxes, thr,
+        hipLaunchKernelGGL(k2_big_rows_kernel<true>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, bigq, other, min_boxes, thr,
                            out_high, reinterpret_cast<unsigned long long *>(out_max));
     else
-        hipLaunchKernelGGL(k2_big_rows_kernel<false>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, bigq, min_boxes, thr,
+        hipLaunchKernelGGL(k2_big_rows_kernel<false>, dim3(blocks), dim3(K2_BLOCK), 0, st, box4, row_off, bigq, other, min_boxes, thr,
                            out_high, (unsigned long long *)nullptr);
     DYD_HIP(hipGetLastError());
     return DYD_OK;

@@ -23,7 +23,7 @@ struct Corners {
 // row stays with its wave as before: a table with thousands of such rows keeps the tile kernel's waves busy anyway.
 constexpr int32_t K2_BIG_ROW = 256;      // rows above this many boxes (the tile kernels hold 128 / 256 per tile)
 constexpr int32_t K2_BIG_LIST = 2048;    // queue capacity
-constexpr size_t K2_BIGQ_BYTES = 8 * (1 + 2 * (size_t)K2_BIG_LIST);
+constexpr size_t K2_BIGQ_BYTES = 8 * (2 + 2 * (size_t)K2_BIG_LIST);   // count + entries of ONE queue (the context holds two, taking turns)
 
 __device__ __forceinline__ bool bigq_push(unsigned long long *q, int64_t row, int32_t n) {   // wave-uniform call
     if (!q) return false;

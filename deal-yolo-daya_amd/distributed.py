@@ -4,14 +4,18 @@ Rows shard contiguously: rank r owns global rows [r*N/G, (r+1)*N/G), so "first o
 lowest (rank, local index).  The poly->bbox (K1) and IoU (K2) stages are independent per row and
 need no communication.  The two set-valued stages exchange hashes exactly once:
 
-    dedup       K3 hash local rows -> ONE all-gather of 16-B keys (RCCL over xGMI) -> every rank
-                inserts all keys into its table, resolves only its own rows (dyd_dedup_global_dev)
+    dedup       K3 hash local rows -> K4 on the shard alone (local keep-mask) -> ONE all-gather of the shard's
+                locally-UNIQUE 16-B keys (RCCL over xGMI; an 8-byte count per rank goes ahead of it) -> K5: a row that
+                survived locally is dropped when its key also occurs on a LOWER rank (keep=first), a HIGHER rank
+                (keep=last) or any other rank (keep=False).  Contiguous shards make "first occurrence" = lowest
+                (rank, local index), so no row index travels, and a rank builds a table of the OTHER ranks' unique
+                keys only — never of all N rows
     ref filter  K3 hash local main rows and local reference rows -> ONE all-gather of the
                 reference keys -> K5 probe of the local main keys
     split       ONE all-gather of per-rank per-category counts (n_cat x 8 B) -> each rank's
-                in-category ranks start at the sum of the lower ranks' counts
-                (dyd_split_ids_sharded_dev); the MT19937 permutation of each GLOBAL category size
-                is computed on every host identically.
+                in-category ranks start at the sum of the lower ranks' counts; the permutation of each GLOBAL
+                category size is made on every rank's device from the seed (K8, dyd_split_ids_seeded_dev): nothing
+                but the counts crosses ranks.
 
     label lines rows are independent (K7 per shard); ONE all-gather of the shards' text sizes (8 B each) turns the
                 local byte offsets into offsets inside the concatenated text of all ranks
@@ -73,6 +77,30 @@ class HipOps:
                               "dyd_hash128_dev")
         return out
 
+    def check_status(self):
+        """device-side failures of the launches queued so far (hash table full ...): raises NativeError"""
+        self.native.check(self.L.dyd_device_status(self._stream()), "dyd_device_status")
+
+    def dedup_local(self, h: torch.Tensor, keep) -> torch.Tensor:
+        """K4 over this rank's keys alone -> uint8 keep-mask"""
+        out = torch.empty(h.shape[0], dtype=torch.uint8, device=self.device)
+        if h.shape[0]:
+            self.native.check(self.L.dyd_dedup_dev(h.data_ptr(), h.shape[0], _KEEP[keep], out.data_ptr(), self._stream()),
+                              "dyd_dedup_dev")
+        return out
+
+    def split_ids_seeded(self, cat, seed, sizes, n_train, n_val, rank_base):
+        """K8 + K6 for a shard: host arrays for the categories' sizes / cuts / rank bases, `cat` on the device"""
+        n = cat.numel()
+        split = torch.empty(n, dtype=torch.uint8, device=self.device)
+        pos = torch.empty(n, dtype=torch.int64, device=self.device)
+        if n:
+            sizes, n_train, n_val, rank_base = (np.ascontiguousarray(a, dtype=np.int64) for a in (sizes, n_train, n_val, rank_base))
+            self.native.check(self.L.dyd_split_ids_seeded_dev(cat.data_ptr(), n, int(seed), sizes.ctypes.data, n_train.ctypes.data,
+                                                              n_val.ctypes.data, len(sizes), rank_base.ctypes.data, split.data_ptr(),
+                                                              pos.data_ptr(), self._stream()), "dyd_split_ids_seeded_dev")
+        return split, pos
+
     def dedup_global(self, all_h: torch.Tensor, first: int, n_local: int, keep) -> torch.Tensor:
         out = torch.empty(n_local, dtype=torch.uint8, device=self.device)
         if n_local:
@@ -123,6 +151,9 @@ def all_gather_rows(t: torch.Tensor, group=None) -> tuple:
     (all_gather_into_tensor on shards padded to the largest; shards differ by <= 1 row).
     -> (gathered [sum n_r, ...], counts per rank)"""
     world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":     # one-GPU rehearsal of several ranks: gloo moves host memory
+        out, counts = all_gather_rows(t.cpu(), group)
+        return out.to(t.device), counts
     n_local = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts_t = torch.empty(world, dtype=torch.int64, device=t.device)
     dist.all_gather_into_tensor(counts_t, n_local, group=group)
@@ -152,6 +183,42 @@ def _local_keys(col, ops, for_isin: bool = False, drop_na: bool = False) -> torc
     return h
 
 
+def dedup_keys_sharded(h: torch.Tensor, keep, ops, group=None, timings: dict | None = None) -> torch.Tensor:
+    """Global keep-mask (bool tensor on h's device) of this rank's keys h [n, 2]: local K4, one all-gather of the locally
+    unique keys, K5 probe of the local survivors against the other ranks' keys (see the module docstring)."""
+    import time as _t
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local_keep = ops.dedup_local(h, keep).bool()
+    uniq_mask = local_keep if keep in ("first", "last") else ops.dedup_local(h, "first").bool()
+    uniq = h[uniq_mask].contiguous()                      # one key per distinct local value, in row order
+    if timings is not None and h.is_cuda:
+        torch.cuda.synchronize(h.device)
+    t0 = _t.perf_counter()
+    gathered, counts = all_gather_rows(uniq, group)
+    if timings is not None:
+        if h.is_cuda:
+            torch.cuda.synchronize(h.device)
+        timings["collective_s"] = timings.get("collective_s", 0.0) + (_t.perf_counter() - t0)
+        timings["gathered_keys"] = int(sum(counts))
+        timings["local_unique_keys"] = int(uniq.shape[0])
+    start = int(sum(counts[:rank]))
+    end = start + counts[rank]
+    if keep == "first":
+        others = gathered[:start]
+    elif keep == "last":
+        others = gathered[end:]
+    else:
+        others = torch.cat([gathered[:start], gathered[end:]]) if world > 1 else gathered[:0]
+    out = local_keep.clone()
+    if others.shape[0] and bool(local_keep.any()):
+        hit = ops.isin(h[local_keep].contiguous(), others.contiguous()).bool()
+        out[local_keep] = ~hit
+    if hasattr(ops, "check_status"):
+        ops.check_status()
+    return out
+
+
 def dedup_keep_mask_sharded(local_col, keep="first", ops=None, group=None) -> np.ndarray:
     """keep-mask of this rank's shard of ``drop_duplicates(keep=keep)`` over the GLOBAL column
     (reference core/processor.py:140-144)."""
@@ -159,10 +226,7 @@ def dedup_keep_mask_sharded(local_col, keep="first", ops=None, group=None) -> np
         raise ValueError('keep must be either "first", "last" or False')
     ops = ops or HipOps()
     h = _local_keys(local_col, ops)
-    all_h, counts = all_gather_rows(h, group)
-    rank = dist.get_rank(group)
-    first = int(sum(counts[:rank]))
-    return ops.dedup_global(all_h, first, counts[rank], keep).cpu().numpy().astype(bool)
+    return dedup_keys_sharded(h, keep, ops, group).cpu().numpy().astype(bool)
 
 
 def ref_hit_mask_sharded(local_main_col, local_ref_col, ops=None, group=None) -> np.ndarray:
@@ -172,7 +236,10 @@ def ref_hit_mask_sharded(local_main_col, local_ref_col, ops=None, group=None) ->
     hm = _local_keys(local_main_col, ops, for_isin=True)
     hr = _local_keys(local_ref_col, ops, for_isin=True, drop_na=True)
     all_ref, _ = all_gather_rows(hr, group)
-    return ops.isin(hm, all_ref).cpu().numpy().astype(bool)
+    hit = ops.isin(hm, all_ref)
+    if hasattr(ops, "check_status"):
+        ops.check_status()
+    return hit.cpu().numpy().astype(bool)
 
 
 def split_ids_sharded(local_cat: np.ndarray, n_cat: int, train_ratio=0.8, val_ratio=0.1, test_ratio=0.1,
@@ -191,13 +258,16 @@ def split_ids_sharded(local_cat: np.ndarray, n_cat: int, train_ratio=0.8, val_ra
     rank_base = all_counts[:rank].sum(axis=0).astype(np.int64)
     cat_off = np.zeros(n_cat + 1, np.int64)
     np.cumsum(sizes, out=cat_off[1:])
-    perm = (np.concatenate([ops.permutation(random_seed, int(s)) for s in sizes])
-            if n_cat else np.zeros(0, np.int64))
     cuts = [split_cut_sizes(int(s), train_ratio, val_ratio, test_ratio) for s in sizes]
     n_train = np.asarray([c[0] for c in cuts], np.int64)
     n_val = np.asarray([c[1] for c in cuts], np.int64)
-    split, pos = ops.split_ids_sharded(ops.tensor(local_cat), ops.tensor(perm), ops.tensor(cat_off),
-                                       ops.tensor(n_train), ops.tensor(n_val), ops.tensor(rank_base))
+    if hasattr(ops, "split_ids_seeded"):                  # K8: the permutations never exist on the host
+        split, pos = ops.split_ids_seeded(ops.tensor(local_cat), random_seed, sizes, n_train, n_val, rank_base)
+    else:
+        perm = (np.concatenate([ops.permutation(random_seed, int(s)) for s in sizes])
+                if n_cat else np.zeros(0, np.int64))
+        split, pos = ops.split_ids_sharded(ops.tensor(local_cat), ops.tensor(perm), ops.tensor(cat_off),
+                                           ops.tensor(n_train), ops.tensor(n_val), ops.tensor(rank_base))
     return split.cpu().numpy(), pos.cpu().numpy()
 
 

@@ -146,6 +146,18 @@ int dyd_isin(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, uin
 int dyd_isin_dev(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r,
                  uint8_t *out_mask, void *stream);
 
+/* ---- multi-GPU -------------------------------------------------------------------------------------------------
+ * One process per GPU; rows are sharded contiguously; K1 / K2 / K7 need no communication.  The path's one real exchange — the
+ * all-gather of each shard's locally unique 16-byte keys (and of the reference keys) — is issued by the host layer
+ * (deal-yolo-daya_amd/distributed.py) through the process group the caller already has: torch.distributed with backend "nccl",
+ * which IS RCCL over xGMI on ROCm, on the stream the `_dev` kernels run on.  SURVEY §8b sketched a library-owned communicator
+ * (dyd_comm_init(nranks, rank, rccl_unique_id) + dyd_comm* variants); it is deliberately NOT part of this ABI: a second
+ * bootstrap (unique-id exchange) and a second RCCL communicator beside the caller's, for a single all-gather, would duplicate
+ * state the caller must own anyway (device binding, stream, process-group lifetime).  The library's side of a sharded call is
+ * therefore the plain `_dev` entry points on the shard's arrays: dyd_hash128_dev, dyd_dedup_dev (shard-local pre-dedup),
+ * dyd_isin_dev (probe of the local survivors against the other ranks' keys), dyd_split_ids_seeded_dev (with cat_rank_base),
+ * and dyd_device_status.  dyd_dedup_global_dev below is the older form (every rank inserts ALL gathered keys). */
+
 /* ---- multi-GPU dedup: keys of ALL ranks after the allgather ----------------------
  * all_h : gathered keys of every rank in global row order          [2*n_all]
  * first_global / n_local: this rank owns global rows [first_global, first_global+n_local)

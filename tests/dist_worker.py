@@ -27,6 +27,9 @@ class OracleOps:
     def hash128(self, data, off):
         return torch.from_numpy(olib.hash128(data.numpy(), off.numpy()).view(np.int64))
 
+    def dedup_local(self, h, keep):
+        return torch.from_numpy(olib.dedup(h.numpy().view(np.uint64), _KEEP[keep]))
+
     def dedup_global(self, all_h, first, n_local, keep):
         mask = olib.dedup(all_h.numpy().view(np.uint64), _KEEP[keep])
         return torch.from_numpy(mask[first:first + n_local].copy())

@@ -103,6 +103,57 @@ def test_fused_ends_a_row_at_its_first_empty_polygon(native, n_rows, max_boxes, 
     assert plain_differs or share == 1.0, "the table must tell the chain from K2-on-K1's-boxes"
 
 
+@pytest.mark.parametrize("variant", [-1, 0, 4, 6])
+def test_rows_of_thousands_of_boxes_through_the_device_entries(native, variant):
+    """a 5000-box row, a 700-box row with an empty polygon in its middle and one of 300 boxes among ordinary rows, device
+    resident: the main kernel queues them and k2_big_rows_kernel spreads them over the grid (csrc/k2_wave.h) — same flags as
+    the oracle's chain, for dyd_bbox_iou_fused_dev and for dyd_iou_any_ge_dev on the resulting boxes"""
+    import torch
+
+    rng = np.random.default_rng(17)
+    nb = rng.integers(0, 20, size=400)
+    nb[37], nb[200], nb[399], nb[5] = 5000, 700, 300, 257
+    box_off = np.zeros(len(nb) + 1, np.int32)
+    np.cumsum(nb, out=box_off[1:])
+    B = int(box_off[-1])
+    npts = np.full(B, 4)
+    npts[box_off[200] + 350] = 0                                   # the 700-box row ends at its 350th polygon
+    pt_off = np.zeros(B + 1, np.int32)
+    np.cumsum(npts, out=pt_off[1:])
+    k_in_row = np.arange(B) - np.repeat(box_off[:-1], nb)
+    corner = np.tile(np.array([[0.0, 0.0], [100.0, 0.0], [100.0, 100.0], [0.0, 100.0]]), (int(npts.sum()) // 4, 1))
+    xy = corner + np.repeat(k_in_row, npts)[:, None] * np.array([[150.0, 0.0]])
+    # the 5000-box row: its last box repeats box 4321 (the only HIGH pair lies deep inside); the 700-box row: boxes 699 and 10
+    for r, a, b in ((37, 4999, 4321), (200, 699, 10), (399, 299, 298)):
+        pa, pb = pt_off[box_off[r] + a], pt_off[box_off[r] + b]
+        xy[pa:pa + 4] = xy[pb:pb + 4]
+    L = native.lib()
+    dev = torch.device("cuda:0")
+    t_xy, t_po, t_bo = (torch.from_numpy(a).to(dev) for a in (xy, pt_off, box_off))
+    n_rows = len(nb)
+    native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+    try:
+        for mb, thr in ((2, 0.98), (3, 0.5)):
+            obox, oarg, ohigh = olib.bbox_iou_chain(xy, pt_off, box_off, mb, thr)
+            t_box = torch.empty((B, 4), dtype=torch.float64, device=dev)
+            t_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
+            t_high = torch.full((n_rows,), 9, dtype=torch.uint8, device=dev)
+            native.check(L.dyd_bbox_iou_fused_dev(t_xy.data_ptr(), t_po.data_ptr(), t_bo.data_ptr(), n_rows, B, len(xy), mb, thr,
+                                                  t_box.data_ptr(), t_arg.data_ptr(), t_high.data_ptr(), None), "fused")
+            torch.cuda.synchronize()
+            assert np.array_equal(t_arg.cpu().numpy(), oarg)
+            assert np.array_equal(t_high.cpu().numpy(), ohigh), (mb, thr, np.flatnonzero(t_high.cpu().numpy() != ohigh))
+            assert ohigh[37] == 1 and ohigh[200] == 0 and ohigh[399] == 1
+            # K2 alone on those boxes (no chain rule there: the 700-box row pairs all of its boxes; its empty polygon is a NaN box)
+            t_high.fill_(9)
+            native.check(L.dyd_iou_any_ge_dev(t_box.data_ptr(), t_bo.data_ptr(), n_rows, B, mb, thr, t_high.data_ptr(), None, None), "k2")
+            torch.cuda.synchronize()
+            assert np.array_equal(t_high.cpu().numpy(), olib.iou_any_ge(obox, box_off, mb, thr))
+    finally:
+        native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+    assert L.dyd_device_status(None) == 0
+
+
 def test_fused_host_entry_edges(native):
     """no rows, rows without boxes, boxes without points"""
     arg, high = native.bbox_iou_fused(np.zeros((0, 2)), np.zeros(1, np.int32), np.zeros(1, np.int32), 2, 0.98)
