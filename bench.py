@@ -279,9 +279,9 @@ def sharded_dedup(rows, rank, world, dev, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--ramp-ms", type=float, default=150.0,
+    ap.add_argument("--ramp-ms", type=float, default=400.0,
                     help="untimed launches before the W warm-up steps until this much GPU time has passed: the card idles at "
                          "a low shader clock while the inputs are generated, and a handful of launches do not bring it up")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")

@@ -53,13 +53,16 @@ bj = os.path.join(prof, f"{tag}_bench.json")
 if os.path.exists(bj):
     bench = json.load(open(bj))
     cfg = bench["config"]
-    fused = cfg.get("launch", "").startswith("fused")
-    key = next((k for k in summary if ("k12_" in k) == fused and ("k12_" in k or "k1_bbox_lds" in k)), None)
+    key = next((k for k in summary if "k12_wave_kernel" in k), None) or next((k for k in summary if "k12_" in k), None)
     t = summary.get(key, {}).get("hbm_traffic_bytes_per_launch") if key else None
+    workload = "c3" if cfg["rows_per_gpu"] == 10_000_000 else ("c2" if cfg["rows_per_gpu"] == 1_000_000 else "other")
     if t:
-        with open(os.path.join(prof, "k1_traffic.json"), "w") as fh:
-            json.dump({"workload": "c2", "fused": fused, "kernel": key, "rows_per_gpu": cfg["rows_per_gpu"],
+        with open(os.path.join(prof, "k12_traffic.json"), "w") as fh:
+            json.dump({"workload": workload, "kernel": key, "rows_per_gpu": cfg["rows_per_gpu"],
                        "traffic_bytes_per_launch": t["total_corrected"], "read_bytes_fetch_size_x2": t["read_corrected_x2"],
                        "write_bytes": t["write"],
-                       "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"},
+                       "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+                       "traffic_over_algorithmic": t["total_corrected"] / bench["roofline"]["algorithmic_bytes_per_launch"],
+                       "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                 "bench.py --steps 3 --warmup 1 on the same table)"},
                       fh, indent=1)
