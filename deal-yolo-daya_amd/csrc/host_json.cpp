@@ -1071,9 +1071,11 @@ void scan_part(dyd_scan *h, const CellSrc &src, const uint8_t *missing, FastPart
         try {
             walk_cell(cell, sk);
             A.xy.put(sxy.data(), sxy.size());
-            A.isint.need(sxy.size() / 2);
-            memset(A.isint.p + A.isint.n, 0, sxy.size() / 2);
-            A.isint.n += sxy.size() / 2;
+            if (!sxy.empty()) {
+                A.isint.need(sxy.size() / 2);
+                memset(A.isint.p + A.isint.n, 0, sxy.size() / 2);
+                A.isint.n += sxy.size() / 2;
+            }
             A.npts.put(snp.data(), snp.size());
             for (size_t k = 0; k < snp.size(); ++k) A.hole.push(0);
             A.cell_boxes.push(sk.box);

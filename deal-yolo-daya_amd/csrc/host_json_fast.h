@@ -37,7 +37,7 @@ struct Raw {
     }
     inline void need(size_t k) { if (n + k > cap) grow(n + k); }
     inline void push(T v) { if (n == cap) grow(n + 1); p[n++] = v; }
-    inline void put(const T *s, size_t k) { need(k); memcpy(p + n, s, k * sizeof(T)); n += k; }
+    inline void put(const T *s, size_t k) { if (!k) return; need(k); memcpy(p + n, s, k * sizeof(T)); n += k; }
     void clear_free() { free(p); p = nullptr; n = cap = 0; }
 };
 
