@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
 
 // K2 alone with the wave kernel's pair stage: a wave owns 16 rows, walks them in tiles of whole rows with at most 64 boxes (one
 // box per lane, loaded 32 bytes per lane), and runs the same all-pairs loop — none of the tile kernels' bookkeeping (row ranks,
-// row search, permutation): 0.245 -> 0.15 ms on the bench table.  Rows beyond 64 boxes take the slow partner-tile route,
+// row search, permutation): 0.245 -> 0.196 ms on the bench table.  Rows beyond 64 boxes take the slow partner-tile route,
 // so tables with many of them stay with the tile kernels (launch_k2 decides by the mean).
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k2_wave64_kernel(const double *box4, const int32_t *__restrict__ box_off, int64_t n_rows,

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--check", type=int, default=2000, help="rows compared with the CPU port of the reference (0 = none)")
+    ap.add_argument("--csv", type=int, default=0, help="1 = also time the path-in / path-out route (SURVEY §8d region 3): the fused CSV "
+                                                       "twin and the two step functions in sequence, files under --dir")
+    ap.add_argument("--dir", default="/tmp/dyd_e2e")
     args = ap.parse_args()
 
     import pandas as pd
@@ -49,6 +52,32 @@ def main():
                           "phases_s": {k: round(v, 3) for k, v in stats.items() if k.startswith("s_")},
                           "fast_cells": stats.get("fast_cells"), "python_cells": stats.get("python_cells"),
                           "out_bytes": out_bytes, "kernel_ms": round(_native.last_kernel_ms(), 3)}), flush=True)
+    if args.csv:
+        os.makedirs(args.dir, exist_ok=True)
+        Q = lambda n: os.path.join(args.dir, n)  # noqa: E731
+        a = time.perf_counter()
+        df.to_csv(Q("in.csv"), index=False, encoding="utf-8-sig")
+        print(json.dumps({"csv": "pandas to_csv of the input table", "seconds": round(time.perf_counter() - a, 2),
+                          "bytes": os.path.getsize(Q("in.csv"))}), flush=True)
+        import contextlib
+        import io
+        for rep in range(2):
+            with contextlib.redirect_stdout(io.StringIO()):
+                a = time.perf_counter()
+                P.process_csv_replace_and_filter(Q("in.csv"), Q("p.csv"), Q("x.csv"), Q("hi.csv"), Q("lo.csv"), 2, 0.98)
+                t_fused = time.perf_counter() - a
+                a = time.perf_counter()
+                P.process_csv_replace_ptlist(Q("in.csv"), Q("p2.csv"), Q("x2.csv"))
+                b = time.perf_counter()
+                P.filter_by_box_count_and_iou(Q("p2.csv"), Q("hi2.csv"), Q("lo2.csv"), 2, 0.98)
+                t_two = (b - a, time.perf_counter() - b)
+            same = all(open(Q(x), "rb").read() == open(Q(y), "rb").read() for x, y in (("p.csv", "p2.csv"), ("hi.csv", "hi2.csv"), ("lo.csv", "lo2.csv")))
+            print(json.dumps({"csv": "CSV -> CSV", "rows": len(df), "fused_twin_s": round(t_fused, 3), "fused_rows_per_s": round(len(df) / t_fused),
+                              "replace_step_s": round(t_two[0], 3), "iou_step_s": round(t_two[1], 3),
+                              "two_steps_rows_per_s": round(len(df) / sum(t_two)), "io_path": dict(P.LAST_IO_PATH),
+                              "same_files": same, "out_bytes": sum(os.path.getsize(Q(n)) for n in ("p.csv", "hi.csv", "lo.csv"))}), flush=True)
+        for n in os.listdir(args.dir):
+            os.remove(os.path.join(args.dir, n))
     if args.check:
         from oracle import steps as osteps
         sub = df.iloc[:args.check]
