@@ -102,6 +102,14 @@ SIGNATURES = {
     "dyd_scan_iou_host": (C.c_void_p, [C.c_void_p]),
     "dyd_scan_fast_cells": (C.c_int64, [C.c_void_p]),
     "dyd_json_scan_polygons_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "dyd_json_replace_iou": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double,
+                                       C.c_int, C.POINTER(C.c_void_p)]),
+    "dyd_scan_high": (C.c_void_p, [C.c_void_p]),
+    "dyd_scan_parts": (C.c_int32, [C.c_void_p]),
+    "dyd_scan_part": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p)]),
+    "dyd_scan_text": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dyd_scan_totals": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_scan_free": (None, [C.c_void_p]),
     "dyd_synth_json": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                  C.POINTER(C.c_void_p), C.c_void_p]),

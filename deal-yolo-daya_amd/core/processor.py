@@ -490,19 +490,27 @@ def _replace_csv_core(input_csv_path, backend, fuse=None):
     print(f"成功读取CSV，共 {table.n_rows} 行数据")
     kept_rows = np.flatnonzero(ann.na == 0)
     excluded_rows = np.flatnonzero(ann.na != 0)
-    scan = _nj.scan_polygons_buffers(ann.data, ann.off, ann.na)
     totals = {"boxes": 0, "points": 0, "host_boxes": 0, "python_cells": 0, "host_rows": 0}
-    irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
-    py = (_replace_cells_python(ann.cells(irregular), be, totals) if len(irregular) else ([], [], []))   # may raise, like the reference
     high = None
-    if fuse is not None:
-        arg4, high = be.bbox_iou_fused(scan.xy, scan.pt_off, scan.cell_box_off, fuse[0], fuse[1])
-        high = high.astype(bool)
-    elif scan.n_boxes:
-        _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
+    if fuse is not None and _native_pipeline(be):
+        # all-native pass: every worker thread scans, launches the fused kernel and emits its share of the cells
+        scan = _nj.replace_iou_buffers(ann.data, ann.off, ann.na, fuse[0], fuse[1])
+        irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+        py = (_replace_cells_python(ann.cells(irregular), be, totals) if len(irregular) else ([], [], []))   # may raise, like the reference
+        high = scan.high.copy()
+        text, off = scan.text_buffers()
     else:
-        arg4 = np.zeros((0, 4), np.int32)
-    text, off = scan.emit_buffers(arg4)
+        scan = _nj.scan_polygons_buffers(ann.data, ann.off, ann.na)
+        irregular = np.flatnonzero(scan.status == _nj.IRREGULAR)
+        py = (_replace_cells_python(ann.cells(irregular), be, totals) if len(irregular) else ([], [], []))   # may raise, like the reference
+        if fuse is not None:
+            arg4, high = be.bbox_iou_fused(scan.xy, scan.pt_off, scan.cell_box_off, fuse[0], fuse[1])
+            high = high.astype(bool)
+        elif scan.n_boxes:
+            _, arg4 = be.bbox_minmax(scan.xy, scan.pt_off)
+        else:
+            arg4 = np.zeros((0, 4), np.int32)
+        text, off = scan.emit_buffers(arg4)
     widths, heights = scan.width_height(0), scan.width_height(1)
     for col, key in ((widths, "width"), (heights, "height")):
         for i, v in enumerate(col):
@@ -742,6 +750,10 @@ def _replace_iou_cells_native(cells, min_boxes, iou_threshold, be, totals):
     widths / heights are numpy columns when every cell is plain (PolygonScan.wh_column), else per-cell lists"""
     import time as _t
     t0 = _t.perf_counter()
+    if _native_pipeline(be):
+        res = _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals)
+        if res is not None:
+            return res
     try:
         scan = _nj.scan_polygons(cells)
     except UnicodeEncodeError:                         # a lone surrogate somewhere: the two steps in sequence, CPython flatten
@@ -784,6 +796,58 @@ def _replace_iou_cells_native(cells, min_boxes, iou_threshold, be, totals):
     scan.close()
     totals["s_fixups"] = totals.get("s_fixups", 0.0) + (t5 - t4)
     totals["s_release"] = totals.get("s_release", 0.0) + (_t.perf_counter() - t5)
+    return texts, widths, heights, high
+
+
+def _native_pipeline(be) -> bool:
+    """the all-native replace -> IoU pass applies when the device stage is the product's own (not an injected checker)"""
+    from .. import _native as _nat
+    return be is _nat and os.environ.get("DYD_NATIVE_PIPELINE", "1") != "0"
+
+
+def _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals):
+    """one batch through dyd_json_replace_iou: every worker thread scans its share of the cells, launches the fused kernel on its
+    own arrays and emits — no gathered copies.  Returns None when the cells cannot be viewed (lone surrogate): the caller's
+    stepwise route handles that."""
+    import time as _t
+    t0 = _t.perf_counter()
+    try:
+        r = _nj.replace_iou(cells, min_boxes, iou_threshold)
+    except UnicodeEncodeError:
+        return None
+    t1 = _t.perf_counter()
+    irregular = np.flatnonzero(r.status == _nj.IRREGULAR)
+    totals["python_cells"] += int(len(irregular))
+    # irregular cells: the only ones that can raise; nothing has been handed out yet
+    py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
+    t2 = _t.perf_counter()
+    texts = r.texts_array()
+    t3 = _t.perf_counter()
+    high = r.high.copy()
+    plain = len(irregular) == 0
+    widths, heights = (r.wh_column(0), r.wh_column(1)) if plain else (r.width_height(0), r.width_height(1))
+    for col, key in ((widths, "width"), (heights, "height")):
+        if isinstance(col, list):
+            for i, v in enumerate(col):
+                if v is Ellipsis:
+                    col[i] = json.loads(cells[i]).get(key)
+    high[r.status != _nj.OK] = False
+    for i in np.flatnonzero((r.iou_host != 0) & (r.status == _nj.OK)).tolist():
+        high[i] = _iou_mask_python([texts[i]], min_boxes, iou_threshold, be, totals)[0]
+    for j, i in enumerate(irregular.tolist()):
+        texts[i], widths[i], heights[i] = py[0][j], py[1][j], py[2][j]
+        high[i] = _iou_mask_python([py[0][j]], min_boxes, iou_threshold, be, totals)[0]
+    totals["boxes"] += r.n_boxes
+    totals["points"] += r.n_points
+    totals["fused_launches"] += r.n_parts
+    totals["fast_cells"] += r.fast_cells
+    t4 = _t.perf_counter()
+    r.close()
+    for k, v in (("s_pipeline", t1 - t0), ("s_python_cells", t2 - t1), ("s_strings", t3 - t2), ("s_fixups", t4 - t3),
+                 ("s_release", _t.perf_counter() - t4), ("s_part_scan", r.seconds["scan"]), ("s_part_device", r.seconds["device"]),
+                 ("s_part_emit", r.seconds["emit"])):
+        totals[k] = totals.get(k, 0.0) + v
+    totals["native_pipeline"] = totals.get("native_pipeline", 0) + 1
     return texts, widths, heights, high
 
 

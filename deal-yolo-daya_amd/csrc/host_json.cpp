@@ -1004,6 +1004,11 @@ struct dyd_scan {
     Raw<double> f_xy;
     Raw<int32_t> f_pt_off;
     Raw<char> f_text;
+    // replace -> IoU pipeline (dyd_json_replace_iou): per-cell flag, totals, phase times (the slowest part's)
+    bool pipelined = false;
+    std::vector<uint8_t> high;
+    int64_t tot_boxes = 0, tot_points = 0;
+    double t_scan = 0, t_device = 0, t_emit = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -1242,6 +1247,136 @@ int dyd_json_scan_polygons_v(const uint8_t *const *cell_ptr, const int64_t *cell
     CellSrc src;
     src.ptr = cell_ptr; src.len = cell_len;
     return scan_polygons_src(src, missing, n_cells, n_threads, out);
+}
+
+// The replace step and the IoU step in one native pass (reference processor.py:262-281 then :341-376; the processing page runs
+// them back to back, ui/pages/processing.py:580-598).  The cell range is cut into one part per thread and every thread takes its
+// part through all three stages on its own — single-parse scan, ONE fused K1+K2 launch on the part's arrays (dyd_bbox_iou_fused:
+// staged straight from the part's buffers, no gathered copy of the points), segment emit — and frees the part's point and segment
+// buffers before it returns.  What stays in the handle: per cell status / flag / width / height / iou_host, and per part the
+// emitted text (dyd_scan_part), which dyd_scan_text gathers into one buffer on request.
+int dyd_json_replace_iou(const uint8_t *text, const int64_t *cell_off, const uint8_t *const *cell_ptr, const int64_t *cell_len,
+                         const uint8_t *missing, int64_t n_cells, int32_t min_boxes, double thr, int n_threads, dyd_scan **out) {
+    if (!out || n_cells < 0) return DYD_ERR_INVALID;
+    CellSrc src;
+    if (cell_ptr && cell_len) { src.ptr = cell_ptr; src.len = cell_len; }
+    else if (cell_off) { src.text = text; src.off = cell_off; }
+    else if (n_cells > 0) return DYD_ERR_INVALID;
+    dyd_scan *h = new (std::nothrow) dyd_scan();
+    if (!h) return DYD_ERR_OOM;
+    const bool use_fast = use_fast_lane();
+    int first_rc = DYD_OK;
+    try {
+        init_polygon_handle(h, n_cells, n_threads, src);
+        h->pipelined = true;
+        h->high.assign((size_t)n_cells, 0);
+        std::vector<double> ts((size_t)h->parts.size() * 3, 0.0);
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                FastPart &A = *h->parts[(size_t)k];
+                auto t0 = std::chrono::steady_clock::now();
+                scan_part(h, src, missing, A, use_fast);
+                const size_t nb = A.npts.n, ncell = (size_t)(A.hi - A.lo);
+                Raw<int32_t> pt_off, box_off, arg4;
+                pt_off.need(nb + 1);
+                box_off.need(ncell + 1);
+                int64_t run = 0;
+                pt_off.p[0] = 0;
+                for (size_t b = 0; b < nb; ++b) { run += A.npts.p[b]; pt_off.p[b + 1] = (int32_t)run; }
+                int64_t runb = 0;
+                box_off.p[0] = 0;
+                for (size_t c = 0; c < ncell; ++c) { runb += A.cell_boxes.p[c]; box_off.p[c + 1] = (int32_t)runb; }
+                arg4.need(4 * nb + 4);
+                auto t1 = std::chrono::steady_clock::now();
+                int rc = (run >= ((int64_t)1 << 31)) ? DYD_ERR_RANGE : DYD_OK;
+                if (!rc && ncell)
+                    rc = dyd_bbox_iou_fused(A.xy.p, pt_off.p, box_off.p, (int64_t)ncell, min_boxes, thr, nullptr, arg4.p,
+                                            h->high.data() + A.lo);
+                auto t2 = std::chrono::steady_clock::now();
+                if (rc) {
+                    int expected = DYD_OK;
+                    __atomic_compare_exchange_n(&first_rc, &expected, rc, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+                    return;
+                }
+                A.xyv = A.xy.p;
+                A.ptv = pt_off.p;
+                A.ptv_bias = 0;
+                if (!emit_part(h, src, A, arg4.p)) {
+                    int expected = DYD_OK;
+                    __atomic_compare_exchange_n(&first_rc, &expected, DYD_ERR_INVALID, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+                }
+                A.box_base = nb;                 // totals are summed below
+                A.pt_base = (size_t)run;
+                A.xyv = nullptr; A.ptv = nullptr;
+                A.xy.clear_free(); A.isint.clear_free(); A.npts.clear_free(); A.hole.clear_free(); A.seg.clear_free();
+                A.seg_off.clear_free(); A.lane_count = 0;
+                for (size_t c = 0; c < A.lane.n; ++c) A.lane_count += A.lane.p[c];
+                A.lane.clear_free();
+                auto t3 = std::chrono::steady_clock::now();
+                ts[(size_t)k * 3 + 0] = std::chrono::duration<double>(t1 - t0).count();
+                ts[(size_t)k * 3 + 1] = std::chrono::duration<double>(t2 - t1).count();
+                ts[(size_t)k * 3 + 2] = std::chrono::duration<double>(t3 - t2).count();
+            }))
+            throw std::bad_alloc();
+        if (first_rc) { delete h; return first_rc; }
+        for (size_t k = 0; k < h->parts.size(); ++k) {
+            h->tot_boxes += (int64_t)h->parts[k]->box_base;
+            h->tot_points += (int64_t)h->parts[k]->pt_base;
+            h->t_scan = std::max(h->t_scan, ts[k * 3]);
+            h->t_device = std::max(h->t_device, ts[k * 3 + 1]);
+            h->t_emit = std::max(h->t_emit, ts[k * 3 + 2]);
+            // per part offsets of the emitted text (cells + 1 entries) for dyd_scan_part
+            FastPart &A = *h->parts[k];
+            const size_t ncell = (size_t)(A.hi - A.lo);
+            A.out_off.need(ncell + 1);
+            A.out_off.p[0] = 0;
+            for (size_t c = 0; c < ncell; ++c) A.out_off.p[c + 1] = A.out_off.p[c] + A.out_len.p[c];
+            A.out_off.n = ncell + 1;
+        }
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return DYD_ERR_OOM;
+    }
+    *out = h;
+    return DYD_OK;
+}
+
+const uint8_t *dyd_scan_high(const dyd_scan *h) { return (h && h->pipelined) ? h->high.data() : nullptr; }
+int32_t dyd_scan_parts(const dyd_scan *h) { return h ? (int32_t)h->parts.size() : 0; }
+// part k covers cells [*lo, *hi); its emitted text is text[off[c - *lo] .. off[c - *lo + 1]) (empty for cells that are not regular)
+int dyd_scan_part(const dyd_scan *h, int32_t k, int64_t *lo, int64_t *hi, const uint8_t **text, const int64_t **off) {
+    if (!h || !h->pipelined || k < 0 || (size_t)k >= h->parts.size() || !lo || !hi || !text || !off) return DYD_ERR_INVALID;
+    const FastPart &A = *h->parts[(size_t)k];
+    if (!A.out_off.n) return DYD_ERR_INVALID;   // already gathered by dyd_scan_text
+    *lo = A.lo; *hi = A.hi;
+    *text = reinterpret_cast<const uint8_t *>(A.out.p);
+    *off = A.out_off.p;
+    return DYD_OK;
+}
+// the parts' texts as one buffer + offsets [n_cells + 1] (for the CSV writer); the per-part views end here
+int dyd_scan_text(dyd_scan *h, const uint8_t **text, const int64_t **off) {
+    if (!h || !h->pipelined || !text || !off) return DYD_ERR_INVALID;
+    try {
+        if (h->text_off.empty()) {
+            if (!gather_text(h)) return DYD_ERR_OOM;
+            for (auto &pp : h->parts) pp->out_off.clear_free();
+        }
+    } catch (const std::bad_alloc &) {
+        return DYD_ERR_OOM;
+    }
+    *text = reinterpret_cast<const uint8_t *>(h->f_text.p);
+    *off = h->text_off.data();
+    return DYD_OK;
+}
+// n_boxes, n_points, fast-lane cells, and the slowest part's seconds in scan / device stage / emit
+void dyd_scan_totals(const dyd_scan *h, int64_t *counts3, double *seconds3) {
+    if (!h) return;
+    if (counts3) {
+        counts3[0] = h->tot_boxes; counts3[1] = h->tot_points;
+        int64_t lanes = 0;
+        for (const auto &pp : h->parts) lanes += pp->lane_count;
+        counts3[2] = lanes;
+    }
+    if (seconds3) { seconds3[0] = h->t_scan; seconds3[1] = h->t_device; seconds3[2] = h->t_emit; }
 }
 
 int64_t dyd_scan_n_boxes(const dyd_scan *h) { return h ? (h->fast ? (int64_t)h->f_pt_off.n - 1 : (int64_t)h->pt_off.size() - 1) : 0; }

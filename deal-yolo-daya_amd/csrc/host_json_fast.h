@@ -58,6 +58,8 @@ struct FastPart {
     // pass 2
     Raw<char> out;
     Raw<int64_t> out_len;            // per cell
+    Raw<int64_t> out_off;            // pipeline: prefix of out_len (cells + 1)
+    int64_t lane_count = 0;          // pipeline: cells this lane took (kept after `lane` is freed)
     size_t box_base = 0, pt_base = 0;  // global index of the part's first box / point
 };
 

@@ -164,6 +164,97 @@ class PolygonScan(_Scan):
         return out
 
 
+class ReplaceIou:
+    """Result of the native replace -> IoU pipeline (dyd_json_replace_iou): per-cell status / HIGH flag / width / height and
+    the emitted bbox text, per part or gathered.  Cells with status IRREGULAR, and cells with ``iou_host`` set, are the caller's."""
+
+    def __init__(self, handle, n_cells, keep):
+        L = _native.load_library()
+        self._h, self._keep, self.n_cells = handle, keep, n_cells
+        self.status = _view(L.dyd_scan_status(handle), np.uint8, n_cells).copy()
+        self.high = _view(L.dyd_scan_high(handle), np.uint8, n_cells).astype(bool)
+        self.iou_host = _view(L.dyd_scan_iou_host(handle), np.uint8, n_cells).copy()
+        self.w_kind = _view(L.dyd_scan_wh_kind(handle, 0), np.uint8, n_cells).copy()
+        self.h_kind = _view(L.dyd_scan_wh_kind(handle, 1), np.uint8, n_cells).copy()
+        self.w_val = _view(L.dyd_scan_wh_value(handle, 0), np.float64, n_cells).copy()
+        self.h_val = _view(L.dyd_scan_wh_value(handle, 1), np.float64, n_cells).copy()
+        counts, secs = np.zeros(3, np.int64), np.zeros(3, np.float64)
+        L.dyd_scan_totals(handle, counts.ctypes.data, secs.ctypes.data)
+        self.n_boxes, self.n_points, self.fast_cells = (int(v) for v in counts)
+        self.n_parts = int(L.dyd_scan_parts(handle))          # = fused launches: one per worker thread's share of the cells
+        self.seconds = {"scan": float(secs[0]), "device": float(secs[1]), "emit": float(secs[2])}
+
+    wh_column = PolygonScan.wh_column
+    width_height = PolygonScan.width_height
+
+    def texts_array(self) -> np.ndarray:
+        """object array: bbox text (str) for regular cells, None elsewhere — str objects made part by part, straight from the
+        parts' buffers (no gathered copy of the text)"""
+        from . import pycells
+
+        L = _native.load_library()
+        out = np.empty(self.n_cells, object)
+        na = (self.status != OK).astype(np.uint8)
+        for k in range(int(L.dyd_scan_parts(self._h))):
+            lo, hi, text, off = C.c_int64(), C.c_int64(), C.c_void_p(), C.c_void_p()
+            _native.check(L.dyd_scan_part(self._h, k, C.byref(lo), C.byref(hi), C.byref(text), C.byref(off)), "dyd_scan_part")
+            n = hi.value - lo.value
+            if n == 0:
+                continue
+            offs = _view(off.value, np.int64, n + 1)
+            if pycells.available():
+                pycells._dydpy.strs_from_utf8(text.value or 0, offs.ctypes.data, n, na[lo.value:hi.value].ctypes.data,
+                                              out.ctypes.data + 8 * lo.value, host_threads())
+            else:
+                out[lo.value:hi.value] = strings_from_buffers(_view(text.value, np.uint8, int(offs[-1])), offs, na[lo.value:hi.value])
+        return out
+
+    def text_buffers(self) -> tuple:
+        """the emitted text of all cells as ONE flat utf-8 buffer + offsets (views into the handle)"""
+        L = _native.load_library()
+        text, off = C.c_void_p(), C.c_void_p()
+        _native.check(L.dyd_scan_text(self._h, C.byref(text), C.byref(off)), "dyd_scan_text")
+        offs = _view(off.value, np.int64, self.n_cells + 1)
+        return _view(text.value, np.uint8, int(offs[-1])), offs
+
+    def close(self):
+        if self._h:
+            _native.load_library().dyd_scan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def replace_iou(cells, min_boxes: int, thr: float, n_threads: int = 0) -> ReplaceIou:
+    """The native pipeline over a column of annotation cells (list / object ndarray / Series of str)."""
+    from . import pycells
+
+    L = _native.lib()                      # the pipeline launches kernels: needs the device
+    h = C.c_void_p()
+    if pycells.available():
+        v = pycells.CellViews(cells.to_numpy() if hasattr(cells, "to_numpy") else cells)
+        _native.check(L.dyd_json_replace_iou(None, None, v.ptr.ctypes.data, v.len.ctypes.data, v.missing.ctypes.data, len(v),
+                                             int(min_boxes), float(thr), n_threads, C.byref(h)), "dyd_json_replace_iou")
+        return ReplaceIou(h, len(v), v)
+    data, off, missing, keep = cells_to_buffers(cells)
+    _native.check(L.dyd_json_replace_iou(data.ctypes.data, off.ctypes.data, None, None, missing.ctypes.data, len(off) - 1,
+                                         int(min_boxes), float(thr), n_threads, C.byref(h)), "dyd_json_replace_iou")
+    return ReplaceIou(h, len(off) - 1, (keep, data, off, missing))
+
+
+def replace_iou_buffers(data, off, missing, min_boxes: int, thr: float, n_threads: int = 0, keep=None) -> ReplaceIou:
+    """the same over cells that already are flat utf-8 (fastcsv.Utf8Column)"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    missing = np.ascontiguousarray(missing, dtype=np.uint8)
+    L = _native.lib()
+    h = C.c_void_p()
+    _native.check(L.dyd_json_replace_iou(data.ctypes.data, off.ctypes.data, None, None, missing.ctypes.data, len(off) - 1,
+                                         int(min_boxes), float(thr), n_threads, C.byref(h)), "dyd_json_replace_iou")
+    return ReplaceIou(h, len(off) - 1, (keep, data, off, missing))
+
+
 class BoxScan(_Scan):
     def __init__(self, handle, n_cells, keep):
         super().__init__(handle, n_cells, keep)

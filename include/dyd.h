@@ -277,6 +277,19 @@ int dyd_json_scan_polygons_v(const uint8_t *const *cell_ptr, const int64_t *cell
 int dyd_json_scan_labelled(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
                            const uint8_t *label_text, const int64_t *label_off, int n_threads, dyd_scan **out);
 const uint8_t *dyd_scan_sel(const dyd_scan *scan);             /* [n_boxes] (labelled scan only) */
+/* The replace step and the IoU step in ONE native pass (processor.py:262-281 then :341-376; ui/pages/processing.py:580-598 runs them
+ * back to back): cells as flat text + offsets, or as one (pointer, length) pair per cell (text == cell_off == NULL).  Every worker
+ * thread takes its share of the cells through scan, ONE dyd_bbox_iou_fused launch on its own arrays and emit.  The handle then
+ * holds per cell: dyd_scan_status, dyd_scan_high (the IoU step's flag, meaningful for status 0 cells; the caller decides cells with
+ * dyd_scan_iou_host != 0 and status 2 cells itself), dyd_scan_wh_*; and the emitted text per part (dyd_scan_part) or gathered
+ * (dyd_scan_text).  Needs the device (no CPU fallback). */
+int dyd_json_replace_iou(const uint8_t *text, const int64_t *cell_off, const uint8_t *const *cell_ptr, const int64_t *cell_len,
+                         const uint8_t *missing, int64_t n_cells, int32_t min_boxes, double thr, int n_threads, dyd_scan **out);
+const uint8_t *dyd_scan_high(const dyd_scan *scan);            /* [n_cells] */
+int32_t dyd_scan_parts(const dyd_scan *scan);
+int dyd_scan_part(const dyd_scan *scan, int32_t k, int64_t *lo, int64_t *hi, const uint8_t **text, const int64_t **off);
+int dyd_scan_text(dyd_scan *scan, const uint8_t **text, const int64_t **off);
+void dyd_scan_totals(const dyd_scan *scan, int64_t *counts3, double *seconds3);   /* boxes, points, fast-lane cells | scan, device, emit s */
 void dyd_scan_free(dyd_scan *scan);
 /* measurement / test aid (host, multithreaded): the annotation cells of a synthetic table as json.dumps would write them
  * (deal-yolo-daya_amd/synth.py: row_json) — flat utf-8 in *out_text (release with dyd_host_free) and offsets [n_rows+1]. */

@@ -449,3 +449,45 @@ def test_a_full_hash_table_is_an_error_not_a_wrong_mask(native):
         native.check(L.dyd_set_option(b"k4_capacity_shift", 0), "opt")
     assert np.array_equal(native.dedup(h, "first"), olib.dedup(h, 0))
     assert L.dyd_device_status(None) == 0
+
+
+def test_native_pipeline_equals_the_stepwise_route(native, monkeypatch):
+    """replace_and_filter_frame through dyd_json_replace_iou (per-part scan / fused launch / emit) and with DYD_NATIVE_PIPELINE=0
+    (scan -> one gathered launch -> emit) on fuzzed cells incl. irregular, undecodable, NaN and big-int ones: identical frames"""
+    import json as _json
+    import random
+
+    import pandas as pd
+    from test_native_json_cpu import Gen
+    from deal_yolo_daya_amd import synth
+    from deal_yolo_daya_amd.core import processor as P
+    from oracle import steps as osteps
+
+    cells = []
+    for s in range(4000):
+        try:
+            c = Gen(5000 + s).cell()
+            osteps.replace_cell(c)                    # keep the cells the replace step survives (the others raise: tested elsewhere)
+            cells.append(c)
+        except Exception:  # noqa: BLE001
+            pass
+    t = synth.generate(3000, seed=9)
+    cells += synth.json_cells(t).tolist()
+    cells += [None, float("nan"), 7, "", " "]
+    random.Random(1).shuffle(cells)
+    df = pd.DataFrame({"source": [f"u{i}" for i in range(len(cells))], P.ANNOTATION_COL: pd.Series(cells, dtype=object)})
+    for mb, thr in ((2, 0.98), (3, 0.5)):
+        stats = {}
+        a = P.replace_and_filter_frame(df, mb, thr, stats=stats)
+        assert stats.get("native_pipeline", 0) >= 1
+        monkeypatch.setenv("DYD_NATIVE_PIPELINE", "0")
+        stats2 = {}
+        b = P.replace_and_filter_frame(df, mb, thr, stats=stats2)
+        monkeypatch.delenv("DYD_NATIVE_PIPELINE")
+        assert "native_pipeline" not in stats2
+        for x, y in zip(a, b):
+            pd.testing.assert_frame_equal(x, y)
+        okept, oproj, _ = osteps.replace_frame(df)
+        ohi, _ = osteps.iou_filter_frame(oproj, mb, thr)
+        assert a[0][P.BBOX_COL].tolist() == okept[osteps.NEW_COL].tolist()
+        assert a[2]["source"].tolist() == ohi["source"].tolist()

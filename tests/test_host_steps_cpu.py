@@ -153,7 +153,7 @@ def run_chain_golden(backend, tmp_path):
         df = pd.read_csv(Q("in.csv"), encoding="utf-8-sig")
         stats = {}
         kept, excluded, high, other = P.replace_and_filter_frame(df, run["min_boxes"], run["thr"], backend, stats)
-        assert stats["fused_launches"] == 1 and stats["host_rows"] >= 1            # big_ints_* rows: CPython decides
+        assert stats["fused_launches"] >= 1 and stats["host_rows"] >= 1            # big_ints_* rows: CPython decides
         want_hi = pd.read_csv(Q("hi.csv"), encoding="utf-8-sig", dtype={"source": str})["source"].tolist()
         assert high["source"].tolist() == want_hi and len(high) + len(other) == len(kept) == g["result"]["filtered_rows"]
         assert kept[P.BBOX_COL].isna().sum() == 2 and len(excluded) == 1
