@@ -511,11 +511,16 @@ def _replace_csv_core(input_csv_path, backend, fuse=None):
         else:
             arg4 = np.zeros((0, 4), np.int32)
         text, off = scan.emit_buffers(arg4)
-    widths, heights = scan.width_height(0), scan.width_height(1)
-    for col, key in ((widths, "width"), (heights, "height")):
-        for i, v in enumerate(col):
-            if v is Ellipsis:
-                col[i] = json.loads(ann.cell(i)).get(key)
+    # width / height of the kept rows: numpy columns when every kept cell is plain (ints / floats / nothing), else the per-cell
+    # lists whose dtype pandas infers like the reference's `filtered_df["width"] = [...]` (:295-296)
+    plain_wh = len(irregular) == 0 and len(kept_rows) > 0 and not (scan.w_kind[kept_rows] == 3).any() \
+        and not (scan.h_kind[kept_rows] == 3).any() and scan.w_kind[kept_rows].any() and scan.h_kind[kept_rows].any()
+    if not plain_wh:
+        widths, heights = scan.width_height(0), scan.width_height(1)
+        for col, key in ((widths, "width"), (heights, "height")):
+            for i, v in enumerate(col):
+                if v is Ellipsis:
+                    col[i] = json.loads(ann.cell(i)).get(key)
     new_na = (scan.status != _nj.OK).astype(np.uint8)
     if fuse is not None:
         high[scan.status != _nj.OK] = False               # no bbox text -> a NaN cell -> no boxes (:344-345)
@@ -537,8 +542,18 @@ def _replace_csv_core(input_csv_path, backend, fuse=None):
         new_col = _fc.Utf8Column(spec[1], spec[2], spec[3])
     else:
         new_col = _fc.Utf8Column(text, off, new_na, scan)
-    kw = pd.Series([widths[i] for i in kept_rows.tolist()])     # dtype inference of `kept["width"] = list` (:295)
-    kh = pd.Series([heights[i] for i in kept_rows.tolist()])
+    if plain_wh:
+        def _col(kind, val):
+            kind, val = kind[kept_rows], val[kept_rows]
+            if (kind == 1).all():
+                return pd.Series(val.astype(np.int64))
+            out = val.copy()
+            out[kind == 0] = np.nan
+            return pd.Series(out)
+        kw, kh = _col(scan.w_kind, scan.w_val), _col(scan.h_kind, scan.h_val)
+    else:
+        kw = pd.Series([widths[i] for i in kept_rows.tolist()])     # dtype inference of `kept["width"] = list` (:295)
+        kh = pd.Series([heights[i] for i in kept_rows.tolist()])
     full_w = pd.Series(np.full(table.n_rows, np.nan, dtype=object) if kw.dtype == object else np.zeros(table.n_rows, kw.dtype))
     full_h = pd.Series(np.full(table.n_rows, np.nan, dtype=object) if kh.dtype == object else np.zeros(table.n_rows, kh.dtype))
     full_w.iloc[kept_rows] = kw.to_numpy()
