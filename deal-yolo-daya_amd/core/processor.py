@@ -820,7 +820,7 @@ def _native_pipeline(be) -> bool:
     return be is _nat and os.environ.get("DYD_NATIVE_PIPELINE", "1") != "0"
 
 
-def _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals):
+def _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals, arrow: bool = False):
     """one batch through dyd_json_replace_iou: every worker thread scans its share of the cells, launches the fused kernel on its
     own arrays and emits — no gathered copies.  Returns None when the cells cannot be viewed (lone surrogate): the caller's
     stepwise route handles that."""
@@ -836,7 +836,9 @@ def _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals):
     # irregular cells: the only ones that can raise; nothing has been handed out yet
     py = _replace_cells_python([cells[i] for i in irregular.tolist()], be, totals) if len(irregular) else ([], [], [])
     t2 = _t.perf_counter()
-    texts = r.texts_array()
+    needs_objects = len(irregular) > 0 or bool(((r.iou_host != 0) & (r.status == _nj.OK)).any())
+    as_arrow = arrow and not needs_objects          # cells the host must patch or re-read need str objects
+    texts = r.texts_arrow() if as_arrow else r.texts_array()
     t3 = _t.perf_counter()
     high = r.high.copy()
     plain = len(irregular) == 0
@@ -857,7 +859,8 @@ def _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals):
     totals["fused_launches"] += r.n_parts
     totals["fast_cells"] += r.fast_cells
     t4 = _t.perf_counter()
-    r.close()
+    if not as_arrow:
+        r.close()                                  # (an Arrow column lives on the handle's buffers and keeps it alive)
     for k, v in (("s_pipeline", t1 - t0), ("s_python_cells", t2 - t1), ("s_strings", t3 - t2), ("s_fixups", t4 - t3),
                  ("s_release", _t.perf_counter() - t4), ("s_part_scan", r.seconds["scan"]), ("s_part_device", r.seconds["device"]),
                  ("s_part_emit", r.seconds["emit"])):
@@ -878,14 +881,19 @@ def _join_columns(parts):
     return out
 
 
-def _replace_and_filter_arrays(cells, min_boxes, iou_threshold, be, totals):
-    """cells: object ndarray / list.  -> (texts object array, widths, heights, high) over all batches"""
+def _replace_and_filter_arrays(cells, min_boxes, iou_threshold, be, totals, arrow: bool = False):
+    """cells: object ndarray / list.  -> (texts object array — or a pandas ArrowStringArray when `arrow` and one native batch
+    without host-decided cells covers the column —, widths, heights, high) over all batches"""
     if not _nj.enabled():                              # DYD_NATIVE_JSON=0: the two steps in sequence on the CPython flatten
         totals["python_cells"] = len(cells)
         texts, widths, heights = _replace_cells_python(list(cells), be, totals)
         arr = np.empty(len(texts), object)
         arr[:] = texts
         return arr, widths, heights, _iou_mask_python(texts, min_boxes, iou_threshold, be, totals)
+    if arrow and _native_pipeline(be) and 0 < len(cells) <= _NATIVE_CHUNK_CELLS:
+        res = _replace_iou_cells_pipeline(cells, min_boxes, iou_threshold, be, totals, arrow=True)
+        if res is not None:
+            return res
     t_p, w_p, h_p, m_p = [], [], [], []
     for start in range(0, len(cells), _NATIVE_CHUNK_CELLS):
         t, w, h, m = _replace_iou_cells_native(cells[start:start + _NATIVE_CHUNK_CELLS], min_boxes, iou_threshold, be, totals)
@@ -911,11 +919,13 @@ def replace_and_filter_cells(cells, min_boxes: int = 2, iou_threshold: float = 0
 
 
 def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None,
-                             stats: Optional[dict] = None):
+                             stats: Optional[dict] = None, text_dtype: str = "object"):
     """In-memory twin of replace_ptlist -> iou_filter run back to back:
     -> (kept frame with the three new columns, excluded rows, HIGH rows of kept, other rows of kept).
     The annotation cells are read in place (UTF-8 views of the column's str objects) and the new column's str objects are
-    created natively, so no per-cell Python work remains for regular cells."""
+    created natively, so no per-cell Python work remains for regular cells.  ``text_dtype="arrow"`` returns the new bbox column
+    as pandas' Arrow-backed ``string`` dtype laid directly over the emitter's buffers (no str objects at all; same values,
+    missing cells are ``pd.NA`` instead of ``None``) — the default keeps the reference's object column of str."""
     import time as _t
     be = _backend(backend)
     t0 = _t.perf_counter()
@@ -925,9 +935,13 @@ def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold
     totals = {"cells": len(kept), "boxes": 0, "points": 0, "host_boxes": 0, "host_rows": 0, "python_cells": 0,
               "fused_launches": 0, "fast_cells": 0}
     t1 = _t.perf_counter()
-    texts, widths, heights, high = _replace_and_filter_arrays(kept[ANNOTATION_COL].to_numpy(), min_boxes, iou_threshold, be, totals)
+    if text_dtype not in ("object", "arrow"):
+        raise ValueError('text_dtype must be "object" or "arrow"')
+    texts, widths, heights, high = _replace_and_filter_arrays(kept[ANNOTATION_COL].to_numpy(), min_boxes, iou_threshold, be, totals,
+                                                              arrow=(text_dtype == "arrow"))
     t2 = _t.perf_counter()
-    kept[BBOX_COL] = pd.Series(texts, index=kept.index, dtype=object)
+    kept[BBOX_COL] = (pd.Series(texts, index=kept.index, dtype=object) if isinstance(texts, np.ndarray)
+                      else pd.Series(texts, index=kept.index))
     kept["width"] = widths
     kept["height"] = heights
     out = (kept, excluded, kept[high], kept[~high])

@@ -278,12 +278,16 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     return launch_null_fix(out_arg4, out_box4, box_off, n_rows, n_boxes, min_boxes, thr, out_high, st);
 }
 
-// Host-pointer twin: stages the three input arrays, runs the fused launch on the library's stream and copies back the arg
-// indices (what the JSON emitter needs), the flags and — only when asked for — the boxes.
+// Host-pointer twin: stages the three input arrays, runs the fused launch and copies back the arg indices (what the JSON emitter
+// needs), the flags and — only when asked for — the boxes.  It works on a stream of its own and holds the library's lock only
+// while the kernels are queued, so the worker threads of the native replace -> IoU pipeline (host_json.cpp: one call per
+// thread's share of the cells) stage and copy side by side.
 int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows, int32_t min_boxes,
                        double thr, double *out_box4_or_null, int32_t *out_arg4, uint8_t *out_high) {
-    DYD_API_ENTER();
-    DYD_REQUIRE(n_rows >= 0, "n_rows < 0");
+    {
+        DYD_API_ENTER();   // context + device binding for this thread; released before the copies
+    }
+    if (n_rows < 0) { set_error("invalid argument: n_rows < 0"); return DYD_ERR_INVALID; }
     if (n_rows == 0) return DYD_OK;
     DYD_REQUIRE(pt_off && box_off && out_high, "null pointer");
     DYD_REQUIRE(box_off[0] == 0 && pt_off[0] == 0, "offsets must start at 0");
@@ -293,27 +297,45 @@ int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *b
     const int64_t n_pts = pt_off[n_boxes];
     DYD_REQUIRE(n_pts == 0 || xy, "xy is null");
     DYD_REQUIRE(n_boxes == 0 || out_arg4, "out_arg4 is null");
+    struct OwnStream {
+        hipStream_t s = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~OwnStream() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } own;
+    DYD_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
+    DYD_HIP(hipEventCreate(&own.e0));
+    DYD_HIP(hipEventCreate(&own.e1));
+    hipStream_t st = own.s;
     DevBuf d_xy, d_po, d_bo, d_box, d_arg, d_high;
     int rc;
     if ((rc = d_xy.alloc(16 * (size_t)n_pts)) || (rc = d_po.alloc(4 * (size_t)(n_boxes + 1))) ||
         (rc = d_bo.alloc(4 * (size_t)(n_rows + 1))) || (rc = d_box.alloc(32 * (size_t)n_boxes)) ||
         (rc = d_arg.alloc(16 * (size_t)n_boxes)) || (rc = d_high.alloc((size_t)n_rows)))
         return rc;
-    hipStream_t st = ctx().stream;
     if (n_pts) DYD_HIP(hipMemcpyAsync(d_xy.p, xy, 16 * (size_t)n_pts, hipMemcpyHostToDevice, st));
     DYD_HIP(hipMemcpyAsync(d_po.p, pt_off, 4 * (size_t)(n_boxes + 1), hipMemcpyHostToDevice, st));
     DYD_HIP(hipMemcpyAsync(d_bo.p, box_off, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice, st));
-    KernelTimer t(st);
+    DYD_HIP(hipEventRecord(own.e0, st));
     rc = dyd_bbox_iou_fused_dev(d_xy.as<double>(), d_po.as<int32_t>(), d_bo.as<int32_t>(), n_rows, n_boxes, n_pts, min_boxes, thr,
-                                d_box.as<double>(), d_arg.as<int32_t>(), d_high.as<uint8_t>(), st);
-    if (rc) return rc;
-    t.finish();
+                                d_box.as<double>(), d_arg.as<int32_t>(), d_high.as<uint8_t>(), st);   // takes the lock while it queues
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    DYD_HIP(hipEventRecord(own.e1, st));
     if (n_boxes) DYD_HIP(hipMemcpyAsync(out_arg4, d_arg.p, 16 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
     if (n_boxes && out_box4_or_null) DYD_HIP(hipMemcpyAsync(out_box4_or_null, d_box.p, 32 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipMemcpyAsync(out_high, d_high.p, (size_t)n_rows, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, own.e0, own.e1) == hipSuccess) set_last_kernel_ms(ms);
     return DYD_OK;
 }
+
+}  // extern "C"
+
+extern "C" {
 
 // Tuning / A-B hook (not part of the reference-facing ABI): selects kernel variants.
 int dyd_set_option(const char *key, int64_t value) {

@@ -209,6 +209,30 @@ class ReplaceIou:
                 out[lo.value:hi.value] = strings_from_buffers(_view(text.value, np.uint8, int(offs[-1])), offs, na[lo.value:hi.value])
         return out
 
+    def texts_arrow(self):
+        """the bbox column as a pandas ArrowStringArray (dtype "string", pyarrow storage; missing where a cell is not regular)
+        built straight ON the parts' buffers: no str objects, no copy.  The arrays keep this object — and so the native
+        handle — alive; do not call close() while they are in use."""
+        import pandas as pd
+        import pyarrow as pa
+
+        L = _native.load_library()
+        chunks = []
+        valid_all = self.status == OK
+        for k in range(int(L.dyd_scan_parts(self._h))):
+            lo, hi, text, off = C.c_int64(), C.c_int64(), C.c_void_p(), C.c_void_p()
+            _native.check(L.dyd_scan_part(self._h, k, C.byref(lo), C.byref(hi), C.byref(text), C.byref(off)), "dyd_scan_part")
+            n = hi.value - lo.value
+            if n == 0:
+                continue
+            total = int(_view(off.value, np.int64, n + 1)[-1])
+            valid = valid_all[lo.value:hi.value]
+            bufs = [None if valid.all() else pa.py_buffer(np.packbits(valid, bitorder="little")),
+                    pa.foreign_buffer(off.value, 8 * (n + 1), base=self),
+                    pa.foreign_buffer(text.value, total, base=self) if total else pa.py_buffer(b"")]
+            chunks.append(pa.LargeStringArray.from_buffers(n, bufs[1], bufs[2], bufs[0], -1 if bufs[0] is not None else 0))
+        return pd.arrays.ArrowStringArray(pa.chunked_array(chunks, type=pa.large_string()))
+
     def text_buffers(self) -> tuple:
         """the emitted text of all cells as ONE flat utf-8 buffer + offsets (views into the handle)"""
         L = _native.load_library()

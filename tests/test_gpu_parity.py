@@ -493,3 +493,26 @@ def test_native_pipeline_equals_the_stepwise_route(native, monkeypatch):
         ohi, _ = osteps.iou_filter_frame(oproj, mb, thr)
         assert a[0][P.BBOX_COL].tolist() == okept[osteps.NEW_COL].tolist()
         assert a[2]["source"].tolist() == ohi["source"].tolist()
+
+
+def test_arrow_backed_bbox_column_holds_the_same_values(native):
+    """replace_and_filter_frame(text_dtype="arrow"): the bbox column laid over the emitter's buffers (pandas string dtype,
+    pyarrow storage) equals the object column value for value, survives the function's locals, and writes the same CSV"""
+    import gc
+
+    import pandas as pd
+    from deal_yolo_daya_amd import synth
+    from deal_yolo_daya_amd.core import processor as P
+
+    t = synth.generate(5000, seed=21)
+    cells = synth.json_cells(t)
+    cells[17], cells[4000] = '{"objects": [', None              # an undecodable cell and a missing one
+    df = pd.DataFrame({"source": synth.urls(t), P.ANNOTATION_COL: cells})
+    ko, _, ho, _ = P.replace_and_filter_frame(df, 2, 0.98)
+    ka, _, ha, oa = P.replace_and_filter_frame(df, 2, 0.98, text_dtype="arrow")
+    gc.collect()
+    assert str(ka[P.BBOX_COL].dtype) == "string" and ko[P.BBOX_COL].dtype == object
+    assert ka[P.BBOX_COL].isna().tolist() == ko[P.BBOX_COL].isna().tolist() and int(ka[P.BBOX_COL].isna().sum()) == 1
+    assert ka[P.BBOX_COL].dropna().tolist() == ko[P.BBOX_COL].dropna().tolist()
+    assert ha["source"].tolist() == ho["source"].tolist() and len(ha) + len(oa) == len(ka)
+    assert ka.to_csv(index=False) == ko.to_csv(index=False)

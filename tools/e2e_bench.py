@@ -52,6 +52,15 @@ def main():
                           "phases_s": {k: round(v, 3) for k, v in stats.items() if k.startswith("s_")},
                           "fast_cells": stats.get("fast_cells"), "python_cells": stats.get("python_cells"),
                           "out_bytes": out_bytes, "kernel_ms": round(_native.last_kernel_ms(), 3)}), flush=True)
+    for rep in range(2):      # the same with the bbox column as pandas' Arrow-backed string dtype (no str objects)
+        stats = {}
+        a = time.perf_counter()
+        kept, excluded, high, other = P.replace_and_filter_frame(df, 2, 0.98, stats=stats, text_dtype="arrow")
+        dt = time.perf_counter() - a
+        print(json.dumps({"text_dtype": "arrow", "bbox_dtype": str(kept[P.BBOX_COL].dtype), "rows": len(df), "seconds": round(dt, 3),
+                          "rows_per_s": round(len(df) / dt), "high": len(high),
+                          "phases_s": {k: round(v, 3) for k, v in stats.items() if k.startswith("s_")}}), flush=True)
+        del kept, excluded, high, other
     if args.csv:
         os.makedirs(args.dir, exist_ok=True)
         Q = lambda n: os.path.join(args.dir, n)  # noqa: E731
