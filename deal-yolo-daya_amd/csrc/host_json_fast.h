@@ -607,13 +607,46 @@ struct FastCell {
     }
 };
 
+// repr(v) for a double that is the nearest one to a decimal with k <= 4 fractional digits and fewer than 15 significant ones
+// (coordinates usually are: pixels with a couple of decimals): c = round(v * 10^k) as an integer; if c / 10^k — one correctly
+// rounded division of exact operands — gives v back, that decimal round-trips, and a decimal of at most 15 significant digits
+// that round-trips IS the shortest one (two different such decimals never share a double), so repr(v) is c with the point put
+// in and trailing zeros dropped.  Returns 0 when v is not of that kind (the caller then formats it the general way).
+inline size_t fj_put_short_float(char *dst, double v) {
+    const double a = v < 0 ? -v : v;
+    if (!(a >= 1e-4 && a < 1e10)) return 0;   // keeps c below 1e14 and repr in fixed notation (zero and -0.0: the general way)
+    static const double p10[] = {1e1, 1e2, 1e3, 1e4};
+    for (int k = 1; k <= 4; ++k) {
+        const double scaled = a * p10[k - 1];
+        const int64_t c = (int64_t)(scaled + 0.5);
+        if ((double)c / p10[k - 1] != a) continue;
+        // digits of c, point k places from the right, trailing zeros of the fraction trimmed (one digit stays)
+        char tmp[24];
+        int nd = 0;
+        int64_t u = c;
+        do { tmp[nd++] = (char)('0' + u % 10); u /= 10; } while (u);
+        while (nd <= k) tmp[nd++] = '0';            // 0.05 -> c = 5: leading zeros up to the units digit
+        size_t o = 0;
+        if (v < 0) dst[o++] = '-';
+        for (int i = nd - 1; i >= k; --i) dst[o++] = tmp[i];
+        dst[o++] = '.';
+        int last = 0;                               // lowest fraction digit to print
+        while (last < k - 1 && tmp[last] == '0') ++last;
+        for (int i = k - 1; i >= last; --i) dst[o++] = tmp[i];
+        return o;
+    }
+    return 0;
+}
+
 // pass 2 helper: one coordinate printed from its value
 inline void fj_put_coord(Raw<char> &o, double v, bool is_int, std::string &tmp) {
+    o.need(32);
     if (is_int) {
-        o.need(24);
         o.n += fj_put_int(o.p + o.n, (int64_t)v);   // exact: |v| <= 2^53; -0.0 (the token "-0") prints as 0
         return;
     }
+    const size_t k = fj_put_short_float(o.p + o.n, v);
+    if (k) { o.n += k; return; }
     tmp.clear();
     append_py_float(tmp, v);
     o.put(tmp.data(), tmp.size());
