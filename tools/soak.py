@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the device kernels against the CPU oracle: fresh shapes and seeds every round, through the host entry
-points of the C ABI (K1, K2, K4, K5, K6, K7) and the fused device entry.  Stops at the first mismatch.
+points of the C ABI (K1, K2, K4, K5, K6, K7, K8), the fused device entry and the product's replace -> IoU pass on JSON cells.  Stops at the first mismatch.
     python tools/soak.py --seconds 240 [--seed N]"""
 import argparse
 import json
@@ -42,7 +42,7 @@ def main():
         rounds += 1
         seed = int(rng.integers(0, 2 ** 31))
         r = np.random.default_rng(seed)
-        what = rounds % 7
+        what = rounds % 9
         ctx = {"round": rounds, "seed": seed, "what": what}
         try:
             if what == 0:      # K1, all three kernels
@@ -112,6 +112,46 @@ def main():
                 want = olib.split_ids(cat, perm, cat_off, ntr, nva)
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "k6"
                 bump("k6")
+            elif what == 7:    # K8 + K6 from a seed: permutations of random sizes against numpy and the oracle's sequential loop
+                n = int(r.choice([1, 2, 3, 700, 40000, 33000, 250000, 1200000]))
+                n = int(r.integers(max(1, n // 2), n + 1))
+                seed8 = int(r.integers(0, 2 ** 32))
+                perm, inv = _native.mt19937_permutation_device(seed8, n, want_inverse=True)
+                assert np.array_equal(perm, np.random.RandomState(seed8).permutation(n)) and np.array_equal(inv[perm], np.arange(n)), ("k8", n)
+                n_cat = int(r.choice([1, 2, 5]))
+                cat = r.integers(-1, n_cat, int(r.integers(1, 400000))).astype(np.int32)
+                sizes = np.bincount(cat[cat >= 0], minlength=n_cat).astype(np.int64)
+                perm = np.concatenate([olib.mt19937_permutation(seed8, int(sz)) for sz in sizes])
+                cat_off = np.zeros(n_cat + 1, np.int64); np.cumsum(sizes, out=cat_off[1:])
+                ntr, nva = (sizes * 8 // 10).astype(np.int64), (sizes // 10).astype(np.int64)
+                got = _native.split_ids_seeded(cat, seed8, sizes, ntr, nva)
+                want = olib.split_ids(cat, perm, cat_off, ntr, nva)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "k8+k6"
+                bump("k8")
+            elif what == 8:    # the product's replace -> IoU pass on JSON cells: native pipeline == stepwise route == chain oracle
+                import pandas as pd
+                from deal_yolo_daya_amd import synth
+                from deal_yolo_daya_amd.core import processor as P
+                t = synth.generate(int(r.integers(1, 6000)), seed=seed, max_boxes=int(r.choice([2, 8, 32, 90])))
+                if r.random() < 0.5:          # plant empty polygons: the chain's prefix rule
+                    npts = np.diff(t.pt_off)
+                    kill = r.random(len(npts)) < 0.05
+                    keep_pt = np.repeat(~kill, npts)
+                    t.xy = t.xy[keep_pt]
+                    npts = np.where(kill, 0, npts)
+                    t.pt_off = np.concatenate([[0], np.cumsum(npts)]).astype(np.int32)
+                df = pd.DataFrame({"source": synth.urls(t), P.ANNOTATION_COL: synth.json_cells(t)})
+                mb, thr = int(r.choice([2, 3])), float(r.choice([0.98, 0.5]))
+                a1 = P.replace_and_filter_frame(df, mb, thr)
+                os.environ["DYD_NATIVE_PIPELINE"] = "0"
+                try:
+                    a2 = P.replace_and_filter_frame(df, mb, thr)
+                finally:
+                    del os.environ["DYD_NATIVE_PIPELINE"]
+                _, oarg, ohigh = olib.bbox_iou_chain(t.xy, t.pt_off, t.box_off, mb, thr)
+                assert a1[0][P.BBOX_COL].tolist() == a2[0][P.BBOX_COL].tolist(), "pipeline vs stepwise text"
+                assert a1[2].index.tolist() == a2[2].index.tolist() == np.flatnonzero(ohigh).tolist(), "pipeline / stepwise / oracle HIGH rows"
+                bump("replace_iou")
             else:              # K7, every kernel
                 n_rows, mbx = int(r.integers(1, 20000)), int(r.choice([1, 1, 2, 5, 40, 700]))
                 n_rows = min(n_rows, 400000 // mbx + 1)
