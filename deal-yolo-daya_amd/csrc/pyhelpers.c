@@ -144,7 +144,53 @@ static PyObject *strs_from_utf8(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+/* gather_utf8(ptr, len, off, n, out, n_threads): out[off[i] .. off[i] + len[i]) = the bytes at ptr[i] — the flat buffer K3 hashes,
+ * copied by worker threads without the GIL (the views come from str_views; off is the caller's prefix sum of len) */
+typedef struct {
+    const char *const *ptr;
+    const int64_t *len, *off;
+    char *out;
+    int64_t lo, hi;
+} gather_t;
+
+static void *gather_worker(void *arg) {
+    gather_t *w = (gather_t *)arg;
+    for (int64_t i = w->lo; i < w->hi; ++i)
+        if (w->len[i]) memcpy(w->out + w->off[i], w->ptr[i], (size_t)w->len[i]);
+    return NULL;
+}
+
+static PyObject *gather_utf8(PyObject *self, PyObject *args) {
+    unsigned long long a_ptr, a_len, a_off, a_out;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKKnKi", &a_ptr, &a_len, &a_off, &n, &a_out, &n_threads)) return NULL;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (n < 65536) n_threads = 1;
+    gather_t w[64];
+    pthread_t th[64];
+    int started[64];
+    Py_BEGIN_ALLOW_THREADS
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].ptr = (const char *const *)(uintptr_t)a_ptr;
+        w[t].len = (const int64_t *)(uintptr_t)a_len;
+        w[t].off = (const int64_t *)(uintptr_t)a_off;
+        w[t].out = (char *)(uintptr_t)a_out;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+        started[t] = (t > 0) && pthread_create(&th[t], NULL, gather_worker, &w[t]) == 0;
+    }
+    for (int t = 0; t < n_threads; ++t)
+        if (!started[t]) gather_worker(&w[t]);
+    for (int t = 0; t < n_threads; ++t)
+        if (started[t]) pthread_join(th[t], NULL);
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
+    {"gather_utf8", gather_utf8, METH_VARARGS, "copy (pointer, length) views into one flat buffer at given offsets"},
     {"str_views", str_views, METH_VARARGS, "UTF-8 views of the str elements of an object array"},
     {"strs_from_utf8", strs_from_utf8, METH_VARARGS, "str objects from flat UTF-8 + offsets into an object array"},
     {NULL, NULL, 0, NULL}};

@@ -256,8 +256,17 @@ def column_key_bytes(col: pd.Series) -> tuple:
         v[na] = 0.0
         raw = np.ascontiguousarray(v).view(np.uint8)
         return raw, np.arange(len(col) + 1, dtype=np.int64) * 8, na
-    # object column.  The usual case — every present cell is a str (URLs) — needs no per-cell Python: pyarrow walks the
-    # objects in C and hands back the flat utf-8 buffer (missing cells come out empty; the caller gives them NA_KEY).
+    # object column.  The usual case — every present cell is a str (URLs) — needs no per-cell Python: the str objects' UTF-8
+    # buffers are gathered by worker threads (pycells), or pyarrow walks the objects in C; missing cells come out empty (the
+    # caller gives them NA_KEY).
+    from . import pycells
+    if pycells.available() and col.dtype == object:
+        try:
+            flat = pycells.flat_utf8(col.to_numpy(), na)
+        except UnicodeEncodeError:
+            flat = None
+        if flat is not None:
+            return flat[0], flat[1], na
     try:
         import pyarrow as pa
         arr = pa.array(col.to_numpy(), type=pa.large_string(), from_pandas=True)
@@ -301,5 +310,13 @@ def column_str_bytes(col: pd.Series, drop_na: bool = False) -> tuple:
     """``col.astype(str)`` (after ``dropna`` when asked) as flat bytes (processor.py:194, :198)."""
     if drop_na:
         col = col.dropna()
+    from . import pycells
+    if pycells.available() and col.dtype == object:      # an all-str column: astype(str) changes nothing but the missing cells (NaN -> "nan", None -> "None")
+        try:
+            flat = pycells.flat_utf8(col.to_numpy(), col.isna().to_numpy(), na_as_text=True)
+        except UnicodeEncodeError:
+            flat = None
+        if flat is not None:
+            return flat
     data, off = _strings_to_bytes(col.astype(str).tolist())
     return data, off

@@ -54,3 +54,35 @@ def strings(text: np.ndarray, off: np.ndarray, na=None, n_threads: int = 0) -> n
     _dydpy.strs_from_utf8(text.ctypes.data if text.size else 0, off.ctypes.data, n, 0 if na_arr is None else na_arr.ctypes.data,
                           out.ctypes.data, n_threads or _nj.host_threads())
     return out
+
+
+def flat_utf8(col_values: np.ndarray, na: np.ndarray, na_as_text: bool = False):
+    """(flat utf-8 bytes u8, offsets i64 [n+1]) of an object array whose present cells are ALL str — or None when some present
+    cell is something else (the caller's tagged spelling handles those).  Missing cells come out empty, or — ``na_as_text``,
+    for ``astype(str)`` — as str(cell): "nan" for NaN, "None" for None.  The str objects' own UTF-8 buffers are copied once, by
+    worker threads."""
+    import ctypes as C
+
+    from . import native_json as _nj
+
+    v = CellViews(col_values)
+    if len(v) and (v.missing.astype(bool) != na).any():
+        return None
+    lens, ptr, keep = v.len, v.ptr, {}
+    if na_as_text and na.any():
+        lens = lens.copy(); ptr = ptr.copy()
+        for i in np.flatnonzero(na).tolist():
+            t = str(v.cells[i])
+            if t not in keep:
+                keep[t] = t.encode("utf-8")
+            b = keep[t]
+            lens[i] = len(b)
+            ptr[i] = C.cast(C.c_char_p(b), C.c_void_p).value
+    off = np.zeros(len(v) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    data = np.empty(max(int(off[-1]), 1), np.uint8)
+    if len(v):
+        _dydpy.gather_utf8(ptr.ctypes.data, np.ascontiguousarray(lens).ctypes.data, off.ctypes.data, len(v), data.ctypes.data,
+                           _nj.host_threads())
+    del keep
+    return data[:int(off[-1])], off

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--csv", type=int, default=0, help="1 = also time the path-in / path-out route (SURVEY §8d region 3): the fused CSV "
                                                        "twin and the two step functions in sequence, files under --dir")
     ap.add_argument("--dir", default="/tmp/dyd_e2e")
+    ap.add_argument("--dedup-rows", type=int, default=0, help="also time the in-memory dedup / reference filter on this many URL rows")
     args = ap.parse_args()
 
     import pandas as pd
@@ -31,6 +32,24 @@ def main():
     from deal_yolo_daya_amd.core import processor as P
 
     _native.lib()
+    if args.dedup_rows:
+        n = args.dedup_rows
+        rng = np.random.default_rng(5)
+        ids = rng.integers(0, int(0.9 * n) + 1, size=n)
+        src = pd.Series(np.char.add(np.char.add("http://img.example/", ids.astype(str)), ".jpg").astype(object), name="source")
+        src.iloc[::1000003] = np.nan
+        ref = pd.Series([f"http://img.example/{k}.jpg" for k in range(0, int(0.9 * n) + 1, 10)], name="source")
+        for rep in range(2):
+            a = time.perf_counter(); m1 = P.dedup_keep_mask(src, "first"); b = time.perf_counter()
+            w1 = ~src.duplicated(keep="first").to_numpy(); c = time.perf_counter()
+            m2 = P.ref_hit_mask(src, ref); d = time.perf_counter()
+            w2 = src.astype(str).isin(set(ref.dropna().astype(str))).to_numpy(); e = time.perf_counter()
+            print(json.dumps({"dedup_rows": n, "dedup_keep_mask_s": round(b - a, 3), "pandas_duplicated_s": round(c - b, 3),
+                              "ref_hit_mask_s": round(d - c, 3), "pandas_isin_s": round(e - d, 3),
+                              "identical": bool(np.array_equal(m1, w1) and np.array_equal(m2, w2)), "kernel_ms": round(_native.last_kernel_ms(), 3)}),
+                  flush=True)
+        if args.rows <= 0:
+            return
     t0 = time.perf_counter()
     parts = []
     for ci, s in enumerate(range(0, args.rows, 250_000)):
