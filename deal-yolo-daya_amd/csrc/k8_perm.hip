@@ -24,6 +24,8 @@
 // inversion — a 165 M-word random scatter, 64 % of K6 — disappears with the host loop.
 #include <cmath>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -393,12 +395,17 @@ int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *
         const int64_t n_blocks = ceil_div(draws, K8_MT_N);
         draws = n_blocks * K8_MT_N;
         const size_t d_bytes = ((((size_t)draws * 4) + 255) & ~(size_t)255) + 4096;   // + the seeded state
-        size_t work = 0;
-        for (int c = 0; c < n_sizes; ++c)
-            if (sizes[c] > 1) {
-                const size_t wb = perm_work_bytes((uint32_t)sizes[c], draws, nullptr);
-                if (wb > work) work = wb;
-            }
+        // every category gets its own work area and (below) its own stream and host thread: the resolve is a chain of ~40
+        // small dependent launches with an 8-byte read-back each, which leaves the device mostly idle — several categories
+        // side by side cost little more than one
+        std::vector<size_t> work_off((size_t)n_sizes + 1, 0);
+        int n_big = 0;
+        for (int c = 0; c < n_sizes; ++c) {
+            size_t wb = 0;
+            if (sizes[c] > 1) { wb = (perm_work_bytes((uint32_t)sizes[c], draws, nullptr) + 255) & ~(size_t)255; ++n_big; }
+            work_off[(size_t)c + 1] = work_off[(size_t)c] + wb;
+        }
+        const size_t work = work_off[(size_t)n_sizes];
         void *scr = nullptr;
         int rc = get_scratch(d_bytes + work, &scr, st);
         if (rc) return rc;
@@ -415,12 +422,54 @@ int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *
             DYD_HIP(hipGetLastError());
         }
         bool short_stream = false;
-        for (int c = 0; c < n_sizes && !short_stream; ++c) {
-            if (sizes[c] <= 1) continue;
-            rc = perm_from_stream(d, draws, (uint32_t)sizes[c], static_cast<char *>(scr) + d_bytes, inv32 ? inv32[c] : nullptr,
-                                  inv64 ? inv64[c] : nullptr, perm64 ? perm64[c] : nullptr, st, &g_k8_last_rounds);
-            if (rc == DYD_ERR_RANGE) short_stream = true;
-            else if (rc) { release_scratch(st); return rc; }
+        char *work_base = static_cast<char *>(scr) + d_bytes;
+        if (n_big <= 1) {
+            for (int c = 0; c < n_sizes && !short_stream; ++c) {
+                if (sizes[c] <= 1) continue;
+                rc = perm_from_stream(d, draws, (uint32_t)sizes[c], work_base + work_off[(size_t)c], inv32 ? inv32[c] : nullptr,
+                                      inv64 ? inv64[c] : nullptr, perm64 ? perm64[c] : nullptr, st, &g_k8_last_rounds);
+                if (rc == DYD_ERR_RANGE) short_stream = true;
+                else if (rc) { release_scratch(st); return rc; }
+            }
+        } else {
+            hipEvent_t ready = nullptr;
+            DYD_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            DYD_HIP(hipEventRecord(ready, st));      // the stream exists; the categories' streams start behind it
+            const int device = ctx().device;
+            std::vector<int> rcs((size_t)n_sizes, DYD_OK);
+            std::vector<std::string> msgs((size_t)n_sizes);
+            std::vector<std::thread> th;
+            for (int c = 0; c < n_sizes; ++c) {
+                if (sizes[c] <= 1) continue;
+                th.emplace_back([&, c] {
+                    int r = DYD_OK;
+                    hipStream_t cs = nullptr;
+                    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
+                        rcs[(size_t)c] = DYD_ERR_HIP;
+                        return;
+                    }
+                    if (hipStreamWaitEvent(cs, ready, 0) != hipSuccess) r = DYD_ERR_HIP;
+                    int rounds = 0;
+                    if (!r)
+                        r = perm_from_stream(d, draws, (uint32_t)sizes[c], work_base + work_off[(size_t)c], inv32 ? inv32[c] : nullptr,
+                                             inv64 ? inv64[c] : nullptr, perm64 ? perm64[c] : nullptr, cs, &rounds);
+                    if (hipStreamSynchronize(cs) != hipSuccess && !r) r = DYD_ERR_HIP;
+                    (void)hipStreamDestroy(cs);
+                    if (r && r != DYD_ERR_RANGE) msgs[(size_t)c] = dyd_last_error();   // the message lives in this thread
+                    rcs[(size_t)c] = r;
+                    g_k8_last_rounds = rounds;
+                });
+            }
+            for (auto &t : th) t.join();
+            (void)hipEventDestroy(ready);
+            for (int c = 0; c < n_sizes; ++c) {
+                if (rcs[(size_t)c] == DYD_ERR_RANGE) short_stream = true;
+                else if (rcs[(size_t)c]) {
+                    set_error("%s", msgs[(size_t)c].empty() ? "K8: a category's permutation failed" : msgs[(size_t)c].c_str());
+                    release_scratch(st);
+                    return rcs[(size_t)c];
+                }
+            }
         }
         release_scratch(st);
         if (!short_stream) return DYD_OK;
