@@ -24,6 +24,7 @@
 // inversion — a 165 M-word random scatter, 64 % of K6 — disappears with the host loop.
 #include <cmath>
 #include <cstring>
+#include <iterator>
 #include <string>
 #include <thread>
 #include <vector>
@@ -153,6 +154,35 @@ struct K8Flag {
     }
 };
 
+// Output side of a resolve round: stores the new count and, where it differs from the previous round's, records the position
+// (atomicMin) — the "first difference" search rides on the scan's own store instead of costing a pass of its own.
+struct K8DiffOut {
+    uint32_t *dst;
+    const uint32_t *old;
+    uint32_t *first;
+    uint32_t base;
+    struct Ref {
+        uint32_t *p;
+        const uint32_t *o;
+        uint32_t *first;
+        uint32_t idx;
+        __device__ __forceinline__ Ref &operator=(uint32_t v) {
+            if (*o != v) atomicMin(first, idx);
+            *p = v;
+            return *this;
+        }
+    };
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = uint32_t;
+    using difference_type = std::ptrdiff_t;
+    using pointer = uint32_t *;
+    using reference = Ref;
+    __host__ __device__ Ref operator[](difference_type i) const { return Ref{dst + i, old + i, first, base + (uint32_t)i}; }
+    __host__ __device__ Ref operator*() const { return (*this)[0]; }
+    __host__ __device__ K8DiffOut operator+(difference_type i) const { return K8DiffOut{dst + i, old + i, first, base + (uint32_t)i}; }
+    __host__ __device__ K8DiffOut &operator+=(difference_type i) { dst += i; old += i; base += (uint32_t)i; return *this; }
+};
+
 // first guess of c(t): inside an octave of mask+1 = M the step index decays like i+1 ~ (i_s+1) exp(-(t-t_s)/M)
 struct K8Octaves {
     int count;
@@ -279,7 +309,7 @@ static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) 
     size_t scan_tmp = 0, sort_tmp = 0;
     K8Flag f{nullptr, nullptr, n};
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), f);
-    (void)rocprim::exclusive_scan(nullptr, scan_tmp, in, (uint32_t *)nullptr, 0u, (size_t)draws, rocprim::plus<uint32_t>());
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, in, K8DiffOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
     (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::make_counting_iterator<uint32_t>(0u),
                                     (uint32_t *)nullptr, (size_t)n, 0u, 32u);
     size_t tmp = scan_tmp > sort_tmp ? scan_tmp : sort_tmp;
@@ -319,12 +349,9 @@ static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n
         K8Flag f{d, cA, n};
         auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>((uint32_t)lo), f);
         size_t tb = tmp_bytes;
-        DYD_HIP(rocprim::exclusive_scan(tmp, tb, in, cB + lo, c_lo, (size_t)(draws - lo), rocprim::plus<uint32_t>(), st));
         DYD_HIP(hipMemsetAsync(res, 0xff, 4, st));
-        const int64_t span = draws - lo;
-        const unsigned gd = (unsigned)(ceil_div(span, 256) < 2048 ? ceil_div(span, 256) : 2048);
-        hipLaunchKernelGGL(k8_first_diff, dim3(gd), dim3(256), 0, st, cA, cB, lo, draws, res);
-        DYD_HIP(hipGetLastError());
+        DYD_HIP(rocprim::exclusive_scan(tmp, tb, in, K8DiffOut{cB + lo, cA + lo, res, (uint32_t)lo}, c_lo, (size_t)(draws - lo),
+                                        rocprim::plus<uint32_t>(), st));
         hipLaunchKernelGGL(k8_pick, dim3(1), dim3(64), 0, st, cB, res);
         DYD_HIP(hipGetLastError());
         uint32_t host[2] = {0, 0};
