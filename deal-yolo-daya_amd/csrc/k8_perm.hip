@@ -167,7 +167,8 @@ struct K8DiffOut {
         uint32_t *first;
         uint32_t idx;
         __device__ __forceinline__ Ref &operator=(uint32_t v) {
-            if (*o != v) atomicMin(first, idx);
+            // almost every count differs in the first rounds: only a position below the minimum seen so far goes to the atomic
+            if (*o != v && idx < __hip_atomic_load(first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(first, idx);
             *p = v;
             return *this;
         }
