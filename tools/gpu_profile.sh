@@ -11,8 +11,11 @@ timeout -k 10 500 python bench.py ${BENCH_ARGS:-} > $OUT/bench.log 2> $OUT/bench
 echo "bench rc=$rc"; tail -n 1 $OUT/bench.log | cut -c1-600
 if [ $rc -ge 124 ]; then exit $rc; fi
 cd /tmp
-# the same command under the kernel trace (stats = per-kernel calls / average duration)
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py ${BENCH_ARGS:-} > $OUT/rocprof_bench.log 2>&1
+# the same command under the kernel trace (stats = per-kernel calls / average duration).  --host-rows 0 --cpu-sample 0: the
+# host-inclusive leg launches the SAME fused kernel on 16 small shares of a 1M-row table, which would pull the kernel's average
+# duration away from the 10M-row launches the roofline is quoted on; everything on the device stays (ramp, warm-up, the K timed
+# steps and the full-pipeline stages: every k12_wave_kernel call is a 10M-row launch)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --host-rows 0 --cpu-sample 0 ${BENCH_ARGS:-} > $OUT/rocprof_bench.log 2>&1
 echo "rocprof stats rc=$?"
 # counters: their own runs, kernel trace off, one TCC counter per pass (FETCH_SIZE and WRITE_SIZE do not fit together); the
 # device-resident part of the command only (the host-side legs launch the same kernels on other table sizes)
