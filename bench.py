@@ -38,6 +38,8 @@ WORKLOADS = {
     # name: (rows per GPU, boxes_per_row or None, description)
     "c2": (1_000_000, None, "configs[1]: 1M rows ptList->bbox + IoU filter (<=32 boxes/img) per GPU"),
     "c3": (10_000_000, None, "configs[2] table: 10M rows (<=32 boxes/img), ptList->bbox + IoU filter per GPU, inputs resident in HBM"),
+    "c4": (12_500_000, None, "configs[3]: 100M rows over 8 GPUs = 12.5M rows per GPU (<=32 boxes/img): ptList->bbox + IoU filter per rank, "
+                             "then the sharded URL dedup / reference filter with its all-gathers (sharded_exchange)"),
     "c5": (1_000_000, 256, "configs[4] scaled: dense-box stress, 256 boxes/img, 4-pt polygons"),
 }
 GEN_CHUNK = 2_000_000
@@ -261,15 +263,14 @@ def sharded_dedup(rows, rank, world, dev, reps=3):
     runs = runs[1:]
     med = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
     tot = torch.tensor([med["kept_local"], med["ref_hits_local"]], dtype=torch.float64, device=dev)
-    if world > 1:
-        if dist.get_backend() == "gloo":
-            tc = tot.cpu(); dist.all_reduce(tc); tot = tc
-        else:
-            dist.all_reduce(tot)
+    if dist.get_backend() == "gloo":
+        tc = tot.cpu(); dist.all_reduce(tc); tot = tc
+    else:
+        dist.all_reduce(tot)
     step_ms = med["k3_ms"] + med["dedup_total_ms"] + med["ref_k3_ms"] + med["ref_allgather_ms"] + med["ref_k5_ms"]
     return {"config": "configs[3] exchange: sharded URL dedup + reference filter, rows sharded contiguously, one all-gather of the "
                       "locally unique keys (dedup) and one of the reference keys",
-            "rows_per_gpu": rows, "rows_total": N, "world": world, "backend": dist.get_backend() if world > 1 else "single process",
+            "rows_per_gpu": rows, "rows_total": N, "world": world, "backend": dist.get_backend(),
             "stages_ms_rank0": {k: round(v, 3) for k, v in med.items() if k.endswith("_ms")},
             "allgather_bytes_dedup": int(med["gathered_keys"]) * 16, "local_unique_keys_rank0": int(med["local_unique_keys"]),
             "kept_rows_total": int(tot[0].item()), "ref_hits_total": int(tot[1].item()),
@@ -393,7 +394,11 @@ def main():
         elapsed = float(tt.item())
     high_rows = int(out_high.sum().item())
     exchange = None
-    if world > 1 and args.exchange:      # every rank takes part; rank 0 reports
+    if (world > 1 and args.exchange) or args.workload == "c4":      # every rank takes part; rank 0 reports
+        if world == 1 and not dist.is_initialized():                  # c4 on one GPU: a group of one, so the same code path runs
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("gloo", rank=0, world_size=1)
         exchange = sharded_dedup(rows, rank, world, dev)
 
     if rank == 0:
@@ -454,7 +459,7 @@ def main():
                     line["kernel_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
                 line["host_inclusive"] = hi
         print(json.dumps(line, ensure_ascii=False))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
