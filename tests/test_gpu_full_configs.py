@@ -142,6 +142,16 @@ def test_config2_ten_million_rows_pipeline(native):
         tr, va = int(n_train[c]), int(n_val[c])
         want = torch.where(pos[m] < tr, 0, torch.where(pos[m] < tr + va, 1, 2)).to(torch.uint8)
         assert torch.equal(split[m], want)
+    # ---- K8 + K6: the permutations made on the device from the seed must place all 165 M records exactly where the host's
+    # sequential Fisher-Yates (numpy's own algorithm) does ------------------------------------------------------------------
+    split8 = torch.empty(B, dtype=torch.uint8, device=dev)
+    pos8 = torch.empty(B, dtype=torch.int64, device=dev)
+    h_sizes = np.asarray(sizes, np.int64)
+    h_tr, h_va = n_train.cpu().numpy(), n_val.cpu().numpy()
+    ck(L.dyd_split_ids_seeded_dev(cat.data_ptr(), B, 42, h_sizes.ctypes.data, h_tr.ctypes.data, h_va.ctypes.data, 2, None,
+                                  split8.data_ptr(), pos8.data_ptr(), sp), "k8 + k6")
+    assert torch.equal(pos8, pos) and torch.equal(split8, split)
+    assert L.dyd_device_status(None) == 0
 
 
 def test_config4_dense_256_boxes_per_image(native):
