@@ -89,7 +89,23 @@ def main():
                           "bytes": os.path.getsize(Q("in.csv"))}), flush=True)
         import contextlib
         import io
+        from deal_yolo_daya_amd import fastcsv as _fc
+        phase = {}
+
+        def timed(name, fn):
+            def w(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    phase[name] = phase.get(name, 0.0) + time.perf_counter() - t
+            return w
+        _fc.read_split = timed("read_split", _fc.read_split)
+        _fc.write_table = timed("write_table", _fc.write_table)
+        P._replace_csv_core = timed("core(read+scan+launch+emit)", P._replace_csv_core)
+        P._as_reread = timed("as_reread", P._as_reread)
         for rep in range(2):
+            phase.clear()
             with contextlib.redirect_stdout(io.StringIO()):
                 a = time.perf_counter()
                 P.process_csv_replace_and_filter(Q("in.csv"), Q("p.csv"), Q("x.csv"), Q("hi.csv"), Q("lo.csv"), 2, 0.98)
@@ -103,6 +119,7 @@ def main():
             print(json.dumps({"csv": "CSV -> CSV", "rows": len(df), "fused_twin_s": round(t_fused, 3), "fused_rows_per_s": round(len(df) / t_fused),
                               "replace_step_s": round(t_two[0], 3), "iou_step_s": round(t_two[1], 3),
                               "two_steps_rows_per_s": round(len(df) / sum(t_two)), "io_path": dict(P.LAST_IO_PATH),
+                              "phases_fused_plus_two_steps_s": {k: round(v, 3) for k, v in phase.items()},
                               "same_files": same, "out_bytes": sum(os.path.getsize(Q(n)) for n in ("p.csv", "hi.csv", "lo.csv"))}), flush=True)
         for n in os.listdir(args.dir):
             os.remove(os.path.join(args.dir, n))
