@@ -160,9 +160,13 @@ def read_split(path: str, heavy_names, encoding: str = "utf-8-sig"):
     """-> SplitTable, or None when the fast path must not be used for this file."""
     if not enabled() or not _utf8_like(encoding):
         return None
+    # the file is mapped, not read: the tokeniser's threads fault the page-cache pages in side by side (a single f.read() of a
+    # 1.5 GB file took more than tokenising, extracting and parsing it together)
+    import mmap
     with open(path, "rb") as f:
-        raw = f.read()
-    start = len(_BOM) if raw.startswith(_BOM) and "sig" in encoding.lower() else 0
+        size = os.fstat(f.fileno()).st_size
+        raw = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else b""
+    start = len(_BOM) if raw[:3] == _BOM and "sig" in encoding.lower() else 0
     idx = CsvIndex.open(np.frombuffer(raw, dtype=np.uint8)[start:])
     if idx is None:
         return None
