@@ -199,7 +199,8 @@ void set_k7_trace(void *p);
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
 // 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off),
-// 5 / 6 = variants 0 / 2 with the f32 reject filter in K2 (k2_filter.h)
+// 5 / 6 = variants 0 / 2 with the f32 reject filter in K2 (k2_filter.h), 9 = fused <1024,8,256> with the filter (rows of up to
+// 256 boxes fit the K2 tile and are swept in x1 order, k2_sweep.h)
 static int g_fused_variant = -1;
 
 }  // namespace dyd
@@ -238,7 +239,7 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
     // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
     // (polygons of 20..48 points: the workgroup tiles keep more lanes walking than a wave's 64-box tile does)
-    if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : 6;   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
+    if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : (n_boxes > 64 * n_rows ? 9 : 6);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
     if (v == 4 || v == 7 || v == 8) {
         const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
         const int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);
@@ -266,6 +267,8 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         rc = launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 6)
         rc = launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
+    else if (v == 9)
+        rc = launch_fused<1024, 8, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 2)
         rc = launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 3)

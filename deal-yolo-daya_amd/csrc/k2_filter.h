@@ -89,6 +89,12 @@ __device__ __forceinline__ void k2f_drain(const double *box4, int64_t base, Wave
     }
 }
 
+}  // namespace dyd
+
+#include "k2_sweep.h"
+
+namespace dyd {
+
 template <bool WANT_MAX, int WROWS, int WCAP>
 __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t *__restrict__ row_off, int64_t r0,
                                               int nr, int32_t min_boxes, double thr, uint8_t *__restrict__ out_high,
@@ -115,6 +121,14 @@ __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t 
     int ra = 0;
     while (ra < nr) {  // every condition below is wave-uniform
         const int32_t base = __builtin_amdgcn_readlane(my_off, ra);
+        {   // ---- a row of many boxes that fits the tile: sorted by x1 and swept (k2_sweep.h) -----
+            const int32_t n0 = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
+            if (n0 >= K2S_MIN && n0 <= WCAP && !zero_hits && (WANT_MAX || n0 >= min_boxes) &&
+                k2s_row<WANT_MAX>(box4, (int64_t)base, n0, ra, S, min_boxes, thr, thr_lo)) {
+                ra += 1;
+                continue;
+            }
+        }
         const unsigned long long fits = __ballot(lane > ra && lane <= nr && my_off - base <= WCAP);
         const int taken = __popcll(fits);
         if (taken == 0) {

@@ -1,0 +1,126 @@
+"""K2's sort-and-sweep path for rows of 96..256 boxes (csrc/k2_sweep.h) against the oracle's double loop
+(reference core/processor.py:328-339, :368-376): the window filter may only admit pairs, never lose one."""
+import numpy as np
+import pytest
+
+from oracle import lib as olib
+
+pytestmark = pytest.mark.gpu
+
+THR = [(0.98, 2), (0.5, 3), (0.05, 2), (1.0, 2), (1e-12, 2), (1.5, 2), (0.0, 2), (-1.0, 2), (0.98, 300)]
+
+
+def _offsets(sizes):
+    off = np.zeros(len(sizes) + 1, np.int32)
+    np.cumsum(sizes, out=off[1:])
+    return off
+
+
+def _plant(rng, box, off, every=1):
+    """near-duplicate, boundary, identical and swapped-corner partners somewhere inside every `every`-th row"""
+    for r in range(0, len(off) - 1, every):
+        s, e = int(off[r]), int(off[r + 1])
+        if e - s < 2:
+            continue
+        i, j = rng.choice(np.arange(s, e), size=2, replace=False)
+        mode = (r // every) % 5
+        box[j] = box[i]
+        if mode == 1:
+            box[j, 3] -= (box[j, 3] - box[j, 1]) * 0.02              # at the 0.98 boundary
+        elif mode == 2:
+            box[j, 0] += (box[j, 2] - box[j, 0]) * 0.0201            # just outside it, shifted in x (the sweep axis)
+        elif mode == 3:
+            box[j] = box[j][[2, 3, 0, 1]]                            # un-normalised corners
+        elif mode == 4:
+            box[j, 0] += (box[j, 2] - box[j, 0]) * 0.0199            # just inside, shifted in x
+    return box
+
+
+def _tables():
+    rng = np.random.default_rng(20260301)
+    out = {}
+    sizes = [256, 96, 95, 100, 128, 129, 200, 255, 256, 7, 0, 1, 256, 130, 97, 64, 250] * 3
+    off = _offsets(sizes)
+    B = int(off[-1])
+    c = rng.random((B, 2)) * [1920, 1080]
+    wh = rng.random((B, 2)) * 100 + 1
+    out["uniform"] = (_plant(rng, np.concatenate([c, c + wh], axis=1), off), off)
+    out["integers"] = (_plant(rng, np.round(np.concatenate([c, c + wh], axis=1), 0), off), off)
+    # columns: many boxes share x1 exactly (the whole window is inside one key bucket), stacked in y
+    col = np.repeat(rng.integers(0, 4, size=B) * 300.0, 1)
+    yy = rng.random(B) * 5000
+    out["columns"] = (_plant(rng, np.stack([col, yy, col + 200, yy + 30], axis=1), off), off)
+    # everything on one spot: the sweep degenerates to all pairs
+    jit = rng.random((B, 4)) * 1e-3
+    out["one_spot"] = (_plant(rng, np.array([100.0, 100.0, 180.0, 160.0]) + jit, off, every=3), off)
+    # magnitudes where f32 cannot tell the boxes apart (2^24 and beyond), negative and tiny coordinates
+    big = np.concatenate([c, c + wh], axis=1) * 4096.0 + 16777216.123
+    out["beyond_f32"] = (_plant(rng, big, off), off)
+    out["negative"] = (_plant(rng, np.concatenate([c, c + wh], axis=1) - [2000, 1000, 2000, 1000], off), off)
+    out["tiny"] = (_plant(rng, np.concatenate([c, c + wh], axis=1) * 1e-300, off), off)
+    out["huge"] = (_plant(rng, np.concatenate([c, c + wh], axis=1) * 1e300, off), off)      # w*h overflows: inf areas
+    out["small"] = (_plant(rng, np.concatenate([c, c + wh], axis=1) * 1e-150, off), off)    # every f32 key is 0
+    out["large"] = (_plant(rng, np.concatenate([c, c + wh], axis=1) * 1e150, off), off)     # every f32 key is FLT_MAX
+    # not finite somewhere in a third of the rows: those rows take the all-pairs code
+    odd = _plant(rng, np.concatenate([c, c + wh], axis=1), off)
+    for r in range(0, len(sizes), 3):
+        if sizes[r] >= 2:
+            k = rng.integers(off[r], off[r + 1])
+            odd[k, rng.integers(0, 4)] = [np.nan, np.inf, -np.inf][r % 3]
+    out["not_finite"] = (odd, off)
+    # zero-width and zero-height boxes, nested boxes
+    z = np.concatenate([c, c + wh], axis=1)
+    z[::7, 2] = z[::7, 0]
+    z[3::11, 3] = z[3::11, 1]
+    z[5::13] = z[4::13][:len(z[5::13])] + [1, 1, -1, -1]
+    out["degenerate"] = (_plant(rng, z, off), off)
+    return out
+
+
+TABLES = _tables()
+
+
+@pytest.mark.parametrize("variant", [-1, 3, 5, 2])
+@pytest.mark.parametrize("name", sorted(TABLES))
+def test_sweep_flags_and_maximum(native, name, variant):
+    box, off = TABLES[name]
+    L = native.lib()
+    native.check(L.dyd_set_option(b"k2_variant", variant), "opt")
+    try:
+        got = {(thr, mb): native.iou_any_ge(box, off, mb, thr) for thr, mb in THR}
+        gmx = native.iou_any_ge(box, off, 2, 0.7, want_max=True)
+    finally:
+        native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
+    for (thr, mb), g in got.items():
+        want = olib.iou_any_ge(box, off, mb, thr)
+        assert np.array_equal(g, want), (name, thr, mb, np.flatnonzero(g != want)[:5])
+    wmx = olib.iou_any_ge(box, off, 2, 0.7, want_max=True)
+    assert np.array_equal(gmx[0], wmx[0])
+    assert np.array_equal(gmx[1].view(np.uint64), wmx[1].view(np.uint64)), name
+
+
+def test_sweep_tables_do_hit(native):
+    """sanity of the tables themselves: the planted partners make some rows HIGH and leave others not"""
+    for name in ("uniform", "columns", "beyond_f32", "small", "large"):
+        box, off = TABLES[name]
+        want = olib.iou_any_ge(box, off, 2, 0.98)
+        assert 0 < want.sum() < len(want), name
+
+
+@pytest.mark.parametrize("variant", [-1, 6, 9])
+@pytest.mark.parametrize("bpr", [100, 128, 200, 256])
+def test_fused_dense_rows(native, bpr, variant):
+    """the fused launch on tables of dense rows: workgroup tiles hand rows of up to 256 boxes to the sweep"""
+    from deal_yolo_daya_amd import synth
+    t = synth.generate(300, seed=bpr, boxes_per_row=bpr)
+    L = native.lib()
+    native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+    try:
+        res = {thr: native.bbox_iou_fused(t.xy, t.pt_off, t.box_off, 2, thr, want_box=True) for thr in (0.98, 0.3)}
+    finally:
+        native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+    for thr, (arg, high, box) in res.items():
+        obox, oarg, ohigh = olib.bbox_iou_chain(t.xy, t.pt_off, t.box_off, 2, thr)
+        assert np.array_equal(arg, oarg) and np.array_equal(box.view(np.uint64), obox.view(np.uint64))
+        assert np.array_equal(high, ohigh), (bpr, variant, thr)
+        assert 0 < ohigh.sum()
