@@ -196,6 +196,9 @@ void set_k7_variant(int v);
 void set_k6_variant(int v);
 void set_k4_capacity_shift(int v);
 void set_k7_trace(void *p);
+#ifdef K2S_DEBUG
+int set_k2s_debug(void *p);
+#endif
 
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
 // 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off),
@@ -368,6 +371,11 @@ int dyd_set_option(const char *key, int64_t value) {
         set_k7_trace(reinterpret_cast<void *>(static_cast<intptr_t>(value)));
         return DYD_OK;
     }
+#ifdef K2S_DEBUG
+    if (!strcmp(key, "k2s_debug_ptr")) {
+        return set_k2s_debug(reinterpret_cast<void *>(static_cast<intptr_t>(value)));
+    }
+#endif
     if (!strcmp(key, "fused_variant")) {
         g_fused_variant = (int)value;
         return DYD_OK;

@@ -104,6 +104,12 @@ static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_row
 // up to 64 boxes per image on average, 256-box tiles (5) beyond
 static int g_k2_variant = -1;
 void set_k2_variant(int v) { g_k2_variant = v; }
+#ifdef K2S_DEBUG
+int set_k2s_debug(void *p) {   // experiment builds only: device buffer of 16 u64 counters (k2_sweep.h)
+    DYD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_k2s_dbg), &p, sizeof(p)));
+    return DYD_OK;
+}
+#endif
 
 int launch_k2_wave64(const double *box4, const int32_t *row_off, int64_t n_rows, int32_t min_boxes, double thr, uint8_t *out_high,
                      unsigned long long *bigq, hipStream_t st);   // k12_fused.hip

@@ -16,10 +16,21 @@
 // intersection is evaluated, the others contribute the 0.0 the maximum starts from.
 //
 // LDS: the wave's float4 tile (k2_filter.h) is reused as sorted keys u32[WCAP] | limits u32[WCAP] | (y1, y2) f32[WCAP][2].
-// Sort: bitonic network over the next power of two (padding keys 0xffffffff sort last and pass no window).
+// Sort: bitonic network over 128 or 256 keys held in registers (padding keys 0xffffffff sort last and pass no window).
 #pragma once
 
 namespace dyd {
+
+#ifdef K2S_DEBUG
+static __device__ unsigned long long *g_k2s_dbg = nullptr;   // experiment counters (tools only; never defined in the product build)
+#define K2S_DBG_ADD(i, v) do { if (g_k2s_dbg && (threadIdx.x & 63) == 0) atomicAdd(&g_k2s_dbg[i], (unsigned long long)(v)); } while (0)
+#define K2S_DBG_MAX(i, v) do { if (g_k2s_dbg && (threadIdx.x & 63) == 0) atomicMax(&g_k2s_dbg[i], (unsigned long long)(v)); } while (0)
+#define K2S_CLOCK() __builtin_readcyclecounter()
+#else
+#define K2S_DBG_ADD(i, v) do {} while (0)
+#define K2S_DBG_MAX(i, v) do {} while (0)
+#define K2S_CLOCK() 0ull
+#endif
 
 constexpr int32_t K2S_MIN = 96;   // rows from this many boxes on are swept (below, the sort costs more than the pairs)
 
@@ -29,62 +40,110 @@ __device__ __forceinline__ uint32_t f32_order(float f) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// Bitonic sort of 64 * E keys held E per lane (sorted position of v[r] afterwards: lane * E + r), ascending.  Strides below E
+// are compare-exchanges between a lane's own registers, the others meet the partner lane through one cross-lane move per
+// register; nothing touches LDS memory, and a stage costs 3-4 VALU instructions per key instead of an LDS round trip.
+template <int E>
+__device__ __forceinline__ void k2s_sort_regs(uint32_t (&v)[E], int lane) {
+    constexpr int P = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const int lj = j / E;   // partner lane = lane ^ lj, same register
+                const bool lower = (lane & lj) == 0;
+                const bool up = (k == P) || (lane & (k / E)) == 0;
+                const bool keep_min = lower == up;
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)v[r], lj);
+                    const uint32_t mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
+                    v[r] = keep_min ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {
+                        const int r2 = r | j;
+                        const bool up = (k < E) ? ((r & k) == 0) : ((k == P) || (lane & (k / E)) == 0);
+                        const uint32_t mn = v[r] < v[r2] ? v[r] : v[r2], mx = v[r] < v[r2] ? v[r2] : v[r];
+                        v[r] = up ? mn : mx;
+                        v[r2] = up ? mx : mn;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// exact f64 test of `cnt` (<= 64) queued pairs from queue slot `first` on; the diagnostic maximum stays in the lane's register
+// (64 LDS atomics on one row's slot serialise: they cost more than the tests)
 template <bool WANT_MAX, int WROWS, int WCAP>
-__device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
-                                        int32_t min_boxes, double thr, double thr_lo) {
-    static_assert(WCAP <= 256 && WCAP >= 64 && (WCAP & (WCAP - 1)) == 0, "box index lives in 8 key bits; bitonic size");
+__device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, WaveLdsF<WROWS, WCAP> &S, int first, int cnt, double thr,
+                                          double thr_lo, double &mxacc) {
+    const int lane = threadIdx.x & 63;
+    bool hit = false;
+    if (lane < cnt) {
+        const uint32_t a = S.qa[first + lane], b = S.qb[first + lane];
+        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;   // the reference's (i < j) argument order
+        const Corners p = load_corners(box4, base + lo), q = load_corners(box4, base + hi);
+        double mx = 0.0;
+        hit = pair_hits<WANT_MAX, true>(p, q, area_of(p), q, thr, thr_lo, false, mx);
+        if (WANT_MAX && mx > mxacc) mxacc = mx;
+    }
+    return __any(hit);
+}
+
+template <bool WANT_MAX, int E, int WROWS, int WCAP>
+__device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
+                                          int32_t min_boxes, double thr, double thr_lo) {
+    constexpr int P = 64 * E;
+    static_assert(P <= WCAP && WCAP <= 256, "box index lives in 8 key bits");
     static_assert(sizeof(S.cf) >= 16 * (size_t)WCAP, "keys + limits + y intervals alias the float4 tile");
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t *skey = reinterpret_cast<uint32_t *>(S.cf);
     uint32_t *slim = skey + WCAP;
     float2 *syy = reinterpret_cast<float2 *>(skey + 2 * WCAP);
-    int P = 64;
-    while (P < n) P <<= 1;   // n <= WCAP, a power of two
     const double tl = WANT_MAX ? 0.0 : thr_lo;
 
-    // ---- keys, limits, y intervals ------------------------------------------------------------------------------
+    // ---- keys (registers), limits and y intervals (LDS, by box index) -------------------------------------------------
+    [[maybe_unused]] const unsigned long long t0 = K2S_CLOCK();
+    [[maybe_unused]] unsigned long long t_drain = 0, n_it = 0, n_cand = 0, n_drain = 0;
     bool bad = false;
+    uint32_t v[E];
     wave_sync();
-    for (int32_t k = lane; k < P; k += kWave) {
-        uint32_t key = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int32_t k = lane + kWave * r;
+        v[r] = 0xffffffffu;
         if (k < n) {
             const Corners c = load_corners(box4, base + k);
             const double lim = c.x2 - tl * (c.x2 - c.x1);
             const double probe = (c.x1 - c.x1) + (c.y1 - c.y1) + (c.x2 - c.x2) + (c.y2 - c.y2) + (lim - lim);   // 0 iff all are finite
             bad |= !(probe == 0.0);
-            key = (f32_order(f32_below(c.x1)) & ~0xffu) | (uint32_t)k;
+            v[r] = (f32_order(f32_below(c.x1)) & ~0xffu) | (uint32_t)k;
             slim[k] = (f32_order(f32_above(lim)) + 256u) | 0xffu;   // finite lim: at most 0xff7fffff + 256, no wrap
             syy[k] = make_float2(f32_below(c.y1), f32_above(c.y2));
         }
-        skey[k] = key;
     }
     if (__any(bad)) {
         wave_sync();
+        K2S_DBG_ADD(1, 1);
         return false;
     }
-
-    // ---- bitonic sort of the keys ------------------------------------------------------------------------------
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            wave_sync();
-            for (int t = lane; t < (P >> 1); t += kWave) {
-                const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int b = a | j;
-                const uint32_t ka = skey[a], kb = skey[b];
-                const uint32_t lo = ka < kb ? ka : kb, hi = ka < kb ? kb : ka;
-                const bool up = (a & k) == 0;
-                skey[a] = up ? lo : hi;
-                skey[b] = up ? hi : lo;
-            }
-        }
-    }
+    k2s_sort_regs<E>(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) skey[lane * E + r] = v[r];
     wave_sync();
+    [[maybe_unused]] const unsigned long long t1 = K2S_CLOCK();
 
     // ---- sweep: lane = sorted position p, partners p+1, p+2, ... while inside the window ---------------------------
     int qn = 0;
-    bool done = false;
-    for (int32_t p0 = 0; p0 < n - 1 && !done; p0 += kWave) {
+    bool any_hit = false;
+    double mxacc = 0.0;
+    for (int32_t p0 = 0; p0 < n - 1; p0 += kWave) {
         const int32_t p = p0 + lane;
         const bool have = p < n - 1;
         const int ia = (int)(skey[have ? p : 0] & 0xffu);
@@ -94,6 +153,9 @@ __device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_
             const int32_t j = p + d;
             const uint32_t kj = (j < P) ? skey[j] : 0xffffffffu;
             const bool inwin = have && kj <= lim;
+#ifdef K2S_DEBUG
+            n_it += 1;
+#endif
             if (!__any(inwin)) break;
             bool cand = false;
             const int ib = (int)(kj & 0xffu);
@@ -109,26 +171,68 @@ __device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_
                     S.qb[slot] = (uint32_t)ib;
                 }
                 qn += __popcll(m);
+#ifdef K2S_DEBUG
+                n_cand += __popcll(m);
+#endif
                 if (qn >= kWave) {
                     wave_sync();
-                    k2f_drain<WANT_MAX>(box4, base, S, qn - kWave, kWave, row, min_boxes, thr, thr_lo);
+#ifdef K2S_DEBUG
+                    n_drain += 1;
+                    const unsigned long long td = K2S_CLOCK();
+#endif
+                    any_hit |= k2s_drain<WANT_MAX>(box4, base, S, qn - kWave, kWave, thr, thr_lo, mxacc);
+#ifdef K2S_DEBUG
+                    t_drain += K2S_CLOCK() - td;
+#endif
                     qn -= kWave;
                     wave_sync();
-                    if (!WANT_MAX && __builtin_amdgcn_readfirstlane(S.flag[row]) != 0) {   // any() is decided
-                        done = true;
-                        qn = 0;
-                        break;
-                    }
+                    if (!WANT_MAX && any_hit) break;   // any() is decided
                 }
             }
         }
+        if (!WANT_MAX && any_hit) break;
     }
-    if (qn > 0) {
+    if (qn > 0 && (WANT_MAX || !any_hit)) {
         wave_sync();
-        k2f_drain<WANT_MAX>(box4, base, S, 0, qn, row, min_boxes, thr, thr_lo);
+#ifdef K2S_DEBUG
+        n_drain += 1;
+        const unsigned long long td = K2S_CLOCK();
+#endif
+        any_hit |= k2s_drain<WANT_MAX>(box4, base, S, 0, qn, thr, thr_lo, mxacc);
+#ifdef K2S_DEBUG
+        t_drain += K2S_CLOCK() - td;
+#endif
+    }
+    K2S_DBG_ADD(0, 1);
+    K2S_DBG_ADD(2, n_it);
+    K2S_DBG_ADD(3, n_cand);
+    K2S_DBG_ADD(4, n_drain);
+    K2S_DBG_MAX(5, n_it);
+    K2S_DBG_ADD(6, t1 - t0);
+    K2S_DBG_ADD(7, K2S_CLOCK() - t1);
+    K2S_DBG_ADD(8, t_drain);
+    if (any_hit && n >= min_boxes && lane == 0) S.flag[row] = 1;
+    if (WANT_MAX) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(mxacc);   // IoU >= 0: the bit patterns order like the values
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(bits, d);
+            bits = o > bits ? o : bits;
+        }
+        if (lane == 0 && bits > S.mx[row]) S.mx[row] = bits;
     }
     wave_sync();
     return true;
+}
+
+template <bool WANT_MAX, int WROWS, int WCAP>
+__device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
+                                        int32_t min_boxes, double thr, double thr_lo) {
+    static_assert(WCAP == 128 || WCAP == 256, "two or four keys per lane");
+    if constexpr (WCAP == 256) {
+        if (n > 128) return k2s_row_e<WANT_MAX, 4>(box4, base, n, row, S, min_boxes, thr, thr_lo);
+    }
+    return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo);
 }
 
 }  // namespace dyd

@@ -158,7 +158,17 @@ def generate_device(n_rows: int, seed: int, device, boxes_per_row: int | None = 
         raise ValueError("point count exceeds int32 offsets; generate in chunks")
     box_of_pt = torch.repeat_interleave(torch.arange(B, device=device), npts)
     centre = torch.rand((B, 2), dtype=torch.float64, **kw) * torch.tensor([1920.0, 1080.0], dtype=torch.float64, device=device)
-    xy = centre[box_of_pt] + (torch.rand((P, 2), dtype=torch.float64, **kw) * 100.0 - 50.0)
+    # one 1-D gather per column: `centre[box_of_pt]` (and index_select) on the [B, 2] tensor return zeros past ~59 M gathered rows on
+    # torch 2.10 + ROCm 7.0 (tools/rng_probe.py), which put every later box of a big table at the origin
+    xy = torch.rand((P, 2), dtype=torch.float64, **kw) * 100.0 - 50.0
+    for col in (0, 1):
+        xy[:, col] += centre[:, col].contiguous()[box_of_pt]
+    if P:   # the draw is only worth something if the gather did what it says: spot-check it
+        probe = torch.randint(0, P, (4096,), device=device)
+        probe[-1] = P - 1
+        off = xy[probe] - centre[box_of_pt[probe]]
+        if not bool(((off >= -50.0) & (off <= 50.0)).all()):
+            raise RuntimeError("synth.generate_device: gathered centres do not match (device indexing fault)")
     del centre
     if bool(dup_row.any()):
         src, dst = first_box[dup_row], last_box[dup_row]
