@@ -40,7 +40,7 @@ WORKLOADS = {
     "c3": (10_000_000, None, "configs[2] table: 10M rows (<=32 boxes/img), ptList->bbox + IoU filter per GPU, inputs resident in HBM"),
     "c4": (12_500_000, None, "configs[3]: 100M rows over 8 GPUs = 12.5M rows per GPU (<=32 boxes/img): ptList->bbox + IoU filter per rank, "
                              "then the sharded URL dedup / reference filter with its all-gathers (sharded_exchange)"),
-    "c5": (1_000_000, 256, "configs[4] scaled: dense-box stress, 256 boxes/img, 4-pt polygons"),
+    "c5": (1_000_000, 256, "configs[4] scaled: dense-box stress, 256 boxes/img, polygons of 3..12 points"),
 }
 GEN_CHUNK = 2_000_000
 

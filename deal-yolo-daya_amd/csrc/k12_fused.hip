@@ -242,7 +242,7 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
     // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
     // (polygons of 20..48 points: the workgroup tiles keep more lanes walking than a wave's 64-box tile does)
-    if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : (n_boxes > 64 * n_rows ? 9 : 6);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
+    if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : (n_boxes > 128 * n_rows ? 9 : 6);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
     if (v == 4 || v == 7 || v == 8) {
         const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
         const int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);

@@ -101,7 +101,7 @@ static int launch_k2_t(const double *box4, const int32_t *row_off, int64_t n_row
 // 2 / 3 = the same two tilings with the f32 reject filter (k2_filter.h), 4 = the fused wave kernel's pair stage alone,
 // 5 = 8 rows / 256 boxes with the filter: rows of up to 256 boxes fit the tile and are swept in x1 order (k2_sweep.h)
 // -1 (default): by the table's shape — the wave kernel's pair stage for sparse tables (variant 4), 8-row tiles + f32 filter (3)
-// up to 64 boxes per image on average, 256-box tiles (5) beyond
+// up to 128 boxes per image on average, 256-box tiles (5) beyond (tools/dense_sweep.py: at 128 boxes per row 0.46 vs 0.51 ms, at 256 4.6 vs 0.54)
 static int g_k2_variant = -1;
 void set_k2_variant(int v) { g_k2_variant = v; }
 #ifdef K2S_DEBUG
@@ -125,7 +125,7 @@ static int launch_k2_main(const double *box4, const int32_t *row_off, int64_t n_
     if (g_k2_variant == 0) return launch_k2_t<K2_WROWS, K2_WCAP>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
     if (g_k2_variant == 1) return launch_k2_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
     if (g_k2_variant == 2) return launch_k2f_t<16, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
-    if (g_k2_variant == 5 || (g_k2_variant < 0 && n_boxes > 64 * n_rows))
+    if (g_k2_variant == 5 || (g_k2_variant < 0 && n_boxes > 128 * n_rows))
         return launch_k2f_t<8, 256>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
     return launch_k2f_t<8, 128>(box4, row_off, n_rows, min_boxes, thr, out_high, out_max, bigq, st);
 }
