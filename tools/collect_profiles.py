@@ -25,7 +25,8 @@ summary = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:   # gpurun merges every call's files into the same directory: the latest run only
         df = pd.read_csv(f)
         df = df[df["Kernel_Name"].str.contains("dyd::")]
         for (k, c), g in df.groupby(["Kernel_Name", "Counter_Name"]):
