@@ -1,4 +1,4 @@
-// k2_sweep.h — K2 for a row of many boxes: sort by the left edge, then only look at the partners that can still reach thr.
+// k2_sweep.h — K2 for a row of 40..256 boxes: sort by the left edge, then only look at the partners that can still reach thr.
 //
 // The pair loops of k2_wave.h / k2_filter.h visit all n(n-1)/2 pairs of a row (reference core/processor.py:368-376,
 // `any(calculate_iou(...) >= thr ...)` over i < j); for a row of 256 boxes that is 32 640 reject tests, 510 trips per lane,
@@ -16,7 +16,7 @@
 // intersection is evaluated, the others contribute the 0.0 the maximum starts from.
 //
 // LDS: the wave's float4 tile (k2_filter.h) is reused as sorted keys u32[WCAP] | limits u32[WCAP] | (y1, y2) f32[WCAP][2].
-// Sort: bitonic network over 128 or 256 keys held in registers (padding keys 0xffffffff sort last and pass no window).
+// Sort: bitonic network over 64, 128 or 256 keys held in registers, one, two or four per lane (padding keys 0xffffffff sort last and pass no window).
 #pragma once
 
 namespace dyd {
@@ -32,7 +32,10 @@ static __device__ unsigned long long *g_k2s_dbg = nullptr;   // experiment count
 #define K2S_CLOCK() 0ull
 #endif
 
-constexpr int32_t K2S_MIN = 96;   // rows from this many boxes on are swept (below, the sort costs more than the pairs)
+#ifndef K2S_MIN_VALUE
+#define K2S_MIN_VALUE 40
+#endif
+constexpr int32_t K2S_MIN = K2S_MIN_VALUE;   // rows from this many boxes on are swept (tools/dense_sweep.py at 40 / 48 / 64 / 80 boxes per row: 0.36 / 0.31 / 0.26 / 0.33 ms against 0.57 / 0.69 / 0.67 / 1.14 for the all-pairs tiles)
 
 // f32 bit pattern -> u32 that orders like the value (-inf < ... < -0 < +0 < ... < +inf)
 __device__ __forceinline__ uint32_t f32_order(float f) {
@@ -228,11 +231,12 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
 template <bool WANT_MAX, int WROWS, int WCAP>
 __device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
                                         int32_t min_boxes, double thr, double thr_lo) {
-    static_assert(WCAP == 128 || WCAP == 256, "two or four keys per lane");
+    static_assert(WCAP == 128 || WCAP == 256, "one, two or four keys per lane");
     if constexpr (WCAP == 256) {
         if (n > 128) return k2s_row_e<WANT_MAX, 4>(box4, base, n, row, S, min_boxes, thr, thr_lo);
     }
-    return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo);
+    if (n > 64) return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo);
+    return k2s_row_e<WANT_MAX, 1>(box4, base, n, row, S, min_boxes, thr, thr_lo);
 }
 
 }  // namespace dyd

@@ -39,7 +39,7 @@ def _plant(rng, box, off, every=1):
 def _tables():
     rng = np.random.default_rng(20260301)
     out = {}
-    sizes = [256, 96, 95, 100, 128, 129, 200, 255, 256, 7, 0, 1, 256, 130, 97, 64, 250] * 3
+    sizes = [256, 96, 95, 100, 128, 129, 200, 255, 256, 7, 0, 1, 256, 130, 97, 64, 250, 33, 40, 48, 63, 65, 70] * 3
     off = _offsets(sizes)
     B = int(off[-1])
     c = rng.random((B, 2)) * [1920, 1080]
