@@ -1477,19 +1477,7 @@ int dyd_synth_json(const double *xy, const int32_t *pt_off, const int32_t *box_o
     return DYD_OK;
 }
 
-// A pipeline handle owns gigabytes (per-thread point arrays, segments, emitted text): returning them to the kernel takes 0.15 s per
-// million cells, which the caller of a step function should not wait for.  Such handles are destroyed on a detached thread.
-void dyd_scan_free(dyd_scan *h) {
-    if (!h) return;
-    if (h->parts.size() > 1 && h->n_cells >= 65536) {
-        try {
-            std::thread([h] { delete h; }).detach();
-            return;
-        } catch (...) {   // no thread to be had: free here
-        }
-    }
-    delete h;
-}
+void dyd_scan_free(dyd_scan *h) { delete h; }
 
 // Scan bbox-JSON cells for the IoU step (processor.py:341-366): two-point boxes per row with the
 // prefix-on-exception rule.  status[i] = 0 regular, 2 = Python path.  Arrays are owned by the handle
