@@ -29,7 +29,7 @@ namespace dyd {
 // CHUNK = K1 point-chunk size, (WROWS, WCAP) = K2 per-wave tile.  The two phases alias one LDS
 // buffer, so its size — and the number of workgroups a CU can hold — is the larger of the two.
 template <int CHUNK, int WROWS, int WCAP, bool FILTER = false>
-__global__ __launch_bounds__(K1_BLOCK) void k12_fused_kernel(const double2 *__restrict__ xy,
+__global__ __launch_bounds__(K1_BLOCK, (FILTER && WCAP == 256 && WROWS == 8) ? 6 : 1) void k12_fused_kernel(const double2 *__restrict__ xy,
                                                              const int32_t *__restrict__ pt_off,
                                                              const int32_t *__restrict__ box_off, int64_t n_rows,
                                                              int32_t min_boxes, double thr, double *out_box4,

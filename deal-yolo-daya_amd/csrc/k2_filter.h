@@ -34,22 +34,18 @@ struct alignas(16) WaveLdsF {
     unsigned short perm[WCAP];
 };
 
-// f32 value <= v (toward -inf) / >= v (toward +inf); NaN stays NaN, |v| > FLT_MAX maps to +-FLT_MAX / +-inf
+// f32 value <= v / >= v for every finite or infinite v (NaN stays NaN).  Not the neighbouring f32 — that costs a dozen instructions
+// (convert back, compare, three sign cases) per corner — but the nearest f32 pushed outward by one part in 2^23 of itself plus
+// 2^-120: the nearest f32 is within half an ulp of v and an ulp is at most 2^-23 of the value, so the push clears v whatever the
+// fma's own rounding does; the constant covers the denormal range where the relative push vanishes.  |v| > FLT_MAX converts to
+// +-inf: the bound on the far side is clamped to +-FLT_MAX first.  Four instructions; the filters only need SOME bound.
 __device__ __forceinline__ float f32_below(double v) {
-    float f = (float)v;
-    if ((double)f > v) {
-        const unsigned b = __float_as_uint(f);
-        f = (f > 0.0f) ? __uint_as_float(b - 1u) : ((f < 0.0f) ? __uint_as_float(b + 1u) : __uint_as_float(0x80000001u));
-    }
-    return f;
+    const float f = fminf((float)v, 3.402823466e+38f);
+    return fmaf(-fabsf(f), 0x1p-23f, f) - 0x1p-120f;
 }
 __device__ __forceinline__ float f32_above(double v) {
-    float f = (float)v;
-    if ((double)f < v) {
-        const unsigned b = __float_as_uint(f);
-        f = (f > 0.0f) ? __uint_as_float(b + 1u) : ((f < 0.0f) ? __uint_as_float(b - 1u) : __uint_as_float(0x00000001u));
-    }
-    return f;
+    const float f = fmaxf((float)v, -3.402823466e+38f);
+    return fmaf(fabsf(f), 0x1p-23f, f) + 0x1p-120f;
 }
 // lane mask of a > b (false for NaN), kept in an SGPR pair: written as C++ the four tests of a pair are widened to
 // integers and recombined with 16-bit VALU ops (17 VALU instructions per pair instead of 4 compares + scalar ANDs)

@@ -122,10 +122,16 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
         const int32_t k = lane + kWave * r;
         v[r] = 0xffffffffu;
         if (k < n) {
-            const Corners c = load_corners(box4, base + k);
+            // corners by IEEE min / max: they differ from the reference's first-wins min / max only for a NaN (the row then leaves
+            // through `bad`) and in the sign of a zero (inside the filter's slack)
+            const double2 *g = reinterpret_cast<const double2 *>(box4 + 4 * (base + k));
+            const double2 pa = g[0], pb = g[1];
+            const Corners c = {vmin(pa.x, pb.x), vmin(pa.y, pb.y), vmax(pa.x, pb.x), vmax(pa.y, pb.y)};
             const double lim = c.x2 - tl * (c.x2 - c.x1);
-            const double probe = (c.x1 - c.x1) + (c.y1 - c.y1) + (c.x2 - c.x2) + (c.y2 - c.y2) + (lim - lim);   // 0 iff all are finite
-            bad |= !(probe == 0.0);
+            // all five finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends
+            // the row to the all-pairs code)
+            bad |= !(__builtin_fabs(pa.x) + __builtin_fabs(pa.y) + __builtin_fabs(pb.x) + __builtin_fabs(pb.y) + __builtin_fabs(lim) <
+                     __builtin_inf());
             v[r] = (f32_order(f32_below(c.x1)) & ~0xffu) | (uint32_t)k;
             slim[k] = (f32_order(f32_above(lim)) + 256u) | 0xffu;   // finite lim: at most 0xff7fffff + 256, no wrap
             syy[k] = make_float2(f32_below(c.y1), f32_above(c.y2));
