@@ -77,6 +77,19 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
     k12_wave_rows(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave], bigq);
 }
 
+// the same kernel for tables above 32 boxes per image on average: rows of 40..256 boxes are sorted and swept (k12_wave.h, k2_sweep.h)
+__global__ __launch_bounds__(256) void k12_wave_dense_kernel(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
+                                                             const int32_t *__restrict__ box_off, int64_t n_rows, int32_t min_boxes,
+                                                             double thr, double *out_box4, int32_t *__restrict__ out_arg4,
+                                                             uint8_t *__restrict__ out_high, unsigned long long *bigq) {
+    __shared__ WaveFuseDense s_all[4];
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * KW_ROWS;
+    if (r0 >= n_rows) return;
+    const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
+    k12_wave_rows<false, true>(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave], bigq);
+}
+
 // K2 alone with the wave kernel's pair stage: a wave owns 16 rows, walks them in tiles of whole rows with at most 64 boxes (one
 // box per lane, loaded 32 bytes per lane), and runs the same all-pairs loop — none of the tile kernels' bookkeeping (row ranks,
 // row search, permutation): 0.245 -> 0.196 ms on the bench table.  Rows beyond 64 boxes take the slow partner-tile route,
@@ -203,7 +216,7 @@ int set_k2s_debug(void *p);
 // -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
 // 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off),
 // 5 / 6 = variants 0 / 2 with the f32 reject filter in K2 (k2_filter.h), 9 = fused <1024,8,256> with the filter (rows of up to
-// 256 boxes fit the K2 tile and are swept in x1 order, k2_sweep.h)
+// 256 boxes fit the K2 tile and are swept in x1 order, k2_sweep.h), 10 = the wave kernel's DENSE instantiation (k12_wave.h)
 static int g_fused_variant = -1;
 
 }  // namespace dyd
@@ -243,6 +256,19 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
     // (polygons of 20..48 points: the workgroup tiles keep more lanes walking than a wave's 64-box tile does)
     if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : (n_boxes > 128 * n_rows ? 9 : 6);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
+    if (v == 10) {   // the wave kernel with sort and sweep for rows of 40..256 boxes
+        const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KW_ROWS);
+        if (blocks > 0x7fffffffLL) {
+            set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
+            return DYD_ERR_RANGE;
+        }
+        hipLaunchKernelGGL(k12_wave_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const double2 *>(xy), pt_off,
+                           box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq);
+        DYD_HIP(hipGetLastError());
+        const int rcb = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
+        if (!rcb) release_bigq(st);
+        return rcb;
+    }
     if (v == 4 || v == 7 || v == 8) {
         const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
         const int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);

@@ -12,6 +12,10 @@
 //       (reference :328-339, :359-362, :368-376).
 // A row with more than 64 boxes takes a slower general path: K1 in 64-box passes to global
 // memory, then K2 streaming 64-box partner tiles through LDS.
+// The DENSE instantiation (tables above 32 boxes per image on average) pairs rows of 40..256 boxes by sort and sweep
+// (k2_sweep.h) instead: the sweep records (key, limit, y interval) are computed from the K1 accumulators while they are still in
+// registers, the keys are sorted there, and only the exact tests read boxes back (from L2).  It costs ~20 VGPRs and 1 KiB of LDS
+// per wave, which is why the kernel for sparse tables does not carry it.
 //
 // Chain semantics (reference :254-255 -> :364-365): a polygon without a valid point becomes a ptList of
 // null coordinates in the replace step, and the IoU step's extract_boxes raises on it inside its blanket
@@ -21,7 +25,7 @@
 #pragma once
 
 #include "k1_tile.h"
-#include "k2_wave.h"
+#include "k2_filter.h"
 
 namespace dyd {
 
@@ -39,6 +43,17 @@ struct alignas(16) WaveFuse {
     int32_t flag[KW_ROWS];
     int32_t nan[KW_ROWS];
 };
+// the DENSE kernel's slice: the same, plus the sweep's queue of candidate pairs; its sorted keys | limits | y intervals (4 KiB for 256
+// boxes) lie over the point buffer, which is dead by then
+struct alignas(16) WaveFuseDense : WaveFuse {
+    uint32_t qa[2 * kWave], qb[2 * kWave];
+};
+static_assert(sizeof(double2) * KW_CHUNK >= 16 * 256, "sweep arrays of a 256-box row fit the point buffer");
+__device__ __forceinline__ K2sView k12_sweep_view(WaveFuseDense &S) {
+    uint32_t *skey = reinterpret_cast<uint32_t *>(S.pts);
+    return K2sView{skey, skey + 256, reinterpret_cast<float2 *>(skey + 512), S.qa, S.qb};
+}
+__device__ __forceinline__ K2sView k12_sweep_view(WaveFuse &) { return K2sView{nullptr, nullptr, nullptr, nullptr, nullptr}; }
 
 // K1 for up to 64 consecutive boxes [b0, b0 + cnt): lane l < cnt owns box b0 + l.  Returns the
 // lane's accumulator (already stored to out_box4 / out_arg4).
@@ -79,12 +94,12 @@ __device__ __forceinline__ BoxAcc k12_wave_boxes(const double2 *__restrict__ xy,
 }
 
 // BOXES_IN: the boxes already exist (K2 alone): out_box4 is then the INPUT and neither xy / pt_off nor out_arg4 are touched
-template <bool BOXES_IN = false>
+template <bool BOXES_IN = false, bool DENSE = false, class Slice = WaveFuse>
 __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
                                               const int32_t *__restrict__ box_off, int64_t r0, int nr,
                                               int32_t min_boxes, double thr, double *out_box4,
                                               int32_t *__restrict__ out_arg4, uint8_t *__restrict__ out_high,
-                                              WaveFuse &S, unsigned long long *bigq = nullptr) {
+                                              Slice &S, unsigned long long *bigq = nullptr) {
     const int lane = threadIdx.x & 63;
     int32_t my_off = 0;
     if (lane <= nr) {
@@ -108,7 +123,75 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
         if (taken == 0) {
             // ---- a row with more than 64 boxes: K1 in passes, then K2 over partner tiles ---------
             int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (!BOXES_IN) {
+            bool k1_done = false;
+            if constexpr (DENSE) {
+                if (n <= 256 && !zero_hits) {
+                    // ---- 65..256 boxes: K1 passes with the sweep records taken from the accumulators, then sort and sweep ----
+                    uint32_t vk[4], vl[4];
+                    float2 vy[4];
+                    unsigned badbits = 0u;
+                    int32_t n_eff = n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int32_t g = kWave * r;
+                        vk[r] = 0xffffffffu;
+                        vl[r] = 0u;
+                        vy[r] = make_float2(0.f, 0.f);
+                        if (g < n) {   // wave-uniform
+                            const int cnt = (n - g < kWave) ? n - g : kWave;
+                            Corners c = {0.0, 0.0, 0.0, 0.0};
+                            if (BOXES_IN) {
+                                if (lane < cnt) c = load_corners(out_box4, (int64_t)base + g + lane);
+                            } else {
+                                const BoxAcc a = k12_wave_boxes(xy, pt_off, (int64_t)base + g, cnt, out_box4, out_arg4, S);
+                                const unsigned long long em = __ballot(lane < cnt && a.imnx < 0);
+                                if (em != 0ull && g + (__ffsll((long long)em) - 1) < n_eff) n_eff = g + (__ffsll((long long)em) - 1);
+                                c = normalise(make_double2(a.mnx, a.mny), make_double2(a.mxx, a.mxy));
+                            }
+                            if (lane < cnt && !k2s_prepare(c, (uint32_t)(g + lane), thr_lo, vk[r], vl[r], vy[r])) badbits |= 1u << r;
+                        }
+                    }
+                    k1_done = true;
+                    n = n_eff;   // the row's IoU list ends at its first empty polygon
+                    if (n < 2 || n < min_boxes) {
+                        ra += 1;
+                        continue;
+                    }
+                    bool bad = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (kWave * r + lane >= n) vk[r] = 0xffffffffu;
+                        else bad |= ((badbits >> r) & 1u) != 0u;
+                    }
+                    if (!__any(bad)) {
+                        // the exact tests re-read this wave's own box stores: wait for them and drop any stale L1 lines
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        const K2sView V = k12_sweep_view(S);
+                        wave_sync();   // the point buffer is dead: limits and y intervals go over it
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int32_t k = kWave * r + lane;
+                            if (k < n) {
+                                V.slim[k] = vl[r];
+                                V.syy[k] = vy[r];
+                            }
+                        }
+                        bool hit;
+                        if (n <= 2 * kWave) {
+                            uint32_t v2[2] = {vk[0], vk[1]};
+                            hit = k2s_sweep_sorted<false, 2>(out_box4, (int64_t)base, n, V, v2, thr, thr_lo, unused_mx);
+                        } else {
+                            hit = k2s_sweep_sorted<false, 4>(out_box4, (int64_t)base, n, V, vk, thr, thr_lo, unused_mx);
+                        }
+                        if (hit && lane == 0) S.flag[ra] = 1;
+                        wave_sync();
+                        ra += 1;
+                        continue;
+                    }
+                    // a corner that is not finite: the generic code below decides (K1 has run)
+                }
+            }
+            if (!BOXES_IN && !k1_done) {
                 int32_t n_eff = n;
                 for (int32_t g = 0; g < n; g += kWave) {
                     const int cnt = (n - g < kWave) ? n - g : kWave;
@@ -172,6 +255,34 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
             for (int r2 = ra + 1; r2 < rb; ++r2) lr += (__builtin_amdgcn_readlane(my_off, r2) - base <= lane) ? 1 : 0;
             const Corners me = normalise(make_double2(acc.mnx, acc.mny), make_double2(acc.mxx, acc.mxy));
             const unsigned long long em = BOXES_IN ? 0ull : __ballot(lane < nb && acc.imnx < 0);  // empty polygons of the tile
+            if constexpr (DENSE) {
+                if (taken == 1 && nb >= K2S_MIN && !zero_hits) {
+                    // ---- one row of 40..64 boxes fills the tile: sort and sweep instead of 20..32 trips of all pairs ----
+                    const int32_t n = (em != 0ull) ? (__ffsll((long long)em) - 1) : nb;   // the list ends at the first empty polygon
+                    if (n < 2 || n < min_boxes) {
+                        ra = rb;
+                        continue;
+                    }
+                    uint32_t v1[1] = {0xffffffffu}, lim1 = 0u;
+                    float2 yy1 = make_float2(0.f, 0.f);
+                    const bool ok = lane >= n || k2s_prepare(me, (uint32_t)lane, thr_lo, v1[0], lim1, yy1);
+                    if (lane >= n) v1[0] = 0xffffffffu;
+                    if (!__any(!ok)) {
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the exact tests read this wave's box stores back
+                        const K2sView V = k12_sweep_view(S);
+                        wave_sync();
+                        if (lane < n) {
+                            V.slim[lane] = lim1;
+                            V.syy[lane] = yy1;
+                        }
+                        const bool hit = k2s_sweep_sorted<false, 1>(out_box4, (int64_t)base, n, V, v1, thr, thr_lo, unused_mx);
+                        if (hit && lane == 0) S.flag[ra] = 1;
+                        wave_sync();
+                        ra = rb;
+                        continue;
+                    }
+                }
+            }
             wave_sync();
             if (lane < nb) {
                 S.c.x1[lane] = me.x1; S.c.y1[lane] = me.y1; S.c.x2[lane] = me.x2; S.c.y2[lane] = me.y2;

@@ -43,52 +43,96 @@ __device__ __forceinline__ uint32_t f32_order(float f) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// median of three u32: with c = 0 it is min(a, b), with c = 0xffffffff max(a, b) — one instruction decides a compare-exchange
+// whose direction differs from lane to lane
+__device__ __forceinline__ uint32_t k2s_med3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// bit `bit` of the lane number spread over a word (0 or 0xffffffff).  volatile: the masks of the 21 cross-lane stages are loop
+// invariants the compiler would otherwise keep in 27 registers across the whole kernel (85 -> 112 VGPRs, a wave less per SIMD)
+template <int BIT>
+__device__ __forceinline__ uint32_t k2s_lane_bit(int lane) {
+    uint32_t r;
+    asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(lane), "n"(BIT));
+    return r;
+}
+constexpr int k2s_log2(int x) { return x <= 1 ? 0 : 1 + k2s_log2(x >> 1); }
+
 // Bitonic sort of 64 * E keys held E per lane (sorted position of v[r] afterwards: lane * E + r), ascending.  Strides below E
 // are compare-exchanges between a lane's own registers, the others meet the partner lane through one cross-lane move per
-// register; nothing touches LDS memory, and a stage costs 3-4 VALU instructions per key instead of an LDS round trip.
-template <int E>
-__device__ __forceinline__ void k2s_sort_regs(uint32_t (&v)[E], int lane) {
-    constexpr int P = 64 * E;
+// register; nothing touches LDS memory, and a stage costs ONE VALU instruction per key (v_med3_u32) instead of an LDS round trip.
+// `down`: 0 where the merge of level K runs ascending for the lane's keys, all ones where descending (levels below E alternate
+// inside the lane and are resolved at compile time).
+template <int E, int K, int J>
+__device__ __forceinline__ void k2s_sort_stage(uint32_t (&v)[E], int lane, uint32_t down) {
+    if constexpr (J >= E) {
+        constexpr int LJ = J / E;   // partner lane = lane ^ LJ, same register; the lower lane of an ascending pair keeps the minimum
+        const uint32_t sel = k2s_lane_bit<k2s_log2(LJ)>(lane) ^ down;
 #pragma unroll
-    for (int k = 2; k <= P; k <<= 1) {
+        for (int r = 0; r < E; ++r) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)v[r], LJ);
+            v[r] = k2s_med3(v[r], o, sel);
+        }
+    } else {
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= E) {
-                const int lj = j / E;   // partner lane = lane ^ lj, same register
-                const bool lower = (lane & lj) == 0;
-                const bool up = (k == P) || (lane & (k / E)) == 0;
-                const bool keep_min = lower == up;
-#pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)v[r], lj);
-                    const uint32_t mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
-                    v[r] = keep_min ? mn : mx;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    if ((r & j) == 0) {
-                        const int r2 = r | j;
-                        const bool up = (k < E) ? ((r & k) == 0) : ((k == P) || (lane & (k / E)) == 0);
-                        const uint32_t mn = v[r] < v[r2] ? v[r] : v[r2], mx = v[r] < v[r2] ? v[r2] : v[r];
-                        v[r] = up ? mn : mx;
-                        v[r2] = up ? mx : mn;
-                    }
-                }
+        for (int r = 0; r < E; ++r) {
+            if ((r & J) == 0) {
+                const int r2 = r | J;
+                const uint32_t lo_sel = (K < E) ? ((r & K) == 0 ? 0u : 0xffffffffu) : down;
+                const uint32_t a = v[r], b = v[r2];
+                v[r] = k2s_med3(a, b, lo_sel);
+                v[r2] = k2s_med3(a, b, ~lo_sel);
             }
         }
     }
+    if constexpr (J > 1) k2s_sort_stage<E, K, J / 2>(v, lane, down);
+}
+template <int E, int K>
+__device__ __forceinline__ void k2s_sort_level(uint32_t (&v)[E], int lane) {
+    constexpr int P = 64 * E;
+    uint32_t down = 0u;
+    if constexpr (K >= E && K < P) down = k2s_lane_bit<k2s_log2(K / E)>(lane);
+    k2s_sort_stage<E, K, K / 2>(v, lane, down);
+    if constexpr (K < P) k2s_sort_level<E, 2 * K>(v, lane);
+}
+template <int E>
+__device__ __forceinline__ void k2s_sort_regs(uint32_t (&v)[E], int lane) {
+    k2s_sort_level<E, 2>(v, lane);
+}
+
+// Where the sweep keeps its arrays (all in the calling wave's LDS): sorted keys [cap], limits and y intervals by box index
+// [cap], and the queue of candidate pairs (2 x 128 box indices).  cap = 64 * E of the instantiation.
+struct K2sView {
+    uint32_t *skey, *slim;
+    float2 *syy;
+    uint32_t *qa, *qb;
+};
+
+// One box -> its sweep record.  Corners must be normalised (x1 <= x2, y1 <= y2 unless a NaN is involved); returns false when
+// one of them or the limit is not finite (the row must then take the all-pairs code).
+__device__ __forceinline__ bool k2s_prepare(const Corners &c, uint32_t k, double tl, uint32_t &key, uint32_t &lim, float2 &yy) {
+    const double l = c.x2 - tl * (c.x2 - c.x1);
+    // all five finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends
+    // the row to the all-pairs code)
+    const bool ok = __builtin_fabs(c.x1) + __builtin_fabs(c.y1) + __builtin_fabs(c.x2) + __builtin_fabs(c.y2) + __builtin_fabs(l) <
+                    __builtin_inf();
+    key = (f32_order(f32_below(c.x1)) & ~0xffu) | k;
+    lim = (f32_order(f32_above(l)) + 256u) | 0xffu;   // finite limit: at most 0xff7fffff + 256, no wrap
+    yy = make_float2(f32_below(c.y1), f32_above(c.y2));
+    return ok;
 }
 
 // exact f64 test of `cnt` (<= 64) queued pairs from queue slot `first` on; the diagnostic maximum stays in the lane's register
 // (64 LDS atomics on one row's slot serialise: they cost more than the tests)
-template <bool WANT_MAX, int WROWS, int WCAP>
-__device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, WaveLdsF<WROWS, WCAP> &S, int first, int cnt, double thr,
-                                          double thr_lo, double &mxacc) {
+template <bool WANT_MAX>
+__device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, const K2sView &V, int first, int cnt, double thr, double thr_lo,
+                                          double &mxacc) {
     const int lane = threadIdx.x & 63;
     bool hit = false;
     if (lane < cnt) {
-        const uint32_t a = S.qa[first + lane], b = S.qb[first + lane];
+        const uint32_t a = V.qa[first + lane], b = V.qb[first + lane];
         const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;   // the reference's (i < j) argument order
         const Corners p = load_corners(box4, base + lo), q = load_corners(box4, base + hi);
         double mx = 0.0;
@@ -98,22 +142,94 @@ __device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, Wave
     return __any(hit);
 }
 
+// The keys of a row's n boxes are in the lanes' registers (any order, padding 0xffffffff), limits and y intervals in LDS under
+// the box index: sort, sweep, exact tests.  Returns whether a pair reached thr; with WANT_MAX mxacc is every lane's running maximum.
+template <bool WANT_MAX, int E>
+__device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t base, int32_t n, const K2sView &V, uint32_t (&v)[E], double thr,
+                                                 double thr_lo, double &mxacc) {
+    constexpr int P = 64 * E;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    [[maybe_unused]] unsigned long long n_it = 0, n_cand = 0, n_drain = 0;
+    k2s_sort_regs<E>(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) V.skey[lane * E + r] = v[r];
+    wave_sync();
+
+    // ---- sweep: lane = sorted position p, partners p+1, p+2, ... while inside the window ---------------------------
+    int qn = 0;
+    bool any_hit = false;
+    for (int32_t p0 = 0; p0 < n - 1; p0 += kWave) {
+        const int32_t p = p0 + lane;
+        const bool have = p < n - 1;
+        const int ia = (int)(V.skey[have ? p : 0] & 0xffu);
+        const uint32_t lim = have ? V.slim[ia] : 0u;
+        const float2 my = V.syy[ia];
+        for (int32_t d = 1;; ++d) {
+            const int32_t j = p + d;
+            const uint32_t kj = (j < P) ? V.skey[j] : 0xffffffffu;
+            const bool inwin = have && kj <= lim;
+#ifdef K2S_DEBUG
+            n_it += 1;
+#endif
+            if (!__any(inwin)) break;
+            bool cand = false;
+            const int ib = (int)(kj & 0xffu);
+            if (inwin) {
+                const float2 o = V.syy[ib];
+                cand = my.y > o.x && o.y > my.x;   // y intervals overlap (outward-rounded, so never a false reject)
+            }
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                if (cand) {
+                    const int slot = qn + __popcll(m & lt);
+                    V.qa[slot] = (uint32_t)ia;
+                    V.qb[slot] = (uint32_t)ib;
+                }
+                qn += __popcll(m);
+#ifdef K2S_DEBUG
+                n_cand += __popcll(m);
+#endif
+                if (qn >= kWave) {
+                    wave_sync();
+#ifdef K2S_DEBUG
+                    n_drain += 1;
+#endif
+                    any_hit |= k2s_drain<WANT_MAX>(box4, base, V, qn - kWave, kWave, thr, thr_lo, mxacc);
+                    qn -= kWave;
+                    wave_sync();
+                    if (!WANT_MAX && any_hit) break;   // any() is decided
+                }
+            }
+        }
+        if (!WANT_MAX && any_hit) break;
+    }
+    if (qn > 0 && (WANT_MAX || !any_hit)) {
+        wave_sync();
+#ifdef K2S_DEBUG
+        n_drain += 1;
+#endif
+        any_hit |= k2s_drain<WANT_MAX>(box4, base, V, 0, qn, thr, thr_lo, mxacc);
+    }
+    K2S_DBG_ADD(0, 1);
+    K2S_DBG_ADD(2, n_it);
+    K2S_DBG_ADD(3, n_cand);
+    K2S_DBG_ADD(4, n_drain);
+    K2S_DBG_MAX(5, n_it);
+    wave_sync();
+    return any_hit;
+}
+
+// A row whose boxes are in memory (the tile kernels): load, prepare, sweep.  false = not finite, nothing was decided.
 template <bool WANT_MAX, int E, int WROWS, int WCAP>
 __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
                                           int32_t min_boxes, double thr, double thr_lo) {
-    constexpr int P = 64 * E;
-    static_assert(P <= WCAP && WCAP <= 256, "box index lives in 8 key bits");
+    static_assert(64 * E <= WCAP && WCAP <= 256, "box index lives in 8 key bits");
     static_assert(sizeof(S.cf) >= 16 * (size_t)WCAP, "keys + limits + y intervals alias the float4 tile");
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t *skey = reinterpret_cast<uint32_t *>(S.cf);
-    uint32_t *slim = skey + WCAP;
-    float2 *syy = reinterpret_cast<float2 *>(skey + 2 * WCAP);
+    const K2sView V = {skey, skey + WCAP, reinterpret_cast<float2 *>(skey + 2 * WCAP), S.qa, S.qb};
     const double tl = WANT_MAX ? 0.0 : thr_lo;
-
-    // ---- keys (registers), limits and y intervals (LDS, by box index) -------------------------------------------------
-    [[maybe_unused]] const unsigned long long t0 = K2S_CLOCK();
-    [[maybe_unused]] unsigned long long t_drain = 0, n_it = 0, n_cand = 0, n_drain = 0;
     bool bad = false;
     uint32_t v[E];
     wave_sync();
@@ -127,14 +243,12 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
             const double2 *g = reinterpret_cast<const double2 *>(box4 + 4 * (base + k));
             const double2 pa = g[0], pb = g[1];
             const Corners c = {vmin(pa.x, pb.x), vmin(pa.y, pb.y), vmax(pa.x, pb.x), vmax(pa.y, pb.y)};
-            const double lim = c.x2 - tl * (c.x2 - c.x1);
-            // all five finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends
-            // the row to the all-pairs code)
-            bad |= !(__builtin_fabs(pa.x) + __builtin_fabs(pa.y) + __builtin_fabs(pb.x) + __builtin_fabs(pb.y) + __builtin_fabs(lim) <
-                     __builtin_inf());
-            v[r] = (f32_order(f32_below(c.x1)) & ~0xffu) | (uint32_t)k;
-            slim[k] = (f32_order(f32_above(lim)) + 256u) | 0xffu;   // finite lim: at most 0xff7fffff + 256, no wrap
-            syy[k] = make_float2(f32_below(c.y1), f32_above(c.y2));
+            uint32_t lim;
+            float2 yy;
+            // vmin / vmax drop a NaN operand: the finiteness test must see the raw corners as well
+            bad |= !k2s_prepare(c, (uint32_t)k, tl, v[r], lim, yy) || !(pa.x + pa.y + pb.x + pb.y == pa.x + pa.y + pb.x + pb.y);
+            V.slim[k] = lim;
+            V.syy[k] = yy;
         }
     }
     if (__any(bad)) {
@@ -142,84 +256,8 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
         K2S_DBG_ADD(1, 1);
         return false;
     }
-    k2s_sort_regs<E>(v, lane);
-#pragma unroll
-    for (int r = 0; r < E; ++r) skey[lane * E + r] = v[r];
-    wave_sync();
-    [[maybe_unused]] const unsigned long long t1 = K2S_CLOCK();
-
-    // ---- sweep: lane = sorted position p, partners p+1, p+2, ... while inside the window ---------------------------
-    int qn = 0;
-    bool any_hit = false;
     double mxacc = 0.0;
-    for (int32_t p0 = 0; p0 < n - 1; p0 += kWave) {
-        const int32_t p = p0 + lane;
-        const bool have = p < n - 1;
-        const int ia = (int)(skey[have ? p : 0] & 0xffu);
-        const uint32_t lim = have ? slim[ia] : 0u;
-        const float2 my = syy[ia];
-        for (int32_t d = 1;; ++d) {
-            const int32_t j = p + d;
-            const uint32_t kj = (j < P) ? skey[j] : 0xffffffffu;
-            const bool inwin = have && kj <= lim;
-#ifdef K2S_DEBUG
-            n_it += 1;
-#endif
-            if (!__any(inwin)) break;
-            bool cand = false;
-            const int ib = (int)(kj & 0xffu);
-            if (inwin) {
-                const float2 o = syy[ib];
-                cand = my.y > o.x && o.y > my.x;   // y intervals overlap (outward-rounded, so never a false reject)
-            }
-            const unsigned long long m = __ballot(cand);
-            if (m) {
-                if (cand) {
-                    const int slot = qn + __popcll(m & lt);
-                    S.qa[slot] = (uint32_t)ia;
-                    S.qb[slot] = (uint32_t)ib;
-                }
-                qn += __popcll(m);
-#ifdef K2S_DEBUG
-                n_cand += __popcll(m);
-#endif
-                if (qn >= kWave) {
-                    wave_sync();
-#ifdef K2S_DEBUG
-                    n_drain += 1;
-                    const unsigned long long td = K2S_CLOCK();
-#endif
-                    any_hit |= k2s_drain<WANT_MAX>(box4, base, S, qn - kWave, kWave, thr, thr_lo, mxacc);
-#ifdef K2S_DEBUG
-                    t_drain += K2S_CLOCK() - td;
-#endif
-                    qn -= kWave;
-                    wave_sync();
-                    if (!WANT_MAX && any_hit) break;   // any() is decided
-                }
-            }
-        }
-        if (!WANT_MAX && any_hit) break;
-    }
-    if (qn > 0 && (WANT_MAX || !any_hit)) {
-        wave_sync();
-#ifdef K2S_DEBUG
-        n_drain += 1;
-        const unsigned long long td = K2S_CLOCK();
-#endif
-        any_hit |= k2s_drain<WANT_MAX>(box4, base, S, 0, qn, thr, thr_lo, mxacc);
-#ifdef K2S_DEBUG
-        t_drain += K2S_CLOCK() - td;
-#endif
-    }
-    K2S_DBG_ADD(0, 1);
-    K2S_DBG_ADD(2, n_it);
-    K2S_DBG_ADD(3, n_cand);
-    K2S_DBG_ADD(4, n_drain);
-    K2S_DBG_MAX(5, n_it);
-    K2S_DBG_ADD(6, t1 - t0);
-    K2S_DBG_ADD(7, K2S_CLOCK() - t1);
-    K2S_DBG_ADD(8, t_drain);
+    const bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc);
     if (any_hit && n >= min_boxes && lane == 0) S.flag[row] = 1;
     if (WANT_MAX) {
         unsigned long long bits = (unsigned long long)__double_as_longlong(mxacc);   // IoU >= 0: the bit patterns order like the values

@@ -107,10 +107,11 @@ def test_sweep_tables_do_hit(native):
         assert 0 < want.sum() < len(want), name
 
 
-@pytest.mark.parametrize("variant", [-1, 6, 9])
-@pytest.mark.parametrize("bpr", [100, 128, 200, 256])
+@pytest.mark.parametrize("variant", [-1, 6, 9, 10])
+@pytest.mark.parametrize("bpr", [40, 48, 64, 65, 100, 128, 129, 200, 256])
 def test_fused_dense_rows(native, bpr, variant):
-    """the fused launch on tables of dense rows: workgroup tiles hand rows of up to 256 boxes to the sweep"""
+    """the fused launch on tables of dense rows: workgroup tiles (6, 9) and the wave kernel's dense instantiation (10) hand rows of
+    40..256 boxes to the sweep"""
     from deal_yolo_daya_amd import synth
     t = synth.generate(300, seed=bpr, boxes_per_row=bpr)
     L = native.lib()
@@ -124,3 +125,50 @@ def test_fused_dense_rows(native, bpr, variant):
         assert np.array_equal(arg, oarg) and np.array_equal(box.view(np.uint64), obox.view(np.uint64))
         assert np.array_equal(high, ohigh), (bpr, variant, thr)
         assert 0 < ohigh.sum()
+
+
+@pytest.mark.parametrize("variant", [10, -1])
+def test_fused_dense_mixed_rows_and_empty_polygons(native, variant):
+    """rows of every size between 1 and 300 boxes in one table, some polygons without a valid point (the row's IoU list ends there,
+    reference processor.py:254-255 -> :364-365), NaN and inf points: flags, boxes and arg indices against the chain oracle"""
+    rng = np.random.default_rng(77)
+    sizes = np.concatenate([rng.integers(1, 301, size=400), [256, 255, 257, 64, 65, 40, 39, 128, 129, 300]])
+    box_off = np.zeros(len(sizes) + 1, np.int32)
+    np.cumsum(sizes, out=box_off[1:])
+    B = int(box_off[-1])
+    npts = rng.integers(1, 9, size=B)
+    npts[rng.integers(0, B, size=120)] = 0                 # polygons without a valid point
+    pt_off = np.zeros(B + 1, np.int32)
+    np.cumsum(npts, out=pt_off[1:])
+    P = int(pt_off[-1])
+    centre = rng.random((B, 2)) * [1920, 1080]
+    xy = np.repeat(centre, npts, axis=0) + rng.random((P, 2)) * 100 - 50
+    xy = np.round(xy, 1)
+    for r in range(0, len(sizes), 3):                      # a near-duplicate of a random box at the end of every third row
+        s, e = int(box_off[r]), int(box_off[r + 1])
+        if e - s >= 2:
+            src, dst = int(rng.integers(s, e - 1)), e - 1
+            k = min(int(npts[src]), int(npts[dst]))
+            if k == 0:
+                continue
+            xy[pt_off[dst]:pt_off[dst] + k] = xy[pt_off[src]:pt_off[src] + k]
+            xy[pt_off[dst] + k:pt_off[dst + 1]] = xy[pt_off[src]]
+            if k < npts[src]:
+                xy[pt_off[src] + k:pt_off[src + 1]] = xy[pt_off[src]]
+    for b in rng.integers(0, B, size=60):                  # polygons of NaN points only
+        xy[pt_off[b]:pt_off[b + 1]] = np.nan
+    for b in rng.integers(0, B, size=60):                  # an inf or a NaN somewhere
+        if npts[b]:
+            xy[pt_off[b] + int(rng.integers(0, npts[b])), int(rng.integers(0, 2))] = [np.inf, -np.inf, np.nan][int(rng.integers(0, 3))]
+    L = native.lib()
+    native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+    try:
+        res = {(thr, mb): native.bbox_iou_fused(xy, pt_off, box_off, mb, thr, want_box=True) for thr, mb in ((0.98, 2), (0.5, 3), (0.0, 2), (1.0, 2))}
+    finally:
+        native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+    for (thr, mb), (arg, high, box) in res.items():
+        obox, oarg, ohigh = olib.bbox_iou_chain(xy, pt_off, box_off, mb, thr)
+        assert np.array_equal(arg, oarg)
+        assert np.array_equal(box.view(np.uint64), obox.view(np.uint64))
+        assert np.array_equal(high, ohigh), (thr, mb, np.flatnonzero(high != ohigh)[:5], sizes[np.flatnonzero(high != ohigh)[:5]])
+    assert 0 < res[(0.98, 2)][1].sum() < len(sizes)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dense rows (48..256 boxes per image): K2 alone and the fused launch, tile variants side by side in one process.
 K2 variant 3 = 8 rows / 128-box tiles (rows above 128 boxes stream partner tiles: the all-pairs path), 5 = 256-box tiles (rows up to
-256 boxes are sorted by x1 and swept, k2_sweep.h); fused 6 / 9 are the same two tilings behind K1.
+256 boxes are sorted by x1 and swept, k2_sweep.h); fused 6 / 9 are the same two tilings behind K1, fused 10 the wave kernel with
+the sweep built in (k12_wave.h, DENSE).
     python tools/dense_sweep.py [--boxes 4000000]"""
 import argparse
 import json
@@ -57,7 +58,7 @@ def main():
             line[f"k2_v{variant}_max_ms"] = timed(lambda: ck(L.dyd_iou_any_ge_dev(out_box.data_ptr(), box_off.data_ptr(), N, B, 2, 0.98, out_high.data_ptr(),
                                                                                     mx.data_ptr(), sp), "k2max"))
         ck(L.dyd_set_option(b"k2_variant", -1), "opt")
-        for variant in (6, 9, -1, 6, 9, -1):
+        for variant in (6, 9, 10, -1, 6, 9, 10, -1):
             ck(L.dyd_set_option(b"fused_variant", variant), "opt")
             ms = timed(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P, 2, 0.98, out_box.data_ptr(),
                                                            out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"))
