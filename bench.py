@@ -434,7 +434,8 @@ def main():
                        "min_boxes": MIN_BOXES, "iou_threshold": THR, "high_rows_rank0": high_rows,
                        "launch": "fused K1+K2 (dyd_bbox_iou_fused_dev)", "kernel_ms": k_ms,
                        "clock_ramp_launches_before_warmup": ramp_launches, "device": _native.device_name()},
-            "roofline": {"bound": "hbm", "kernel": "k12_wave_kernel (fused K1+K2)",
+            "roofline": {"bound": "hbm", "kernel": ("k12_wave_kernel (fused K1+K2)" if B <= 32 * N else
+                                                    "k12_wave_dense_kernel (fused K1+K2, rows of 40..256 boxes sorted and swept)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,

@@ -78,15 +78,20 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
 }
 
 // the same kernel for tables above 32 boxes per image on average: rows of 40..256 boxes are sorted and swept (k12_wave.h, k2_sweep.h)
-__global__ __launch_bounds__(256) void k12_wave_dense_kernel(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
+// WPE = waves per SIMD the register allocation aims at: 7 (72 VGPRs, 16 bytes of scratch) wins up to 128 boxes per image, 6 (80, none)
+// beyond, where the four-keys-per-lane sort is what runs (tools/dense_sweep.py: 2.13 / 2.25 / 2.54 ms against 2.19 / 2.35 / 2.43 at
+// 64 / 128 / 256 boxes per row)
+constexpr int KWD_ROWS = 8;   // image rows per wave: dense rows are long, half of KW_ROWS keeps twice as many waves in flight on small tables
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void k12_wave_dense_kernel(const double2 *__restrict__ xy, const int32_t *__restrict__ pt_off,
                                                              const int32_t *__restrict__ box_off, int64_t n_rows, int32_t min_boxes,
                                                              double thr, double *out_box4, int32_t *__restrict__ out_arg4,
                                                              uint8_t *__restrict__ out_high, unsigned long long *bigq) {
     __shared__ WaveFuseDense s_all[4];
     const int wave = threadIdx.x >> 6;
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * KW_ROWS;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * KWD_ROWS;
     if (r0 >= n_rows) return;
-    const int nr = (n_rows - r0 < KW_ROWS) ? (int)(n_rows - r0) : KW_ROWS;
+    const int nr = (n_rows - r0 < KWD_ROWS) ? (int)(n_rows - r0) : KWD_ROWS;
     k12_wave_rows<false, true>(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave], bigq);
 }
 
@@ -252,18 +257,23 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         if (rcq) return rcq;
     }
     int v = g_fused_variant;
-    // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes
-    // handed to K2 through LDS); dense rows: workgroup-level fusion with the f32 reject filter in K2
-    // (polygons of 20..48 points: the workgroup tiles keep more lanes walking than a wave's 64-box tile does)
-    if (v < 0) v = (n_boxes <= 32 * n_rows && n_points <= 20 * n_boxes) ? 4 : (n_boxes > 128 * n_rows ? 9 : 6);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
+    // sparse rows (<= 32 boxes per image on average): the wave-autonomous kernel (32 waves per CU, boxes handed to K2 through
+    // LDS); denser tables: its DENSE instantiation (rows of 40..256 boxes sorted and swept; tools/fused_sweep.py and
+    // tools/dense_sweep.py: ahead of the workgroup kernels from 24 boxes per row on, 2.15-2.4 ms against 2.4-2.9 per 64 M boxes);
+    // polygons of 20..48 points: workgroup-level fusion (its tiles keep more lanes walking than a wave's 64-box tile does)
+    if (v < 0) v = (n_points > 20 * n_boxes) ? (n_boxes > 128 * n_rows ? 9 : 6) : (n_boxes <= 32 * n_rows ? 4 : 10);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
     if (v == 10) {   // the wave kernel with sort and sweep for rows of 40..256 boxes
-        const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KW_ROWS);
+        const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KWD_ROWS);
         if (blocks > 0x7fffffffLL) {
             set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
             return DYD_ERR_RANGE;
         }
-        hipLaunchKernelGGL(k12_wave_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const double2 *>(xy), pt_off,
-                           box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq);
+        if (n_boxes > 128 * n_rows)
+            hipLaunchKernelGGL(k12_wave_dense_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const double2 *>(xy),
+                               pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq);
+        else
+            hipLaunchKernelGGL(k12_wave_dense_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const double2 *>(xy),
+                               pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq);
         DYD_HIP(hipGetLastError());
         const int rcb = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
         if (!rcb) release_bigq(st);

@@ -21,7 +21,7 @@ def main():
     def ck(rc, what):
         _native.check(rc, what)
 
-    for bpr in (4, 16, 24, 32, 48, 64, 96, 128):
+    for bpr in (4, 16, 24, 32, 40, 48, 64, 96, 128, 256):
         n = max(1000, 4_000_000 // bpr)
         t = synth.generate(n, seed=7, boxes_per_row=bpr)
         xy = torch.from_numpy(t.xy).to(dev); pt_off = torch.from_numpy(t.pt_off).to(dev); box_off = torch.from_numpy(t.box_off).to(dev)
@@ -29,7 +29,7 @@ def main():
         out_box = torch.empty((B, 4), dtype=torch.float64, device=dev); out_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
         out_high = torch.empty(N, dtype=torch.uint8, device=dev)
         res, highs = {}, {}
-        for variant in (4, 6, -1, 4, 6, -1):
+        for variant in (4, 6, 10, -1, 4, 6, 10, -1):
             ck(L.dyd_set_option(b"fused_variant", variant), "opt")
             ts = []
             for it in range(12):
@@ -43,7 +43,7 @@ def main():
             res.setdefault(variant, []).append(float(np.median(ts)))
             highs[variant] = int(out_high.sum().item())
         ck(L.dyd_set_option(b"fused_variant", -1), "opt")
-        print(json.dumps({"boxes_per_row": bpr, "rows": N, "boxes": B, "wave_ms": round(min(res[4]), 4), "workgroup_filter_ms": round(min(res[6]), 4),
+        print(json.dumps({"boxes_per_row": bpr, "rows": N, "boxes": B, "wave_ms": round(min(res[4]), 4), "workgroup_filter_ms": round(min(res[6]), 4), "wave_dense_ms": round(min(res[10]), 4),
                           "auto_ms": round(min(res[-1]), 4), "same_flags": len(set(highs.values())) == 1}), flush=True)
         del xy, pt_off, box_off, out_box, out_arg, out_high
 
