@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="1 = also time configs[2]'s full pipeline per stage (c3, N=1)")
     ap.add_argument("--exchange", type=int, default=1,
                     help="1 = at N > 1 also time configs[3]'s sharded dedup / reference filter with its all-gathers (after the K steps)")
+    ap.add_argument("--fused-variant", type=int, default=-1, help="A/B only: force a kernel variant of the fused launch (dyd_set_option)")
     args = ap.parse_args()
 
     import torch
@@ -323,6 +324,8 @@ def main():
     L = _native.lib()
     ck = _native.check
 
+    if args.fused_variant >= 0:
+        ck(L.dyd_set_option(b"fused_variant", args.fused_variant), "dyd_set_option")
     rows, bpr, desc = WORKLOADS[args.workload]
     if args.rows:
         rows = args.rows
@@ -432,7 +435,7 @@ def main():
             "data": "synthetic (drawn on the device: synth.generate_device, the distributions of SURVEY §8d)",
             "config": {"workload": desc, "rows_per_gpu": rows, "boxes_per_gpu": B, "points_per_gpu": P,
                        "min_boxes": MIN_BOXES, "iou_threshold": THR, "high_rows_rank0": high_rows,
-                       "launch": "fused K1+K2 (dyd_bbox_iou_fused_dev)", "kernel_ms": k_ms,
+                       "launch": "fused K1+K2 (dyd_bbox_iou_fused_dev)" + (f", forced variant {args.fused_variant}" if args.fused_variant >= 0 else ""), "kernel_ms": k_ms,
                        "clock_ramp_launches_before_warmup": ramp_launches, "device": _native.device_name()},
             "roofline": {"bound": "hbm", "kernel": ("k12_wave_kernel (fused K1+K2)" if B <= 32 * N else
                                                     "k12_wave_dense_kernel (fused K1+K2, rows of 40..256 boxes sorted and swept)"),
