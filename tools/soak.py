@@ -42,7 +42,7 @@ def main():
         rounds += 1
         seed = int(rng.integers(0, 2 ** 31))
         r = np.random.default_rng(seed)
-        what = rounds % 9
+        what = rounds % 10
         ctx = {"round": rounds, "seed": seed, "what": what}
         try:
             if what == 0:      # K1, all three kernels
@@ -62,7 +62,7 @@ def main():
                 box, off = random_boxes(r, n_rows, int(r.integers(1, 90)), True, fixed or None)
                 thr, mb = float(r.choice([0.98, 0.5, 0.0, 1.0, 0.9])), int(r.choice([2, 2, 3, 1]))
                 want, wmx = olib.iou_any_ge(box, off, mb, thr, want_max=True)
-                for v in (-1, 3, 0, 1, 2, 4):
+                for v in (-1, 3, 0, 1, 2, 4, 5):
                     _native.check(L.dyd_set_option(b"k2_variant", v), "opt")
                     got, gmx = _native.iou_any_ge(box, off, mb, thr, want_max=True)
                     assert np.array_equal(got, want) and np.array_equal(gmx.view(np.uint64), wmx.view(np.uint64)), ("k2", v)
@@ -79,7 +79,7 @@ def main():
                 t_xy = torch.from_numpy(np.ascontiguousarray(xy)).to(dev); t_po = torch.from_numpy(poff).to(dev); t_bo = torch.from_numpy(boff).to(dev)
                 t_box = torch.empty((B, 4), dtype=torch.float64, device=dev); t_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
                 t_high = torch.empty(n_rows, dtype=torch.uint8, device=dev)
-                for v in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8):
+                for v in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
                     _native.check(L.dyd_set_option(b"fused_variant", v), "opt")
                     t_box.fill_(-7.0); t_arg.fill_(-7); t_high.fill_(9)
                     _native.check(L.dyd_bbox_iou_fused_dev(t_xy.data_ptr(), t_po.data_ptr(), t_bo.data_ptr(), n_rows, B, int(xy.shape[0]), 2, 0.5,
@@ -152,6 +152,54 @@ def main():
                 assert a1[0][P.BBOX_COL].tolist() == a2[0][P.BBOX_COL].tolist(), "pipeline vs stepwise text"
                 assert a1[2].index.tolist() == a2[2].index.tolist() == np.flatnonzero(ohigh).tolist(), "pipeline / stepwise / oracle HIGH rows"
                 bump("replace_iou")
+            elif what == 9:    # rows of 33..300 boxes (sort and sweep, k2_sweep.h): K2 variants with the maximum, fused variants with the chain rule
+                n_rows = int(r.integers(1, 120))
+                sizes = r.integers(33, 301, size=n_rows)
+                sizes[r.random(n_rows) < 0.15] = r.integers(0, 33, size=int((r.random(n_rows) < 0.15).sum() or 1))[0]
+                boff = np.zeros(n_rows + 1, np.int32); np.cumsum(sizes, out=boff[1:])
+                B = int(boff[-1])
+                style = int(r.integers(0, 5))
+                ctr = r.random((B, 2)) * [1920, 1080]
+                if style == 1:
+                    ctr[:, 0] = np.round(ctr[:, 0] / 120.0) * 120.0          # columns: many boxes share x1
+                elif style == 2:
+                    ctr = ctr * 0.02 + 500.0                                 # one crowded spot
+                elif style == 3:
+                    ctr = ctr * 4096.0 + 16777216.0                          # beyond f32 resolution
+                wh = r.random((B, 2)) * (1.0 if style == 2 else 90.0) + 1.0
+                npts = r.integers(1, 6, size=B)
+                npts[r.random(B) < 0.01] = 0                                 # polygons without a valid point
+                poff = np.zeros(B + 1, np.int32); np.cumsum(npts, out=poff[1:])
+                xy = np.repeat(ctr, npts, axis=0) + (r.random((int(poff[-1]), 2)) - 0.5) * np.repeat(wh, npts, axis=0)
+                if style != 3:
+                    xy = np.round(xy, int(r.integers(0, 3)))
+                for rr in range(0, n_rows, 2):                               # a copy of a random box at the end of every other row
+                    s0, e0 = int(boff[rr]), int(boff[rr + 1])
+                    if e0 - s0 >= 2:
+                        src, dst = int(r.integers(s0, e0 - 1)), e0 - 1
+                        k = min(int(npts[src]), int(npts[dst]))
+                        if k:
+                            xy[poff[dst]:poff[dst] + k] = xy[poff[src]:poff[src] + k]
+                            xy[poff[dst] + k:poff[dst + 1]] = xy[poff[src]]
+                            xy[poff[src] + k:poff[src + 1]] = xy[poff[src]]
+                if r.random() < 0.3 and len(xy):
+                    xy[r.integers(0, len(xy), 5), r.integers(0, 2, 5)] = r.choice([np.nan, np.inf, -np.inf], 5)
+                thr, mb = float(r.choice([0.98, 0.9, 0.5, 0.3, 1.0, 1e-9, 0.0])), int(r.choice([2, 2, 3, 40]))
+                obox, oarg, want = olib.bbox_iou_chain(xy, poff, boff, mb, thr)
+                for v in (-1, 4, 6, 9, 10):
+                    _native.check(L.dyd_set_option(b"fused_variant", v), "opt")
+                    arg, high, box = _native.bbox_iou_fused(xy, poff, boff, mb, thr, want_box=True)
+                    assert np.array_equal(arg, oarg) and same_f64(box, obox), ("dense fused k1", v, style)
+                    assert np.array_equal(high, want), ("dense fused k2", v, style, thr, mb, np.flatnonzero(high != want)[:4].tolist())
+                _native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+                kbox = np.where(np.isnan(obox), 0.0, obox)                     # K2 alone on the boxes (empty polygons as zero boxes)
+                want2, wmx = olib.iou_any_ge(kbox, boff, mb, thr, want_max=True)
+                for v in (-1, 3, 5, 2, 4):
+                    _native.check(L.dyd_set_option(b"k2_variant", v), "opt")
+                    got, gmx = _native.iou_any_ge(kbox, boff, mb, thr, want_max=True)
+                    assert np.array_equal(got, want2) and np.array_equal(gmx.view(np.uint64), wmx.view(np.uint64)), ("dense k2", v, style, thr, mb)
+                _native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
+                bump("dense_rows")
             else:              # K7, every kernel
                 n_rows, mbx = int(r.integers(1, 20000)), int(r.choice([1, 1, 2, 5, 40, 700]))
                 n_rows = min(n_rows, 400000 // mbx + 1)
