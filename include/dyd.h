@@ -380,7 +380,10 @@ void dyd_host_free(void *p);
 
 /* ---- tuning hook (not reference-facing): selects kernel variants for A/B measurement,
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging; "k7_variant": -1 by the table's shape (default),
- * 2 / 22 row tiles (one / two per ticket), 30 box tiles (rows of many boxes). */
+ * 2 / 22 row tiles (one / two per ticket), 30 box tiles (rows of many boxes); "fused_variant": -1 by the table's shape (default:
+ * 4 up to 32 boxes per image on average, 10 beyond, 6 / 9 for polygons of 20..48 points), 4 = wave kernel, 10 = its dense
+ * instantiation (rows of 40..256 boxes sorted and swept), 0 / 2 / 3 / 5 / 6 / 9 = workgroup tilings, 1 = two launches;
+ * "k2_variant": -1 by shape, 4 = the wave kernel's pair stage, 0..3 / 5 = tile kernels (2 / 3 / 5 with the f32 filter and the sweep). */
 int dyd_set_option(const char *key, int64_t value);
 /* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 3-5 the same non-temporal, 16 B per
  * lane) used to record the box's HBM ceiling next to the kernels' achieved GB/s; modes 6 / 7 / 8: one 8-byte word per lane
