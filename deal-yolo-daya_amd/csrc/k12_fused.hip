@@ -213,6 +213,7 @@ void set_k2_variant(int v);
 void set_k7_variant(int v);
 void set_k6_variant(int v);
 void set_k4_capacity_shift(int v);
+void set_k8_band(int v);
 void set_k7_trace(void *p);
 #ifdef K2S_DEBUG
 int set_k2s_debug(void *p);
@@ -397,6 +398,10 @@ int dyd_set_option(const char *key, int64_t value) {
     }
     if (!strcmp(key, "k4_capacity_shift")) {   // test hook: undersized hash table (the failure path must surface)
         set_k4_capacity_shift((int)value);
+        return DYD_OK;
+    }
+    if (!strcmp(key, "k8_band")) {   // 0 = K8 resolves the rejections by full-length rounds only (A/B, tests)
+        set_k8_band((int)value);
         return DYD_OK;
     }
     if (!strcmp(key, "k7_variant")) {

@@ -31,6 +31,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 #include <rocprim/functional.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -184,6 +185,107 @@ struct K8DiffOut {
     __host__ __device__ K8DiffOut &operator+=(difference_type i) { dst += i; old += i; base += (uint32_t)i; return *this; }
 };
 
+// ---- the banded resolve ----------------------------------------------------------------------------------------------------
+// The analytic guess c0(t) is off by the fluctuation of the rejection count, a few standard deviations of sqrt(t - c0(t)) at most.
+// For every count inside the band c0(t) +- K(t) most draws are decided the same way: accepted even at the band's smallest step
+// index, or rejected even at its largest.  Only the draws whose value falls between the two (2K/mask of them: 1-3 % for
+// n >= 2^22) or whose band straddles an octave boundary depend on the exact count.  So: one scan counts the certain acceptances
+// (base), the uncertain draws are compacted into a list, the Picard rounds run on THAT list (count = base + accepted uncertain
+// draws before: the same recurrence, two orders of magnitude shorter), their outcomes are scattered back as a byte per draw,
+// and one more scan yields the exact counts — which are checked against the band they were derived under (a count outside it
+// anywhere voids the result and the full-length rounds run instead).
+constexpr float K8_BAND_SIGMAS = 5.0f;
+__device__ __forceinline__ uint32_t k8_band(uint32_t t, uint32_t c0) {
+    const float r = (float)(t > c0 ? t - c0 : 0u);   // expected rejections so far
+    return (uint32_t)(K8_BAND_SIGMAS * sqrtf(r + 16.0f) + 8.0f);
+}
+// 0 = rejected, 1 = accepted for every count in the band, 2 = depends on the count
+__device__ __forceinline__ uint32_t k8_classify(uint32_t dt, uint32_t t, uint32_t c0, uint32_t n) {
+    const uint32_t K = k8_band(t, c0);
+    const uint32_t lo = c0 > K ? c0 - K : 0u, hi = c0 + K;
+    if (lo >= n - 1u) return 0u;           // every step is done
+    if (hi >= n - 1u) return 2u;
+    const uint32_t i_hi = n - 1u - lo, i_lo = n - 1u - hi;
+    const uint32_t m = k8_mask(i_hi);
+    if (m != k8_mask(i_lo)) return 2u;     // an octave boundary inside the band
+    const uint32_t v = dt & m;
+    return v <= i_lo ? 1u : (v > i_hi ? 0u : 2u);
+}
+struct K8CertainAccept {   // scan input: the certain acceptances
+    const uint32_t *d, *c0;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t t) const { return k8_classify(d[t], t, c0[t], n) == 1u ? 1u : 0u; }
+};
+struct K8Uncertain {       // select flag
+    const uint32_t *d, *c0;
+    uint32_t n;
+    __device__ __forceinline__ bool operator()(uint32_t t) const { return k8_classify(d[t], t, c0[t], n) == 2u; }
+};
+struct K8FlagU {           // the recurrence on the list of uncertain draws: count = base + accepted uncertain draws before
+    const uint32_t *d, *pos, *bu, *cnt_prev;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t u) const {
+        const uint32_t c = bu[u] + cnt_prev[u];
+        if (c >= n - 1u) return 0u;
+        const uint32_t i = n - 1u - c;
+        return ((d[pos[u]] & k8_mask(i)) <= i) ? 1u : 0u;
+    }
+};
+struct K8FlagFinal {       // scan input of the last pass: certain outcomes from the band, the others from the byte array
+    const uint32_t *d, *c0;
+    const uint8_t *mark;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t operator()(uint32_t t) const {
+        const uint32_t k = k8_classify(d[t], t, c0[t], n);
+        return k == 2u ? (uint32_t)mark[t] : k;
+    }
+};
+// output of the last pass: the exact count, checked against the band it was derived under
+struct K8BandOut {
+    uint32_t *dst;
+    const uint32_t *c0;
+    uint32_t *violated;
+    uint32_t base;
+    struct Ref {
+        uint32_t *p;
+        uint32_t c0v, t;
+        uint32_t *violated;
+        __device__ __forceinline__ Ref &operator=(uint32_t v) {
+            const uint32_t K = k8_band(t, c0v);
+            if ((v > c0v ? v - c0v : c0v - v) > K) *violated = 1u;
+            *p = v;
+            return *this;
+        }
+    };
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = uint32_t;
+    using difference_type = std::ptrdiff_t;
+    using pointer = uint32_t *;
+    using reference = Ref;
+    __host__ __device__ Ref operator[](difference_type i) const { return Ref{dst + i, c0[i], base + (uint32_t)i, violated}; }
+    __host__ __device__ Ref operator*() const { return (*this)[0]; }
+    __host__ __device__ K8BandOut operator+(difference_type i) const { return K8BandOut{dst + i, c0 + i, violated, base + (uint32_t)i}; }
+    __host__ __device__ K8BandOut &operator+=(difference_type i) { dst += i; c0 += i; base += (uint32_t)i; return *this; }
+};
+// per uncertain draw: its base count and the first guess of "accepted uncertain draws before it"
+__global__ __launch_bounds__(256) void k8_small_init(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ base,
+                                                     const uint32_t *__restrict__ c0, uint32_t n_u, uint32_t *__restrict__ bu,
+                                                     uint32_t *__restrict__ cntA, uint32_t *__restrict__ cntB) {
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n_u) return;
+    const uint32_t t = pos[u], b = base[t], g = c0[t];
+    const uint32_t c = g > b ? g - b : 0u;
+    bu[u] = b;
+    cntA[u] = c;
+    cntB[u] = c;
+}
+// the outcome of every uncertain draw under the exact counts, as a byte at the draw's place
+__global__ __launch_bounds__(256) void k8_small_mark(K8FlagU f, uint32_t n_u, uint8_t *__restrict__ mark) {
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= n_u) return;
+    mark[f.pos[u]] = (uint8_t)f(u);
+}
+
 // first guess of c(t): inside an octave of mask+1 = M the step index decays like i+1 ~ (i_s+1) exp(-(t-t_s)/M)
 struct K8Octaves {
     int count;
@@ -314,10 +416,100 @@ static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) 
     (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::make_counting_iterator<uint32_t>(0u),
                                     (uint32_t *)nullptr, (size_t)n, 0u, 32u);
     size_t tmp = scan_tmp > sort_tmp ? scan_tmp : sort_tmp;
+    {   // the banded resolve: its scans (certain acceptances, final counts, the short recurrence) and the compaction
+        size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        const auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
+        (void)rocprim::exclusive_scan(nullptr, t1, rocprim::make_transform_iterator(cnt, K8CertainAccept{nullptr, nullptr, n}), (uint32_t *)nullptr, 0u,
+                                      (size_t)draws, rocprim::plus<uint32_t>());
+        (void)rocprim::select(nullptr, t2, cnt, rocprim::make_transform_iterator(cnt, K8Uncertain{nullptr, nullptr, n}), (uint32_t *)nullptr,
+                              (size_t *)nullptr, (size_t)draws);
+        (void)rocprim::exclusive_scan(nullptr, t3, rocprim::make_transform_iterator(cnt, K8FlagFinal{nullptr, nullptr, nullptr, n}),
+                                      K8BandOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
+        (void)rocprim::exclusive_scan(nullptr, t4, rocprim::make_transform_iterator(cnt, K8FlagU{nullptr, nullptr, nullptr, nullptr, n}),
+                                      K8DiffOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
+        for (size_t t : {t1, t2, t3, t4}) tmp = t > tmp ? t : tmp;
+    }
     tmp = (tmp + 255) & ~(size_t)255;
     if (tmp_bytes_out) *tmp_bytes_out = tmp;
     const size_t a = (((size_t)draws * 4) + 255) & ~(size_t)255, b = (((size_t)n * 4) + 255) & ~(size_t)255;
     return 2 * a + 5 * b + tmp + 256;
+}
+
+constexpr uint32_t K8_BAND_MIN_N = 1u << 20;   // below, the uncertain share is large and the full-length rounds are cheap anyway
+static bool g_k8_band = true;                    // A/B and test hook (dyd_set_option "k8_band")
+void set_k8_band(int v) { g_k8_band = v != 0; }
+
+// The banded resolve (see k8_classify).  On success with *resolved = true the exact counts are in cB and the partners in key.
+// The list arrays live in the regions the sort phase uses later: mark | cntB in hs, pos_u in is, bu in last, cntA in pos.
+static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t *cA, uint32_t *cB, uint32_t *hs, uint32_t *is, uint32_t *last,
+                          uint32_t *pos, size_t region_bytes, void *tmp, size_t tmp_bytes, uint32_t *res, uint32_t *key, hipStream_t st,
+                          int *rounds_out, bool *resolved) {
+    *resolved = false;
+    const size_t mark_bytes = (((size_t)draws) + 255) & ~(size_t)255;
+    if (region_bytes < mark_bytes + 1024) return DYD_OK;
+    uint8_t *mark = reinterpret_cast<uint8_t *>(hs);
+    uint32_t *cntB0 = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hs) + mark_bytes);
+    const size_t cap_b = (region_bytes - mark_bytes) / 4, cap = cap_b < (size_t)n ? cap_b : (size_t)n;
+    uint32_t *pos_u = is, *bu = last, *cntA0 = pos;
+    const auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
+    size_t tb = tmp_bytes;
+    // base[t] = certain acceptances before t  (into cB)
+    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8CertainAccept{d, cA, n}), cB, 0u, (size_t)draws,
+                                    rocprim::plus<uint32_t>(), st));
+    // the uncertain draws, in order
+    size_t *n_sel = reinterpret_cast<size_t *>(res + 4);
+    tb = tmp_bytes;
+    DYD_HIP(rocprim::select(tmp, tb, cnt, rocprim::make_transform_iterator(cnt, K8Uncertain{d, cA, n}), key, n_sel, (size_t)draws, st));
+    size_t n_u_host = 0;
+    DYD_HIP(hipMemcpyAsync(&n_u_host, n_sel, sizeof(size_t), hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    if (n_u_host > cap || n_u_host >= (size_t)draws) return DYD_OK;   // not worth it (or no room): the full-length rounds
+    const uint32_t n_u = (uint32_t)n_u_host;
+    // `key` served as the compaction's output: it is the first of five adjacent regions of 4n bytes (20 n >= 4 * draws bytes), none of
+    // which holds anything yet, so even a list of all draws would have stayed inside the work area; a list that fits moves to `is`
+    if (n_u) DYD_HIP(hipMemcpyAsync(pos_u, key, (size_t)n_u * 4, hipMemcpyDeviceToDevice, st));
+    DYD_HIP(hipMemsetAsync(mark, 0, (size_t)draws, st));
+    int rounds = 0;
+    if (n_u) {
+        hipLaunchKernelGGL(k8_small_init, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, pos_u, cB, cA, n_u, bu, cntA0, cntB0);
+        DYD_HIP(hipGetLastError());
+        uint32_t *a = cntA0, *bq = cntB0;
+        uint32_t lo = 0, c_lo = 0;
+        while (lo < n_u) {
+            K8FlagU f{d, pos_u, bu, a, n};
+            auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(lo), f);
+            tb = tmp_bytes;
+            DYD_HIP(hipMemsetAsync(res, 0xff, 4, st));
+            DYD_HIP(rocprim::exclusive_scan(tmp, tb, in, K8DiffOut{bq + lo, a + lo, res, lo}, c_lo, (size_t)(n_u - lo), rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(k8_pick, dim3(1), dim3(64), 0, st, bq, res);
+            DYD_HIP(hipGetLastError());
+            uint32_t host[2] = {0, 0};
+            DYD_HIP(hipMemcpyAsync(host, res, 8, hipMemcpyDeviceToHost, st));
+            DYD_HIP(hipStreamSynchronize(st));
+            ++rounds;
+            uint32_t *t2 = a; a = bq; bq = t2;   // a = the newest counts: exact up to the first difference
+            if (host[0] == 0xffffffffu) break;
+            lo = host[0];
+            c_lo = host[1];
+            if (rounds > 100000) { set_error("K8: the banded resolve did not settle"); return DYD_ERR_HIP; }
+        }
+        hipLaunchKernelGGL(k8_small_mark, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, K8FlagU{d, pos_u, bu, a, n}, n_u, mark);
+        DYD_HIP(hipGetLastError());
+    }
+    // exact counts (into cB, over the base counts that are no longer needed), checked against the band
+    DYD_HIP(hipMemsetAsync(res + 2, 0, 4, st));
+    tb = tmp_bytes;
+    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8FlagFinal{d, cA, mark, n}), K8BandOut{cB, cA, res + 2, 0u}, 0u,
+                                    (size_t)draws, rocprim::plus<uint32_t>(), st));
+    uint32_t violated = 1;
+    DYD_HIP(hipMemcpyAsync(&violated, res + 2, 4, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    if (rounds_out) *rounds_out = rounds;
+    if (violated) return DYD_OK;   // a count left its band somewhere: nothing above is trusted
+    hipLaunchKernelGGL(k8_partners, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, d, cB, n, (int64_t)0, draws, key);
+    DYD_HIP(hipGetLastError());
+    *resolved = true;
+    return DYD_OK;
 }
 
 static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n, void *work, uint32_t *inv32, int64_t *inv64,
@@ -340,11 +532,16 @@ static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n
 
     hipLaunchKernelGGL(k8_guess, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, oc, n, draws, cA);
     DYD_HIP(hipGetLastError());
+    int rounds = 0;
+    bool resolved = false;
+    if (n >= K8_BAND_MIN_N && g_k8_band) {
+        const int rc = resolve_banded(d, draws, n, cA, cB, hs, is, last, pos, b, tmp, tmp_bytes, res, key, st, &rounds, &resolved);
+        if (rc) return rc;
+    }
     // Picard rounds over the not yet final suffix [lo, draws): cB[t] = c_lo + sum of flags(cA) on [lo, t).  Whatever lies before
     // the first difference is final (its flags were computed from exact counts), so the partners of that stretch are written
     // at once and the next round starts there.
-    int rounds = 0;
-    int64_t lo = 0;
+    int64_t lo = resolved ? draws : 0;
     uint32_t c_lo = 0;
     while (lo < draws) {
         K8Flag f{d, cA, n};

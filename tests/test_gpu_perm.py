@@ -55,3 +55,20 @@ def test_split_ids_seeded_matches_the_oracle(native, sizes):
         want = olib.split_ids(cat, perm, off, tr, va)
         got = native.split_ids_seeded(cat, seed, sizes, tr, va)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 1, 1_500_000, (1 << 21) - 1, 1 << 22, 5_000_003, 20_000_000])
+@pytest.mark.parametrize("seed", [42, 7, 2 ** 32 - 1])
+def test_banded_resolve_equals_the_full_length_rounds(native, n, seed):
+    """from 2^20 on K8 resolves the rejections on the short list of count-dependent draws (csrc/k8_perm.hip, k8_classify): same
+    permutation as numpy and as the full-length rounds, octave boundaries (2^k) and both sides of them included"""
+    L = native.lib()
+    want = np.random.RandomState(seed).permutation(n)
+    for band in (1, 0):
+        native.check(L.dyd_set_option(b"k8_band", band), "opt")
+        try:
+            perm, inv = native.mt19937_permutation_device(seed, n, want_inverse=True)
+        finally:
+            native.check(L.dyd_set_option(b"k8_band", 1), "opt")
+        assert np.array_equal(perm, want), band
+        assert np.array_equal(inv[perm], np.arange(n))
