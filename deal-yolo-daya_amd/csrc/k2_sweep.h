@@ -25,11 +25,9 @@ namespace dyd {
 static __device__ unsigned long long *g_k2s_dbg = nullptr;   // experiment counters (tools only; never defined in the product build)
 #define K2S_DBG_ADD(i, v) do { if (g_k2s_dbg && (threadIdx.x & 63) == 0) atomicAdd(&g_k2s_dbg[i], (unsigned long long)(v)); } while (0)
 #define K2S_DBG_MAX(i, v) do { if (g_k2s_dbg && (threadIdx.x & 63) == 0) atomicMax(&g_k2s_dbg[i], (unsigned long long)(v)); } while (0)
-#define K2S_CLOCK() __builtin_readcyclecounter()
 #else
 #define K2S_DBG_ADD(i, v) do {} while (0)
 #define K2S_DBG_MAX(i, v) do {} while (0)
-#define K2S_CLOCK() 0ull
 #endif
 
 #ifndef K2S_MIN_VALUE

@@ -54,8 +54,7 @@ def main():
             c = dbg.cpu().tolist(); dbg.zero_()
             k = max(1, c[0])
             res[mode + "_counters"] = {"rows_swept": c[0] // args.iters, "rows_not_finite": c[1] // args.iters, "iterations_per_row": round(c[2] / k, 2),
-                                       "candidates_per_row": round(c[3] / k, 2), "drains_per_row": round(c[4] / k, 3), "max_iterations": c[5],
-                                       "clk_load_sort_per_row": round(c[6] / k), "clk_sweep_per_row": round(c[7] / k), "clk_drains_per_row": round(c[8] / k)}
+                                       "candidates_per_row": round(c[3] / k, 2), "drains_per_row": round(c[4] / k, 3), "max_iterations": c[5]}
     print(json.dumps({"rows": n, "boxes_per_row": args.bpr, "variant": args.variant, "dup": args.dup, "tie": args.tie, "ms": res}))
 
 
