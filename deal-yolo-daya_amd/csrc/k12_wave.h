@@ -201,6 +201,12 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                 }
                 n = n_eff;  // the row's IoU list ends at its first empty polygon
             }
+            if constexpr (!DENSE) {   // 65..256 boxes in the kernel for sparse tables: the drain kernel sorts and sweeps the row (k2_wave.h)
+                if (n <= K2_BIG_ROW && n >= 2 && n >= min_boxes && !zero_hits && midq_push(bigq, r0 + ra, n)) {
+                    ra += 1;
+                    continue;
+                }
+            }
             if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // thousands of boxes: k2_big_rows_kernel pairs them (k2_wave.h)
                 ra += 1;
                 continue;

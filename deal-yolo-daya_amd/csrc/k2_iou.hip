@@ -178,7 +178,13 @@ int launch_k2(const double *box4, const int32_t *row_off, int64_t n_rows, int32_
 constexpr int32_t K2_BIG_CHUNK = 4096;
 
 struct alignas(16) BigRowLds {
-    double x1[kWave], y1[kWave], x2[kWave], y2[kWave];
+    union {
+        struct {
+            double x1[kWave], y1[kWave], x2[kWave], y2[kWave];
+        };
+        uint32_t sweep[4 * 256];   // a queued row of up to 256 boxes: sorted keys | limits | y intervals (k2_sweep.h)
+    };
+    uint32_t qa[2 * kWave], qb[2 * kWave];
 };
 
 template <bool WANT_MAX>
@@ -196,16 +202,79 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
     const bool zero_hits = (0.0 >= thr);
     const double thr_lo = (thr > 0.0) ? thr * 0.999 : 0.0;
     int64_t item = 0;   // running number of the items, the same in every wave
-    const unsigned long long pushed = bigq[0];
+    const unsigned long long pushed = bigq[0], pushed_mid = bigq[1];
     const int32_t n_big = pushed < (unsigned long long)K2_BIG_LIST ? (int32_t)pushed : K2_BIG_LIST;
+    const int32_t n_mid = pushed_mid < (unsigned long long)K2_MID_LIST ? (int32_t)pushed_mid : K2_MID_LIST;
     // two queues take turns: this launch empties the OTHER one (its last user's drain has finished — same stream, or waited for),
     // so the next launch finds an empty queue without a memset in front of it
-    if (blockIdx.x == 0 && threadIdx.x == 0) bigq_other[0] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        bigq_other[0] = 0ull;
+        bigq_other[1] = 0ull;
+    }
+    // ---- rows of 65..256 boxes deferred by the sparse wave kernel: one row per wave, sorted by x1 and swept (k2_sweep.h) ----
+    if constexpr (!WANT_MAX) {
+        for (int64_t k = me_wave; k < n_mid; k += n_waves) {
+            const unsigned long long *e = bigq + K2_BIGQ_MID0 + 2 * k;
+            const int64_t r = (int64_t)e[0];
+            const int32_t n = (int32_t)e[1];   // 2 .. 256, >= min_boxes, thr > 0 (the pusher checked)
+            const int64_t base = row_off[r];
+            const K2sView V = {S.sweep, S.sweep + 256, reinterpret_cast<float2 *>(S.sweep + 512), S.qa, S.qb};
+            uint32_t vk[4], vl[4];
+            float2 vy[4];
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int32_t b = kWave * q + lane;
+                vk[q] = 0xffffffffu;
+                vl[q] = 0u;
+                vy[q] = make_float2(0.f, 0.f);
+                if (b < n) {
+                    const Corners c = load_corners(box4, base + b);
+                    bad |= !k2s_prepare(c, (uint32_t)b, thr_lo, vk[q], vl[q], vy[q]);
+                }
+            }
+            bool hit = false;
+            if (__any(bad)) {   // a corner that is not finite: all pairs in the reference's (i < j) order
+                double unused = 0.0;
+                for (int32_t i = lane; i < n - 1; i += kWave) {
+                    const Corners me = load_corners(box4, base + i);
+                    const double me_ar = area_of(me);
+                    for (int32_t j = i + 1; j < n; ++j) {
+                        const Corners o = load_corners(box4, base + j);
+                        hit |= pair_hits<false, false>(me, o, me_ar, o, thr, thr_lo, false, unused);
+                    }
+                }
+                hit = __any(hit);
+            } else {
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int32_t b = kWave * q + lane;
+                    if (b < n) {
+                        V.slim[b] = vl[q];
+                        V.syy[b] = vy[q];
+                    }
+                }
+                double unused = 0.0;
+                if (n <= kWave) {
+                    uint32_t v1[1] = {vk[0]};
+                    hit = k2s_sweep_sorted<false, 1>(box4, base, n, V, v1, thr, thr_lo, unused);
+                } else if (n <= 2 * kWave) {
+                    uint32_t v2[2] = {vk[0], vk[1]};
+                    hit = k2s_sweep_sorted<false, 2>(box4, base, n, V, v2, thr, thr_lo, unused);
+                } else {
+                    hit = k2s_sweep_sorted<false, 4>(box4, base, n, V, vk, thr, thr_lo, unused);
+                }
+            }
+            if (hit && lane == 0) out_high[r] = 1;
+            wave_sync();
+        }
+    }
     if (n_big == 0) return;
     for (int32_t k = 0; k < n_big; ++k) {
-        const int64_t r = (int64_t)bigq[1 + 2 * k];
+        const int64_t r = (int64_t)bigq[2 + 2 * k];
         const int64_t base = row_off[r];
-        const int32_t n = (int32_t)bigq[2 + 2 * k];   // boxes to pair: the row's, or its prefix before an empty polygon (fused path)
+        const int32_t n = (int32_t)bigq[3 + 2 * k];   // boxes to pair: the row's, or its prefix before an empty polygon (fused path)
         if (!WANT_MAX && n < min_boxes) continue;
         bool hit = false;
         double mx = 0.0;
@@ -259,7 +328,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
 
 int launch_k2_big_rows(const double *box4, const int32_t *row_off, unsigned long long *bigq, int32_t min_boxes, double thr,
                        uint8_t *out_high, double *out_max, hipStream_t st) {
-    const unsigned blocks = (unsigned)ctx().num_cu * 2;   // 8 waves per CU, striding over the items (an empty queue is the usual case)
+    const unsigned blocks = (unsigned)ctx().num_cu * 4;   // 16 waves per CU, striding over the items (an empty queue is the usual case)
     unsigned long long *base = static_cast<unsigned long long *>(ctx().bigq);
     unsigned long long *other = (bigq == base) ? base + K2_BIGQ_BYTES / 8 : base;
     if (out_max)

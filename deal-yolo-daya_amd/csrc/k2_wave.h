@@ -23,21 +23,30 @@ struct Corners {
 // row stays with its wave as before: a table with thousands of such rows keeps the tile kernel's waves busy anyway.
 constexpr int32_t K2_BIG_ROW = 256;      // rows above this many boxes (the tile kernels hold 128 / 256 per tile)
 constexpr int32_t K2_BIG_LIST = 2048;    // queue capacity
-constexpr size_t K2_BIGQ_BYTES = 8 * (2 + 2 * (size_t)K2_BIG_LIST);   // count + entries of ONE queue (the context holds two, taking turns)
+// The same queue carries a second list: rows of 65..256 boxes met by the SPARSE wave kernel (k12_wave.h), which has neither the
+// registers nor the LDS to sort and sweep them (k2_sweep.h) and would pair them all against all from memory — two orders of magnitude
+// above a row's fair share, so that 2 % of such rows in a table of small ones add 60 % to the launch.  The drain kernel sweeps them,
+// one row per wave.  Layout of ONE queue (u64 words): [0] big pushes, [1] mid pushes, then (row, boxes) pairs of either list.
+constexpr int32_t K2_MID_LIST = 1 << 16;
+constexpr size_t K2_BIGQ_MID0 = 2 + 2 * (size_t)K2_BIG_LIST;                       // first word of the mid list
+constexpr size_t K2_BIGQ_BYTES = 8 * (K2_BIGQ_MID0 + 2 * (size_t)K2_MID_LIST);     // ONE queue (the context holds two, taking turns)
 
-__device__ __forceinline__ bool bigq_push(unsigned long long *q, int64_t row, int32_t n) {   // wave-uniform call
+__device__ __forceinline__ bool k2_queue_push(unsigned long long *q, int which, int64_t row, int32_t n) {   // wave-uniform call
     if (!q) return false;
     unsigned long long idx = 0;
-    if ((threadIdx.x & 63) == 0) idx = atomicAdd(&q[0], 1ull);
+    if ((threadIdx.x & 63) == 0) idx = atomicAdd(&q[which], 1ull);
     idx = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(idx >> 32)) << 32) |
           (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
-    if (idx >= (unsigned long long)K2_BIG_LIST) return false;
+    if (idx >= (unsigned long long)(which ? K2_MID_LIST : K2_BIG_LIST)) return false;
     if ((threadIdx.x & 63) == 0) {
-        q[1 + 2 * idx] = (unsigned long long)row;
-        q[2 + 2 * idx] = (unsigned long long)(unsigned)n;
+        unsigned long long *e = q + (which ? K2_BIGQ_MID0 : 2) + 2 * idx;
+        e[0] = (unsigned long long)row;
+        e[1] = (unsigned long long)(unsigned)n;
     }
     return true;
 }
+__device__ __forceinline__ bool bigq_push(unsigned long long *q, int64_t row, int32_t n) { return k2_queue_push(q, 0, row, n); }
+__device__ __forceinline__ bool midq_push(unsigned long long *q, int64_t row, int32_t n) { return k2_queue_push(q, 1, row, n); }
 
 // per-wave LDS slice: WROWS image rows, at most WCAP boxes staged at a time
 template <int WROWS, int WCAP>

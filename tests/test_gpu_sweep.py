@@ -172,3 +172,54 @@ def test_fused_dense_mixed_rows_and_empty_polygons(native, variant):
         assert np.array_equal(box.view(np.uint64), obox.view(np.uint64))
         assert np.array_equal(high, ohigh), (thr, mb, np.flatnonzero(high != ohigh)[:5], sizes[np.flatnonzero(high != ohigh)[:5]])
     assert 0 < res[(0.98, 2)][1].sum() < len(sizes)
+
+
+@pytest.mark.parametrize("variant", [-1, 4])
+@pytest.mark.parametrize("thr,mb", [(0.98, 2), (0.4, 3), (0.0, 2), (0.98, 100)])
+def test_sparse_table_with_a_heavy_tail(native, variant, thr, mb):
+    """a table of small rows (the sparse wave kernel's) with a few rows of 65..256 boxes and some beyond: the kernel queues them and
+    the drain kernel sorts and sweeps them (k2_wave.h, k2_big_rows_kernel) — flags, boxes and arg indices against the chain oracle,
+    empty polygons (the list's end) and non-finite corners inside the long rows included; K2 alone on the same boxes as well"""
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(0, 21, size=4000)
+    sizes[rng.integers(0, 4000, size=90)] = rng.integers(65, 257, size=90)
+    sizes[rng.integers(0, 4000, size=6)] = rng.integers(257, 700, size=6)
+    sizes[[7, 8, 9]] = [65, 256, 64]
+    box_off = np.zeros(len(sizes) + 1, np.int32)
+    np.cumsum(sizes, out=box_off[1:])
+    B = int(box_off[-1])
+    assert B <= 32 * len(sizes)                               # the automatic choice is the sparse kernel
+    npts = rng.integers(1, 7, size=B)
+    npts[rng.integers(0, B, size=40)] = 0
+    pt_off = np.zeros(B + 1, np.int32)
+    np.cumsum(npts, out=pt_off[1:])
+    centre = rng.random((B, 2)) * [1920, 1080]
+    xy = np.round(np.repeat(centre, npts, axis=0) + rng.random((int(pt_off[-1]), 2)) * 80 - 40, 1)
+    for r in np.flatnonzero(sizes >= 2)[::2]:                 # a copy of a random box at the end of every other row
+        s0, e0 = int(box_off[r]), int(box_off[r + 1])
+        src, dst = int(rng.integers(s0, e0 - 1)), e0 - 1
+        k = min(int(npts[src]), int(npts[dst]))
+        if k:
+            xy[pt_off[dst]:pt_off[dst] + k] = xy[pt_off[src]:pt_off[src] + k]
+            xy[pt_off[dst] + k:pt_off[dst + 1]] = xy[pt_off[src]]
+            xy[pt_off[src] + k:pt_off[src + 1]] = xy[pt_off[src]]
+    xy[rng.integers(0, len(xy), 12), rng.integers(0, 2, 12)] = rng.choice([np.nan, np.inf, -np.inf], 12)
+    L = native.lib()
+    native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+    try:
+        arg, high, box = native.bbox_iou_fused(xy, pt_off, box_off, mb, thr, want_box=True)
+    finally:
+        native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+    obox, oarg, ohigh = olib.bbox_iou_chain(xy, pt_off, box_off, mb, thr)
+    assert np.array_equal(arg, oarg) and np.array_equal(box.view(np.uint64), obox.view(np.uint64))
+    bad = np.flatnonzero(high != ohigh)
+    assert len(bad) == 0, (bad[:6].tolist(), sizes[bad[:6]].tolist())
+    if thr == 0.98 and mb == 2:
+        assert ohigh[sizes > 64].sum() > 10
+    kbox = np.where(np.isnan(obox), 0.0, obox)
+    native.check(L.dyd_set_option(b"k2_variant", 4 if variant == 4 else -1), "opt")
+    try:
+        got = native.iou_any_ge(kbox, box_off, mb, thr)
+    finally:
+        native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
+    assert np.array_equal(got, olib.iou_any_ge(kbox, box_off, mb, thr))
