@@ -328,7 +328,7 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
 
 int launch_k2_big_rows(const double *box4, const int32_t *row_off, unsigned long long *bigq, int32_t min_boxes, double thr,
                        uint8_t *out_high, double *out_max, hipStream_t st) {
-    const unsigned blocks = (unsigned)ctx().num_cu * 4;   // 16 waves per CU, striding over the items (an empty queue is the usual case)
+    const unsigned blocks = (unsigned)ctx().num_cu * 2;   // 8 waves per CU, striding over the items (an empty queue is the usual case)
     unsigned long long *base = static_cast<unsigned long long *>(ctx().bigq);
     unsigned long long *other = (bigq == base) ? base + K2_BIGQ_BYTES / 8 : base;
     if (out_max)

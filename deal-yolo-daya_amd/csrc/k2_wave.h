@@ -27,7 +27,7 @@ constexpr int32_t K2_BIG_LIST = 2048;    // queue capacity
 // registers nor the LDS to sort and sweep them (k2_sweep.h) and would pair them all against all from memory — two orders of magnitude
 // above a row's fair share, so that 2 % of such rows in a table of small ones add 60 % to the launch.  The drain kernel sweeps them,
 // one row per wave.  Layout of ONE queue (u64 words): [0] big pushes, [1] mid pushes, then (row, boxes) pairs of either list.
-constexpr int32_t K2_MID_LIST = 1 << 16;
+constexpr int32_t K2_MID_LIST = 1 << 20;   // 16 MB per queue; a table with more such rows than this is not sparse
 constexpr size_t K2_BIGQ_MID0 = 2 + 2 * (size_t)K2_BIG_LIST;                       // first word of the mid list
 constexpr size_t K2_BIGQ_BYTES = 8 * (K2_BIGQ_MID0 + 2 * (size_t)K2_MID_LIST);     // ONE queue (the context holds two, taking turns)
 
