@@ -207,7 +207,7 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                     continue;
                 }
             }
-            if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // thousands of boxes: k2_big_rows_kernel pairs them (k2_wave.h)
+            if (k2_defer_row<false>(bigq, r0 + ra, n, min_boxes, zero_hits)) {   // hundreds or thousands of boxes: k2_big_rows_kernel (k2_wave.h)
                 ra += 1;
                 continue;
             }

@@ -130,7 +130,7 @@ __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t 
         if (taken == 0) {
             // ---- one row larger than the LDS tile: partner tiles of f32 boxes stream through LDS -----
             const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // left to k2_big_rows_kernel, which spreads it over the grid
+            if (k2_defer_row<WANT_MAX>(bigq, r0 + ra, n, min_boxes, zero_hits)) {   // left to k2_big_rows_kernel
                 ra += 1;
                 continue;
             }

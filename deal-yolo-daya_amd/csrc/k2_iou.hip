@@ -182,7 +182,7 @@ struct alignas(16) BigRowLds {
         struct {
             double x1[kWave], y1[kWave], x2[kWave], y2[kWave];
         };
-        uint32_t sweep[4 * 256];   // a queued row of up to 256 boxes: sorted keys | limits | y intervals (k2_sweep.h)
+        uint32_t sweep[4 * K2_MID_ROW];   // a queued row of up to 1024 boxes: sorted keys | limits | y intervals (k2_sweep.h), 16 KB
     };
     uint32_t qa[2 * kWave], qb[2 * kWave];
 };
@@ -211,62 +211,73 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
         bigq_other[0] = 0ull;
         bigq_other[1] = 0ull;
     }
-    // ---- rows of 65..256 boxes deferred by the sparse wave kernel: one row per wave, sorted by x1 and swept (k2_sweep.h) ----
-    if constexpr (!WANT_MAX) {
+    // ---- the mid list: rows of 65..256 boxes deferred by the sparse wave kernel and rows of 257..1024 boxes deferred by every
+    //      main kernel — one row per wave, sorted by x1 and swept (k2_sweep.h; up to 16 keys per lane) ----
+    {
+        unsigned long long *mx_out = WANT_MAX ? out_max_bits : nullptr;
         for (int64_t k = me_wave; k < n_mid; k += n_waves) {
             const unsigned long long *e = bigq + K2_BIGQ_MID0 + 2 * k;
             const int64_t r = (int64_t)e[0];
-            const int32_t n = (int32_t)e[1];   // 2 .. 256, >= min_boxes, thr > 0 (the pusher checked)
+            const int32_t n = (int32_t)e[1];   // 2 .. 1024 (or fewer with the maximum wanted), thr > 0: the pusher checked
             const int64_t base = row_off[r];
-            const K2sView V = {S.sweep, S.sweep + 256, reinterpret_cast<float2 *>(S.sweep + 512), S.qa, S.qb};
-            uint32_t vk[4], vl[4];
-            float2 vy[4];
+            const K2sView V = {S.sweep, S.sweep + K2_MID_ROW, reinterpret_cast<float2 *>(S.sweep + 2 * K2_MID_ROW), S.qa, S.qb};
+            const double tl = WANT_MAX ? 0.0 : thr_lo;
+            uint32_t vk[16];
             bool bad = false;
+            wave_sync();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 const int32_t b = kWave * q + lane;
                 vk[q] = 0xffffffffu;
-                vl[q] = 0u;
-                vy[q] = make_float2(0.f, 0.f);
-                if (b < n) {
-                    const Corners c = load_corners(box4, base + b);
-                    bad |= !k2s_prepare(c, (uint32_t)b, thr_lo, vk[q], vl[q], vy[q]);
+                if (kWave * q < n) {   // wave-uniform
+                    if (b < n) {
+                        const Corners c = load_corners(box4, base + b);
+                        uint32_t lim;
+                        float2 yy;
+                        bad |= !(n > 256 ? k2s_prepare<10>(c, (uint32_t)b, tl, vk[q], lim, yy) : k2s_prepare<8>(c, (uint32_t)b, tl, vk[q], lim, yy));
+                        V.slim[b] = lim;
+                        V.syy[b] = yy;
+                    }
                 }
             }
             bool hit = false;
-            if (__any(bad)) {   // a corner that is not finite: all pairs in the reference's (i < j) order
-                double unused = 0.0;
+            double mx = 0.0;
+            if (n < 2) {
+            } else if (__any(bad)) {   // a corner that is not finite: all pairs in the reference's (i < j) order
                 for (int32_t i = lane; i < n - 1; i += kWave) {
                     const Corners me = load_corners(box4, base + i);
                     const double me_ar = area_of(me);
                     for (int32_t j = i + 1; j < n; ++j) {
                         const Corners o = load_corners(box4, base + j);
-                        hit |= pair_hits<false, false>(me, o, me_ar, o, thr, thr_lo, false, unused);
+                        hit |= pair_hits<WANT_MAX, false>(me, o, me_ar, o, thr, thr_lo, false, mx);
                     }
                 }
                 hit = __any(hit);
+            } else if (n <= kWave) {
+                uint32_t v1[1] = {vk[0]};
+                hit = k2s_sweep_sorted<WANT_MAX, 1>(box4, base, n, V, v1, thr, thr_lo, mx);
+            } else if (n <= 2 * kWave) {
+                uint32_t v2[2] = {vk[0], vk[1]};
+                hit = k2s_sweep_sorted<WANT_MAX, 2>(box4, base, n, V, v2, thr, thr_lo, mx);
+            } else if (n <= 4 * kWave) {
+                uint32_t v4[4] = {vk[0], vk[1], vk[2], vk[3]};
+                hit = k2s_sweep_sorted<WANT_MAX, 4>(box4, base, n, V, v4, thr, thr_lo, mx);
+            } else if (n <= 8 * kWave) {
+                uint32_t v8[8] = {vk[0], vk[1], vk[2], vk[3], vk[4], vk[5], vk[6], vk[7]};
+                hit = k2s_sweep_sorted<WANT_MAX, 8, 10>(box4, base, n, V, v8, thr, thr_lo, mx);
             } else {
-                wave_sync();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int32_t b = kWave * q + lane;
-                    if (b < n) {
-                        V.slim[b] = vl[q];
-                        V.syy[b] = vy[q];
-                    }
-                }
-                double unused = 0.0;
-                if (n <= kWave) {
-                    uint32_t v1[1] = {vk[0]};
-                    hit = k2s_sweep_sorted<false, 1>(box4, base, n, V, v1, thr, thr_lo, unused);
-                } else if (n <= 2 * kWave) {
-                    uint32_t v2[2] = {vk[0], vk[1]};
-                    hit = k2s_sweep_sorted<false, 2>(box4, base, n, V, v2, thr, thr_lo, unused);
-                } else {
-                    hit = k2s_sweep_sorted<false, 4>(box4, base, n, V, vk, thr, thr_lo, unused);
-                }
+                hit = k2s_sweep_sorted<WANT_MAX, 16, 10>(box4, base, n, V, vk, thr, thr_lo, mx);
             }
-            if (hit && lane == 0) out_high[r] = 1;
+            if (hit && lane == 0 && n >= min_boxes) out_high[r] = 1;
+            if (WANT_MAX) {
+                unsigned long long bits = (unsigned long long)__double_as_longlong(mx);   // IoU >= 0: the bit patterns order like the values
+#pragma unroll
+                for (int dd = 32; dd >= 1; dd >>= 1) {
+                    const unsigned long long o = __shfl_xor(bits, dd);
+                    bits = o > bits ? o : bits;
+                }
+                if (lane == 0 && bits) atomicMax(&mx_out[r], bits);
+            }
             wave_sync();
         }
     }

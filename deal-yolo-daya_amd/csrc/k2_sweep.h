@@ -110,14 +110,18 @@ struct K2sView {
 
 // One box -> its sweep record.  Corners must be normalised (x1 <= x2, y1 <= y2 unless a NaN is involved); returns false when
 // one of them or the limit is not finite (the row must then take the all-pairs code).
+// IB = bits of the key that carry the box index (8: rows of up to 256 boxes, 10: up to 1024): x1 is truncated DOWN by up to 2^IB - 1 ulp and
+// the limit pushed UP by 2^IB .. 2^(IB+1) - 1 ulp.
+template <int IB = 8>
 __device__ __forceinline__ bool k2s_prepare(const Corners &c, uint32_t k, double tl, uint32_t &key, uint32_t &lim, float2 &yy) {
+    constexpr uint32_t IM = (1u << IB) - 1u;
     const double l = c.x2 - tl * (c.x2 - c.x1);
     // all five finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends
     // the row to the all-pairs code)
     const bool ok = __builtin_fabs(c.x1) + __builtin_fabs(c.y1) + __builtin_fabs(c.x2) + __builtin_fabs(c.y2) + __builtin_fabs(l) <
                     __builtin_inf();
-    key = (f32_order(f32_below(c.x1)) & ~0xffu) | k;
-    lim = (f32_order(f32_above(l)) + 256u) | 0xffu;   // finite limit: at most 0xff7fffff + 256, no wrap
+    key = (f32_order(f32_below(c.x1)) & ~IM) | k;
+    lim = (f32_order(f32_above(l)) + (IM + 1u)) | IM;   // finite limit: at most 0xff7fffff + 2^IB, no wrap (padding keys stay above)
     yy = make_float2(f32_below(c.y1), f32_above(c.y2));
     return ok;
 }
@@ -142,10 +146,12 @@ __device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, cons
 
 // The keys of a row's n boxes are in the lanes' registers (any order, padding 0xffffffff), limits and y intervals in LDS under
 // the box index: sort, sweep, exact tests.  Returns whether a pair reached thr; with WANT_MAX mxacc is every lane's running maximum.
-template <bool WANT_MAX, int E>
+template <bool WANT_MAX, int E, int IB = 8>
 __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t base, int32_t n, const K2sView &V, uint32_t (&v)[E], double thr,
                                                  double thr_lo, double &mxacc) {
     constexpr int P = 64 * E;
+    constexpr uint32_t IM = (1u << IB) - 1u;
+    static_assert(P <= (1 << IB), "the box index must fit the key's low bits");
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     [[maybe_unused]] unsigned long long n_it = 0, n_cand = 0, n_drain = 0;
@@ -160,7 +166,7 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
     for (int32_t p0 = 0; p0 < n - 1; p0 += kWave) {
         const int32_t p = p0 + lane;
         const bool have = p < n - 1;
-        const int ia = (int)(V.skey[have ? p : 0] & 0xffu);
+        const int ia = (int)(V.skey[have ? p : 0] & IM);
         const uint32_t lim = have ? V.slim[ia] : 0u;
         const float2 my = V.syy[ia];
         for (int32_t d = 1;; ++d) {
@@ -172,7 +178,7 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
 #endif
             if (!__any(inwin)) break;
             bool cand = false;
-            const int ib = (int)(kj & 0xffu);
+            const int ib = (int)(kj & IM);
             if (inwin) {
                 const float2 o = V.syy[ib];
                 cand = my.y > o.x && o.y > my.x;   // y intervals overlap (outward-rounded, so never a false reject)

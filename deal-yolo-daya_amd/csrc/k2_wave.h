@@ -47,6 +47,19 @@ __device__ __forceinline__ bool k2_queue_push(unsigned long long *q, int which, 
 }
 __device__ __forceinline__ bool bigq_push(unsigned long long *q, int64_t row, int32_t n) { return k2_queue_push(q, 0, row, n); }
 __device__ __forceinline__ bool midq_push(unsigned long long *q, int64_t row, int32_t n) { return k2_queue_push(q, 1, row, n); }
+// A row of more than K2_BIG_ROW boxes leaves the main kernels: up to K2_MID_ROW boxes onto the mid list (sorted and swept by one
+// wave of the drain kernel: 16 keys per lane), beyond onto the big list (all pairs spread over the grid).  true = the row is
+// taken care of (queued, or nothing to do: too few boxes for a flag and no maximum wanted).
+constexpr int32_t K2_MID_ROW = 1024;
+template <bool WANT_MAX>
+__device__ __forceinline__ bool k2_defer_row(unsigned long long *q, int64_t row, int32_t n, int32_t min_boxes, bool zero_hits) {
+    if (n <= K2_BIG_ROW || !q) return false;
+    if (n <= K2_MID_ROW && !zero_hits) {
+        if (!WANT_MAX && (n < 2 || n < min_boxes)) return true;
+        if (midq_push(q, row, n)) return true;
+    }
+    return bigq_push(q, row, n);
+}
 
 // per-wave LDS slice: WROWS image rows, at most WCAP boxes staged at a time
 template <int WROWS, int WCAP>
@@ -186,7 +199,7 @@ __device__ __forceinline__ void k2_wave_rows(const double *box4, const int32_t *
         if (taken == 0) {
             // ---- one row larger than the LDS tile: stream partner tiles through LDS ----------
             const int32_t n = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (n > K2_BIG_ROW && bigq_push(bigq, r0 + ra, n)) {   // left to k2_big_rows_kernel, which spreads it over the grid
+            if (k2_defer_row<WANT_MAX>(bigq, r0 + ra, n, min_boxes, zero_hits)) {   // left to k2_big_rows_kernel
                 ra += 1;
                 continue;
             }

@@ -400,11 +400,13 @@ def test_whole_chain_with_label_replace_matches_the_cpu_port(native, tmp_path, m
                      zip(sheet[P.BBOX_COL], labels, cids, sheet["width"], sheet["height"])] and any(texts)
 
 
-@pytest.mark.parametrize("sizes", [[1025], [3000, 5, 0, 1200], [10, 4100, 2, 1030, 7], [257, 256, 300, 1, 600], [300] * 2100 + [900]])
+@pytest.mark.parametrize("sizes", [[1025], [3000, 5, 0, 1200], [10, 4100, 2, 1030, 7], [257, 256, 300, 1, 600], [300] * 2100 + [900],
+                                   [512, 513, 1023, 1024, 1025, 511, 64, 5, 768]])
 @pytest.mark.parametrize("thr,min_boxes", [(0.98, 2), (0.3, 2), (0.0, 2), (0.98, 5000)])
 def test_k2_rows_of_thousands_of_boxes(native, sizes, thr, min_boxes):
-    """rows above 256 boxes (when a table has few of them) leave the tile kernel for k2_big_rows_kernel (their pairs spread over the grid): same flags and the
-    same maximum IoU as the oracle's double loop, NaN corners and exact ties included"""
+    """rows above 256 boxes leave the main kernel for k2_big_rows_kernel (up to 1024 boxes: sorted and swept by one wave, 8 or 16 keys per
+    lane; beyond: all pairs spread over the grid): same flags and the same maximum IoU as the oracle's double loop, NaN corners and exact
+    ties included"""
     rng = np.random.default_rng(sum(sizes) + int(thr * 100))
     off = np.zeros(len(sizes) + 1, np.int32)
     np.cumsum(sizes, out=off[1:])
