@@ -29,7 +29,10 @@
 
 namespace dyd {
 
-constexpr int KW_ROWS = 16;    // image rows per wave
+#ifndef KW_ROWS_VALUE
+#define KW_ROWS_VALUE 16
+#endif
+constexpr int KW_ROWS = KW_ROWS_VALUE;    // image rows per wave
 constexpr int KW_CHUNK = 256;  // points per LDS piece (4 KiB)
 
 struct alignas(16) WaveFuse {
