@@ -350,15 +350,17 @@ __global__ __launch_bounds__(256) void k8_inverse(const uint32_t *__restrict__ h
                                                   const uint32_t *__restrict__ last, const uint32_t *__restrict__ pos, uint32_t n,
                                                   uint32_t *__restrict__ inv32, int64_t *__restrict__ inv64,
                                                   int64_t *__restrict__ perm64) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t v = is[k];
+    // one thread per VALUE (not per sorted position): last[v] and the result are then read and written in order, and the values
+    // that a later step fetches (most of them) finish without a single random access
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t v = (uint32_t)t;
     const uint32_t lv = last[v];
     uint32_t where;
     if (lv != 0xffffffffu && lv > v) {
         where = lv;                                   // fetched by the first step that targets slot v
     } else {
-        uint32_t kk = (uint32_t)k;                    // v rides step T = is[kk] to slot hs[kk]
+        uint32_t kk = pos[v];                         // v rides its own step T = is[kk] = v to slot hs[kk]
         while (true) {
             const uint32_t slot = hs[kk];
             if (kk > 0 && hs[kk - 1] == slot) { where = is[kk - 1]; break; }   // the next smaller step targeting that slot
