@@ -31,7 +31,6 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_select.hpp>
 #include <rocprim/functional.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -211,15 +210,44 @@ __device__ __forceinline__ uint32_t k8_classify(uint32_t dt, uint32_t t, uint32_
     const uint32_t v = dt & m;
     return v <= i_lo ? 1u : (v > i_hi ? 0u : 2u);
 }
-struct K8CertainAccept {   // scan input: the certain acceptances
+// one scan instead of a scan and a compaction: the certain acceptances in the low word, the uncertain draws in the high word; the
+// output side stores the base count of every draw and, for an uncertain draw, its position at its rank in the list
+struct K8Packed {
     const uint32_t *d, *c0;
     uint32_t n;
-    __device__ __forceinline__ uint32_t operator()(uint32_t t) const { return k8_classify(d[t], t, c0[t], n) == 1u ? 1u : 0u; }
+    __device__ __forceinline__ unsigned long long operator()(uint32_t t) const {
+        const uint32_t k = k8_classify(d[t], t, c0[t], n);
+        return k == 1u ? 1ull : (k == 2u ? (1ull << 32) : 0ull);
+    }
 };
-struct K8Uncertain {       // select flag
+struct K8SplitOut {
+    uint32_t *base, *pos_u;
     const uint32_t *d, *c0;
-    uint32_t n;
-    __device__ __forceinline__ bool operator()(uint32_t t) const { return k8_classify(d[t], t, c0[t], n) == 2u; }
+    uint32_t *total;        // [0] = number of uncertain draws (written by the last draw's store)
+    uint32_t n, cap, last_t, t0;
+    struct Ref {
+        uint32_t *base, *pos_u;
+        const uint32_t *d, *c0;
+        uint32_t *total;
+        uint32_t n, cap, last_t, t;
+        __device__ __forceinline__ Ref &operator=(unsigned long long v) {
+            base[t] = (uint32_t)v;
+            const uint32_t rank = (uint32_t)(v >> 32);
+            const bool unc = k8_classify(d[t], t, c0[t], n) == 2u;
+            if (unc && rank < cap) pos_u[rank] = t;
+            if (t == last_t) *total = rank + (unc ? 1u : 0u);
+            return *this;
+        }
+    };
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = unsigned long long;
+    using difference_type = std::ptrdiff_t;
+    using pointer = unsigned long long *;
+    using reference = Ref;
+    __host__ __device__ Ref operator[](difference_type i) const { return Ref{base, pos_u, d, c0, total, n, cap, last_t, t0 + (uint32_t)i}; }
+    __host__ __device__ Ref operator*() const { return (*this)[0]; }
+    __host__ __device__ K8SplitOut operator+(difference_type i) const { K8SplitOut r = *this; r.t0 += (uint32_t)i; return r; }
+    __host__ __device__ K8SplitOut &operator+=(difference_type i) { t0 += (uint32_t)i; return *this; }
 };
 struct K8FlagU {           // the recurrence on the list of uncertain draws: count = base + accepted uncertain draws before
     const uint32_t *d, *pos, *bu, *cnt_prev;
@@ -421,10 +449,9 @@ static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) 
     {   // the banded resolve: its scans (certain acceptances, final counts, the short recurrence) and the compaction
         size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         const auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
-        (void)rocprim::exclusive_scan(nullptr, t1, rocprim::make_transform_iterator(cnt, K8CertainAccept{nullptr, nullptr, n}), (uint32_t *)nullptr, 0u,
-                                      (size_t)draws, rocprim::plus<uint32_t>());
-        (void)rocprim::select(nullptr, t2, cnt, rocprim::make_transform_iterator(cnt, K8Uncertain{nullptr, nullptr, n}), (uint32_t *)nullptr,
-                              (size_t *)nullptr, (size_t)draws);
+        (void)rocprim::exclusive_scan(nullptr, t1, rocprim::make_transform_iterator(cnt, K8Packed{nullptr, nullptr, n}),
+                                      K8SplitOut{nullptr, nullptr, nullptr, nullptr, nullptr, n, 0u, 0u, 0u}, 0ull, (size_t)draws,
+                                      rocprim::plus<unsigned long long>());
         (void)rocprim::exclusive_scan(nullptr, t3, rocprim::make_transform_iterator(cnt, K8FlagFinal{nullptr, nullptr, nullptr, n}),
                                       K8BandOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
         (void)rocprim::exclusive_scan(nullptr, t4, rocprim::make_transform_iterator(cnt, K8FlagU{nullptr, nullptr, nullptr, nullptr, n}),
@@ -455,21 +482,17 @@ static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t
     uint32_t *pos_u = is, *bu = last, *cntA0 = pos;
     const auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
     size_t tb = tmp_bytes;
-    // base[t] = certain acceptances before t  (into cB)
-    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8CertainAccept{d, cA, n}), cB, 0u, (size_t)draws,
-                                    rocprim::plus<uint32_t>(), st));
-    // the uncertain draws, in order
-    size_t *n_sel = reinterpret_cast<size_t *>(res + 4);
-    tb = tmp_bytes;
-    DYD_HIP(rocprim::select(tmp, tb, cnt, rocprim::make_transform_iterator(cnt, K8Uncertain{d, cA, n}), key, n_sel, (size_t)draws, st));
-    size_t n_u_host = 0;
-    DYD_HIP(hipMemcpyAsync(&n_u_host, n_sel, sizeof(size_t), hipMemcpyDeviceToHost, st));
+    // ONE scan: base[t] = certain acceptances before t (into cB) and the uncertain draws, in order, into the list
+    uint32_t *n_sel = res + 4;
+    DYD_HIP(hipMemsetAsync(n_sel, 0, 4, st));
+    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8Packed{d, cA, n}),
+                                    K8SplitOut{cB, pos_u, d, cA, n_sel, n, (uint32_t)cap, (uint32_t)(draws - 1), 0u}, 0ull, (size_t)draws,
+                                    rocprim::plus<unsigned long long>(), st));
+    uint32_t n_u = 0;
+    DYD_HIP(hipMemcpyAsync(&n_u, n_sel, 4, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
-    if (n_u_host > cap || n_u_host >= (size_t)draws) return DYD_OK;   // not worth it (or no room): the full-length rounds
-    const uint32_t n_u = (uint32_t)n_u_host;
-    // `key` served as the compaction's output: it is the first of five adjacent regions of 4n bytes (20 n >= 4 * draws bytes), none of
-    // which holds anything yet, so even a list of all draws would have stayed inside the work area; a list that fits moves to `is`
-    if (n_u) DYD_HIP(hipMemcpyAsync(pos_u, key, (size_t)n_u * 4, hipMemcpyDeviceToDevice, st));
+    if ((size_t)n_u > cap || (int64_t)n_u >= draws) return DYD_OK;   // not worth it (or no room): the full-length rounds
+    (void)key;
     DYD_HIP(hipMemsetAsync(mark, 0, (size_t)draws, st));
     int rounds = 0;
     if (n_u) {
