@@ -71,9 +71,10 @@ __global__ __launch_bounds__(64 * WPB) void k12_wave_kernel(const double2 *__res
                                                             uint8_t *__restrict__ out_high, unsigned long long *bigq) {
     __shared__ WaveFuse s_all[WPB];
     const int wave = threadIdx.x >> 6;
-    // workgroups are dealt round-robin to the 8 XCDs: with this mapping every XCD streams one contiguous eighth of the table instead of
-    // every eighth workgroup-sized piece (tools/xcd_ab.sh, 10 M rows, alternating: 5.44 / 5.54 / 5.44 ms against 5.53 / 5.55 / 5.54; -DK12_NO_XCD_REMAP = the plain order)
-#ifndef K12_NO_XCD_REMAP
+    // experiment (-DK12_XCD_REMAP; workgroups are dealt round-robin to the 8 XCDs): every XCD streams one contiguous eighth of the table
+    // instead of every eighth workgroup-sized piece.  tools/xcd_ab.sh, 10 M rows: 1-2 % ahead on one box (5.44 / 5.54 / 5.44 ms against
+    // 5.53 / 5.55 / 5.54), 2-4 % behind and erratic on the next (5.77 / 5.78 / 5.46 against 5.54 / 5.57 / 5.53): not the default
+#ifdef K12_XCD_REMAP
     const int64_t per = gridDim.x / 8;
     const int64_t blk = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
 #else
@@ -97,7 +98,13 @@ __global__ __launch_bounds__(256, WPE) void k12_wave_dense_kernel(const double2 
                                                              uint8_t *__restrict__ out_high, unsigned long long *bigq) {
     __shared__ WaveFuseDense s_all[4];
     const int wave = threadIdx.x >> 6;
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * KWD_ROWS;
+#ifdef K12_XCD_REMAP   // as in k12_wave_kernel (experiment)
+    const int64_t per = gridDim.x / 8;
+    const int64_t blk = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+#else
+    const int64_t blk = blockIdx.x;
+#endif
+    const int64_t r0 = (blk * 4 + wave) * KWD_ROWS;
     if (r0 >= n_rows) return;
     const int nr = (n_rows - r0 < KWD_ROWS) ? (int)(n_rows - r0) : KWD_ROWS;
     k12_wave_rows<false, true>(xy, pt_off, box_off, r0, nr, min_boxes, thr, out_box4, out_arg4, out_high, s_all[wave], bigq);
@@ -272,7 +279,10 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     // polygons of 20..48 points: workgroup-level fusion (its tiles keep more lanes walking than a wave's 64-box tile does)
     if (v < 0) v = (n_points > 20 * n_boxes) ? (n_boxes > 128 * n_rows ? 9 : 6) : (n_boxes <= 32 * n_rows ? 4 : 10);   // tools/fused_sweep.py: fixed 32 boxes per row 0.146 vs 0.171 ms, 48: equal, 96: 0.60 vs 0.32
     if (v == 10) {   // the wave kernel with sort and sweep for rows of 40..256 boxes
-        const int64_t blocks = ceil_div(n_rows, (int64_t)4 * KWD_ROWS);
+        int64_t blocks = ceil_div(n_rows, (int64_t)4 * KWD_ROWS);
+#ifdef K12_XCD_REMAP
+        blocks = ceil_div(blocks, 8) * 8;
+#endif
         if (blocks > 0x7fffffffLL) {
             set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
             return DYD_ERR_RANGE;
@@ -291,7 +301,7 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
     if (v == 4 || v == 7 || v == 8) {
         const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
         int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);
-#ifndef K12_NO_XCD_REMAP
+#ifdef K12_XCD_REMAP
         blocks = ceil_div(blocks, 8) * 8;   // the grid is a multiple of 8: workgroups beyond the table leave at once
 #endif
         if (blocks > 0x7fffffffLL) {
