@@ -23,8 +23,6 @@
 // K6 wants exactly this INVERSE (shuffled position of the record with in-category rank v), so its former permutation
 // inversion — a 165 M-word random scatter, 64 % of K6 — disappears with the host loop.
 #include <cmath>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <iterator>
 #include <string>
@@ -309,51 +307,6 @@ __global__ __launch_bounds__(256) void k8_small_init(const uint32_t *__restrict_
     cntA[u] = c;
     cntB[u] = c;
 }
-// After a round the counts are exact up to the first difference; the next K8_SEQ list entries are then walked in order by ONE lane
-// (the others fetch).  The rounds stall on short stretches where each decision tips the next — a round settles half of what is left of
-// such a stretch, 10 rounds for 600 entries — and a sequential walk of 2048 entries costs less than one round's read-back.
-// res[0] = first unsettled entry (0xffffffff: none), res[1] = its exact count; both are moved past the stretch.
-constexpr uint32_t K8_SEQ = 2048;
-__global__ __launch_bounds__(64) void k8_small_seq(K8FlagU f, uint32_t n_u, uint32_t *__restrict__ cnt_new, uint32_t *__restrict__ cnt_old,
-                                                   uint32_t *__restrict__ res) {
-    __shared__ uint32_t sd[64], sb[64], sc[64], s_cnt;
-    const uint32_t first = res[0];
-    if (first == 0xffffffffu) return;
-    const uint32_t end = (n_u - first > K8_SEQ) ? first + K8_SEQ : n_u;
-    const int lane = threadIdx.x;
-    uint32_t cnt = res[1];
-    for (uint32_t u0 = first; u0 < end; u0 += 64) {
-        const uint32_t u = u0 + lane;
-        if (u < end) {
-            sd[lane] = f.d[f.pos[u]];
-            sb[lane] = f.bu[u];
-        }
-        __syncthreads();
-        if (lane == 0) {
-            const uint32_t m = (end - u0 < 64u) ? end - u0 : 64u;
-            for (uint32_t j = 0; j < m; ++j) {
-                sc[j] = cnt;
-                const uint32_t c = sb[j] + cnt;
-                if (c < f.n - 1u) {
-                    const uint32_t i = f.n - 1u - c;
-                    cnt += ((sd[j] & k8_mask(i)) <= i) ? 1u : 0u;
-                }
-            }
-            s_cnt = cnt;
-        }
-        __syncthreads();
-        if (u < end) {
-            cnt_new[u] = sc[lane];
-            cnt_old[u] = sc[lane];
-        }
-        cnt = s_cnt;
-        __syncthreads();
-    }
-    if (lane == 0) {
-        res[0] = end < n_u ? end : 0xffffffffu;
-        res[1] = cnt;
-    }
-}
 // the outcome of every uncertain draw under the exact counts, as a byte at the draw's place
 __global__ __launch_bounds__(256) void k8_small_mark(K8FlagU f, uint32_t n_u, uint8_t *__restrict__ mark) {
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
@@ -554,13 +507,12 @@ static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t
             DYD_HIP(hipMemsetAsync(res, 0xff, 4, st));
             DYD_HIP(rocprim::exclusive_scan(tmp, tb, in, K8DiffOut{bq + lo, a + lo, res, lo}, c_lo, (size_t)(n_u - lo), rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(k8_pick, dim3(1), dim3(64), 0, st, bq, res);
-            hipLaunchKernelGGL(k8_small_seq, dim3(1), dim3(64), 0, st, K8FlagU{d, pos_u, bu, a, n}, n_u, bq, a, res);
             DYD_HIP(hipGetLastError());
             uint32_t host[2] = {0, 0};
             DYD_HIP(hipMemcpyAsync(host, res, 8, hipMemcpyDeviceToHost, st));
             DYD_HIP(hipStreamSynchronize(st));
             ++rounds;
-            uint32_t *t2 = a; a = bq; bq = t2;   // a = the newest counts: exact up to the first difference (and the walked stretch behind it)
+            uint32_t *t2 = a; a = bq; bq = t2;   // a = the newest counts: exact up to the first difference
             if (host[0] == 0xffffffffu) break;
             lo = host[0];
             c_lo = host[1];
