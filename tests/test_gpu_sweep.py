@@ -223,3 +223,32 @@ def test_sparse_table_with_a_heavy_tail(native, variant, thr, mb):
     finally:
         native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
     assert np.array_equal(got, olib.iou_any_ge(kbox, box_off, mb, thr))
+
+
+@pytest.mark.parametrize("thr", [float("nan"), float("inf"), -float("inf"), 1e-300, 5e-324, 1.0000000000000002, 0.9999999999999999])
+def test_odd_thresholds_on_dense_rows(native, thr):
+    """thresholds no UI sends but the C ABI accepts: the sweep's window arithmetic must not turn them into something else (NaN: nothing
+    is >= NaN; inf: nothing; tiny positive: every intersecting pair; the neighbours of 1.0: identical boxes only / also almost identical)"""
+    box, off = TABLES["integers"]
+    L = native.lib()
+    for variant in (-1, 3, 5):
+        native.check(L.dyd_set_option(b"k2_variant", variant), "opt")
+        try:
+            got = native.iou_any_ge(box, off, 2, thr)
+            gmx = native.iou_any_ge(box, off, 2, thr, want_max=True)
+        finally:
+            native.check(L.dyd_set_option(b"k2_variant", -1), "opt")
+        want = olib.iou_any_ge(box, off, 2, thr, want_max=True)
+        assert np.array_equal(got, want[0]) and np.array_equal(gmx[0], want[0]), (thr, variant)
+        assert np.array_equal(gmx[1].view(np.uint64), want[1].view(np.uint64)), (thr, variant)
+    t = TABLES["uniform"]
+    from deal_yolo_daya_amd import synth
+    tb = synth.generate(200, seed=3, boxes_per_row=150)
+    for variant in (-1, 4, 6, 10):
+        native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+        try:
+            arg, high = native.bbox_iou_fused(tb.xy, tb.pt_off, tb.box_off, 2, thr)
+        finally:
+            native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+        _, oarg, ohigh = olib.bbox_iou_chain(tb.xy, tb.pt_off, tb.box_off, 2, thr)
+        assert np.array_equal(arg, oarg) and np.array_equal(high, ohigh), (thr, variant)
