@@ -1,22 +1,25 @@
-// k2_sweep.h — K2 for a row of 40..256 boxes: sort by the left edge, then only look at the partners that can still reach thr.
+// k2_sweep.h — K2 for a row of 40..1024 boxes: sort by the left edge, then only look at the partners that can still reach thr.
 //
 // The pair loops of k2_wave.h / k2_filter.h visit all n(n-1)/2 pairs of a row (reference core/processor.py:368-376,
 // `any(calculate_iou(...) >= thr ...)` over i < j); for a row of 256 boxes that is 32 640 reject tests, 510 trips per lane,
-// and the table of configs[4] (256 boxes per image) is bound by exactly that loop.  Most of those pairs cannot hit:
+// and the table of configs[4] (256 boxes per image) was bound by exactly that loop.  Most of those pairs cannot hit:
 //   IoU >= thr  =>  inter >= thr * union >= thr * area_a  and  inter_h <= h_a  =>  inter_w >= thr * w_a
 //   inter_w <= x2_a - x1_b                                                      =>  x1_b <= x2_a - thr * w_a =: lim_a
 // for EITHER box of the pair as `a` (no assumption on which one lies further left).  So with the row's boxes ordered by x1,
 // box a only has to meet the boxes after it while their x1 stays <= lim_a — for thr = 0.98 a window of 2 % of its width.
 // The test is only a filter: what passes it (and a y-overlap test) is queued and decided by the exact f64 code
-// (k2f_drain), so rounding in the filter may only ever ADMIT pairs.  Hence: thr_lo = 0.999 thr instead of thr (the
-// margin pair_hits already uses for its division shortcut), x1 rounded down and lim rounded up to f32, the low 8 bits
-// of the (order-preserving) key given to the box index — x1 is truncated DOWN by up to 255 ulp, lim pushed UP by
-// 256..511 ulp.  A row holding a corner that is not finite, or whose lim overflows, is left to the all-pairs code.
-// For the diagnostic maximum (WANT_MAX) the window is the overlap window, lim_a = x2_a: every pair with a non-empty
+// (k2s_drain -> pair_hits), so rounding in the filter may only ever ADMIT pairs.  Hence: thr_lo = 0.999 thr instead of thr (the
+// margin pair_hits already uses for its division shortcut), x1 bounded from below and lim from above in f32 (k2_filter.h), the low
+// IB = 8 or 10 bits of the (order-preserving) key given to the box index — x1 is truncated DOWN by up to 2^IB - 1 ulp, lim pushed
+// UP by 2^IB .. 2^(IB+1) - 1 ulp.  A row holding a corner that is not finite, or whose lim overflows, is left to the all-pairs
+// code.  For the diagnostic maximum (WANT_MAX) the window is the overlap window, lim_a = x2_a: every pair with a non-empty
 // intersection is evaluated, the others contribute the 0.0 the maximum starts from.
+// tests/test_sweep_filter_cpu.py restates the filter in numpy and checks the argument; tests/test_gpu_sweep.py checks the kernels.
 //
-// LDS: the wave's float4 tile (k2_filter.h) is reused as sorted keys u32[WCAP] | limits u32[WCAP] | (y1, y2) f32[WCAP][2].
-// Sort: bitonic network over 64, 128 or 256 keys held in registers, one, two or four per lane (padding keys 0xffffffff sort last and pass no window).
+// Pieces: k2s_prepare (a box -> key, limit, y interval), k2s_sort_regs (bitonic network over 64 * E keys held E per lane, E = 1 .. 16;
+// padding keys 0xffffffff sort last and pass no window), k2s_sweep_sorted (sort, sweep, exact tests; arrays through a K2sView of the
+// caller's LDS), k2s_row (a row whose boxes are in memory: the tile kernels).  Callers that have the boxes in registers (k12_wave.h,
+// DENSE) or more LDS (k2_big_rows_kernel: rows of up to 1024 boxes) use the pieces directly.
 #pragma once
 
 namespace dyd {
