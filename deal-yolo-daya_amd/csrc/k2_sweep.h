@@ -1,21 +1,18 @@
-// k2_sweep.h — K2 for a row of 40..1024 boxes: sort by the top-left corner's diagonal, then only look at the partners that can still reach thr.
+// k2_sweep.h — K2 for a row of 40..1024 boxes: sort by the left edge, then only look at the partners that can still reach thr.
 //
 // The pair loops of k2_wave.h / k2_filter.h visit all n(n-1)/2 pairs of a row (reference core/processor.py:368-376,
 // `any(calculate_iou(...) >= thr ...)` over i < j); for a row of 256 boxes that is 32 640 reject tests, 510 trips per lane,
 // and the table of configs[4] (256 boxes per image) was bound by exactly that loop.  Most of those pairs cannot hit:
 //   IoU >= thr  =>  inter >= thr * union >= thr * area_a  and  inter_h <= h_a  =>  inter_w >= thr * w_a
-//   inter_w <= x2_a - x1_b                                                      =>  x1_b <= x2_a - thr * w_a
-// and the same in y, for EITHER box of the pair as `a` (no assumption on which one lies further left).  Added up:
-//   s_b := x1_b + y1_b  <=  (x2_a - thr * w_a) + (y2_a - thr * h_a)  =: lim_a.
-// So with the row's boxes ordered by s (their top-left corner projected on the diagonal: a column of equal x1 or a line of equal
-// y1 still spreads out), box a only has to meet the boxes after it while their s stays <= lim_a — for thr = 0.98 a window of
-// 2 % of its width plus height.
+//   inter_w <= x2_a - x1_b                                                      =>  x1_b <= x2_a - thr * w_a =: lim_a
+// for EITHER box of the pair as `a` (no assumption on which one lies further left).  So with the row's boxes ordered by x1,
+// box a only has to meet the boxes after it while their x1 stays <= lim_a — for thr = 0.98 a window of 2 % of its width.
 // The test is only a filter: what passes it (and a y-overlap test) is queued and decided by the exact f64 code
 // (k2s_drain -> pair_hits), so rounding in the filter may only ever ADMIT pairs.  Hence: thr_lo = 0.999 thr instead of thr (the
-// margin pair_hits already uses for its division shortcut), s bounded from below and lim from above in f32 (k2_filter.h), the low
-// IB = 8 or 10 bits of the (order-preserving) key given to the box index — s is truncated DOWN by up to 2^IB - 1 ulp, lim pushed
+// margin pair_hits already uses for its division shortcut), x1 bounded from below and lim from above in f32 (k2_filter.h), the low
+// IB = 8 or 10 bits of the (order-preserving) key given to the box index — x1 is truncated DOWN by up to 2^IB - 1 ulp, lim pushed
 // UP by 2^IB .. 2^(IB+1) - 1 ulp.  A row holding a corner that is not finite, or whose lim overflows, is left to the all-pairs
-// code.  For the diagnostic maximum (WANT_MAX) the window is the overlap window, lim_a = x2_a + y2_a: every pair with a non-empty
+// code.  For the diagnostic maximum (WANT_MAX) the window is the overlap window, lim_a = x2_a: every pair with a non-empty
 // intersection is evaluated, the others contribute the 0.0 the maximum starts from.
 // tests/test_sweep_filter_cpu.py restates the filter in numpy and checks the argument; tests/test_gpu_sweep.py checks the kernels.
 //
@@ -121,15 +118,12 @@ struct K2sView {
 template <int IB = 8>
 __device__ __forceinline__ bool k2s_prepare(const Corners &c, uint32_t k, double tl, uint32_t &key, uint32_t &lim, float2 &yy) {
     constexpr uint32_t IM = (1u << IB) - 1u;
-    // the sort axis is the diagonal: s = x1 + y1 against lim = (x2 - tl w) + (y2 - tl h) — the x bound and the same bound in y added
-    // up.  Along x alone a column of boxes (text lines, table cells: equal x1) would all sit in one another's window
-    const double sk = c.x1 + c.y1;
-    const double l = (c.x2 - tl * (c.x2 - c.x1)) + (c.y2 - tl * (c.y2 - c.y1));
-    // all finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends the row
-    // to the all-pairs code)
-    const bool ok = __builtin_fabs(c.x1) + __builtin_fabs(c.y1) + __builtin_fabs(c.x2) + __builtin_fabs(c.y2) + __builtin_fabs(l) +
-                    __builtin_fabs(sk) < __builtin_inf();
-    key = (f32_order(f32_below(sk)) & ~IM) | k;
+    const double l = c.x2 - tl * (c.x2 - c.x1);
+    // all five finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends
+    // the row to the all-pairs code)
+    const bool ok = __builtin_fabs(c.x1) + __builtin_fabs(c.y1) + __builtin_fabs(c.x2) + __builtin_fabs(c.y2) + __builtin_fabs(l) <
+                    __builtin_inf();
+    key = (f32_order(f32_below(c.x1)) & ~IM) | k;
     lim = (f32_order(f32_above(l)) + (IM + 1u)) | IM;   // finite limit: at most 0xff7fffff + 2^IB, no wrap (padding keys stay above)
     yy = make_float2(f32_below(c.y1), f32_above(c.y2));
     return ok;

@@ -1,6 +1,6 @@
 """The sort-and-sweep filter of csrc/k2_sweep.h, restated in numpy: whatever the exact f64 test (the oracle's calculate_iou,
 reference core/processor.py:328-339) calls a hit must lie inside the window the filter leaves open — for either box of the pair as
-the one that is met first in the sorted order — and pass its y test.  This pins the ARGUMENT (window derivation, outward f32 bounds, key
+the one that is met first in x1 order — and pass its y test.  This pins the ARGUMENT (window derivation, outward f32 bounds, key
 truncation, limit slack); the kernels themselves are compared with the oracle on the GPU (tests/test_gpu_sweep.py)."""
 import numpy as np
 import pytest
@@ -24,15 +24,13 @@ def _push(v, sign):
 
 
 def _records(box, thr, ib=8):
-    """per box: key (bound of x1 + y1 | index), limit, y interval — k2s_prepare"""
+    """per box: key (x1 bound | index), limit, y interval — k2s_prepare"""
     x1, y1 = np.minimum(box[:, 0], box[:, 2]), np.minimum(box[:, 1], box[:, 3])
     x2, y2 = np.maximum(box[:, 0], box[:, 2]), np.maximum(box[:, 1], box[:, 3])
     tl = thr * 0.999
-    with np.errstate(over="ignore", invalid="ignore"):
-        lim = (x2 - tl * (x2 - x1)) + (y2 - tl * (y2 - y1))
-        sk = x1 + y1
+    lim = x2 - tl * (x2 - x1)
     im = np.uint32((1 << ib) - 1)
-    key = (_f32_order(_push(sk, -1)) & ~im) | np.arange(len(box), dtype=np.uint32)
+    key = (_f32_order(_push(x1, -1)) & ~im) | np.arange(len(box), dtype=np.uint32)
     limit = (_f32_order(_push(lim, +1)) + (im + np.uint32(1))) | im
     return key, limit, _push(y1, -1), _push(y2, +1)
 

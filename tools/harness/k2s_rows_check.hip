@@ -20,9 +20,8 @@ __global__ __launch_bounds__(256) void rows_kernel(const double *box4, const int
     k2f_wave_rows<WANT_MAX, 8, 256>(box4, row_off, r0, nr, 2, thr, out_high, out_max, s_all[wave], nullptr);
 }
 static uint32_t ordf(float f) { uint32_t b; memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-// k2_filter.h f32_below / f32_above on the host
-static float below(double v) { float f = fminf((float)v, 3.402823466e+38f); return fmaf(-fabsf(f), 0x1p-23f, f) - 0x1p-120f; }
-static float above(double v) { float f = fmaxf((float)v, -3.402823466e+38f); return fmaf(fabsf(f), 0x1p-23f, f) + 0x1p-120f; }
+static float below(double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -INFINITY); return f; }
+static float above(double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, INFINITY); return f; }
 int main(int argc, char **argv) {
     const int n = 256, rows = argc > 1 ? atoi(argv[1]) : 64;
     srand(7);
@@ -53,9 +52,9 @@ int main(int argc, char **argv) {
             const double *bb = b.data() + 4 * (size_t)n * r;
             std::vector<uint32_t> key(n), lim(n); std::vector<float> y1(n), y2(n);
             for (int k = 0; k < n; ++k) {
-                double x1 = bb[4 * k], x2 = bb[4 * k + 2], yy1 = bb[4 * k + 1], yy2 = bb[4 * k + 3];
-                key[k] = (ordf(below(x1 + yy1)) & ~0xffu) | k;
-                lim[k] = (ordf(above((x2 - tl * (x2 - x1)) + (yy2 - tl * (yy2 - yy1)))) + 256u) | 0xffu;
+                double x1 = bb[4 * k], x2 = bb[4 * k + 2];
+                key[k] = (ordf(below(x1)) & ~0xffu) | k;
+                lim[k] = (ordf(above(x2 - tl * (x2 - x1))) + 256u) | 0xffu;
                 y1[k] = below(bb[4 * k + 1]); y2[k] = above(bb[4 * k + 3]);
             }
             std::vector<uint32_t> s = key; std::sort(s.begin(), s.end());
