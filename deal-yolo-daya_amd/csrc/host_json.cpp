@@ -16,6 +16,7 @@
 // reference maps them to None (:280-281).
 //
 // Threads: cells are independent; both entry points split the cell range over std::threads.
+#include <sys/mman.h>
 #include <algorithm>
 #include <charconv>
 #include <chrono>

@@ -34,6 +34,20 @@ struct Raw {
         if (!q) throw std::bad_alloc();
         p = q;
         cap = c;
+        huge_hint(q, c * sizeof(T));
+    }
+    // The arrays of a million-cell pass are hundreds of megabytes per thread: in 4 KB pages that is a million first-touch faults
+    // while scanning and a million page-table entries to tear down when the pass is freed (0.15 s per million cells).  Where the
+    // kernel offers transparent huge pages on request (`madvise` mode) the 2 MB-aligned inside of a big array asks for them.
+    static void huge_hint(void *q, size_t bytes) {
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+        if (bytes < (size_t)8 << 20) return;
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(q) + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+        const uintptr_t e = (reinterpret_cast<uintptr_t>(q) + bytes) & ~(((uintptr_t)2 << 20) - 1);
+        if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+#else
+        (void)q; (void)bytes;
+#endif
     }
     inline void need(size_t k) { if (n + k > cap) grow(n + k); }
     inline void push(T v) { if (n == cap) grow(n + 1); p[n++] = v; }
