@@ -1478,18 +1478,7 @@ int dyd_synth_json(const double *xy, const int32_t *pt_off, const int32_t *box_o
     return DYD_OK;
 }
 
-// The parts of a big pass are returned to the kernel side by side (one thread per part: most of an munmap is freeing pages, which
-// the kernel does outside the address-space lock); the caller still waits for all of it, unlike a detached reaper.
-void dyd_scan_free(dyd_scan *h) {
-    if (!h) return;
-    if (h->parts.size() > 1 && h->n_cells >= 65536) {
-        try {
-            parallel_index_safe((int)h->parts.size(), [&](int k) { h->parts[(size_t)k].reset(); });
-        } catch (...) {   // no threads to be had: the destructor below frees what is left
-        }
-    }
-    delete h;
-}
+void dyd_scan_free(dyd_scan *h) { delete h; }
 
 // Scan bbox-JSON cells for the IoU step (processor.py:341-366): two-point boxes per row with the
 // prefix-on-exception rule.  status[i] = 0 regular, 2 = Python path.  Arrays are owned by the handle
