@@ -428,6 +428,15 @@ static double expected_draws(uint32_t n, K8Octaves *oc) {
     return t;
 }
 
+// The (partner, step) sort: keys of at most 30 bits.  rocprim's gfx950 default takes 8 bits per pass — four passes for the 27 bits of
+// 82.5 M records, the last one for 3 bits; 9 bits per pass make it three.
+#ifndef K8_SORT_BITS
+#define K8_SORT_BITS 9
+#endif
+using K8SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>,
+                                                                                    K8_SORT_BITS, rocprim::block_radix_rank_algorithm::match>>;
+
 struct PermScratch {
     uint32_t *d = nullptr;          // tempered stream
     int64_t n_draws = 0;            // words of d (multiple of 624)
@@ -443,7 +452,7 @@ static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) 
     K8Flag f{nullptr, nullptr, n};
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), f);
     (void)rocprim::exclusive_scan(nullptr, scan_tmp, in, K8DiffOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
-    (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::make_counting_iterator<uint32_t>(0u),
+    (void)rocprim::radix_sort_pairs<K8SortConfig>(nullptr, sort_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::make_counting_iterator<uint32_t>(0u),
                                     (uint32_t *)nullptr, (size_t)n, 0u, 32u);
     size_t tmp = scan_tmp > sort_tmp ? scan_tmp : sort_tmp;
     {   // the banded resolve: its scans (certain acceptances, final counts, the short recurrence) and the compaction
@@ -611,7 +620,7 @@ static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n
     unsigned bits = 1;
     while (bits < 32 && (1ull << bits) < (unsigned long long)n) ++bits;
     size_t tb = tmp_bytes;
-    DYD_HIP(rocprim::radix_sort_pairs(tmp, tb, key, hs, rocprim::make_counting_iterator<uint32_t>(0u), is, (size_t)n, 0u, bits, st));
+    DYD_HIP(rocprim::radix_sort_pairs<K8SortConfig>(tmp, tb, key, hs, rocprim::make_counting_iterator<uint32_t>(0u), is, (size_t)n, 0u, bits, st));
     DYD_HIP(hipMemsetAsync(last, 0xff, (size_t)n * 4, st));
     hipLaunchKernelGGL(k8_last, dim3(gn), dim3(256), 0, st, hs, is, n, last, pos);
     DYD_HIP(hipGetLastError());
