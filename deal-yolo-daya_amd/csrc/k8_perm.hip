@@ -44,6 +44,7 @@ namespace dyd {
 
 constexpr int K8_MT_N = 624;
 constexpr int K8_MT_THREADS = 640;   // 10 waves, lanes 624..639 idle
+constexpr size_t K8_HEAD_BYTES = (((size_t)34 * K8_MT_N * 4) + 4095) & ~(size_t)4095;   // seeded state + the 33 head blocks, untempered
 
 __device__ __forceinline__ uint32_t k8_twist(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
@@ -115,10 +116,18 @@ __global__ __launch_bounds__(K8_MT_THREADS) void k8_mt_stream(uint32_t seed, int
         if (k < K8_MT_N)
             for (int wd = 0; wd < K8_MT_N; ++wd) {
                 uint32_t bits = g[wd];   // the same word for every lane
-                while (bits) {
-                    const int bit = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    acc ^= k8_raw(seeded, out, base + wd * 32 + bit);
+                if (pass == 0) {   // the first 19937 + 624 raw words, kept untempered behind the stream by `head`
+                    while (bits) {
+                        const int bit = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        acc ^= seeded[base + wd * 32 + bit];
+                    }
+                } else {
+                    while (bits) {
+                        const int bit = __builtin_ctz(bits);
+                        bits &= bits - 1;
+                        acc ^= k8_raw(seeded, out, base + wd * 32 + bit);
+                    }
                 }
             }
         if (k < K8_MT_N) st[0][k] = acc;
@@ -131,6 +140,7 @@ __global__ __launch_bounds__(K8_MT_THREADS) void k8_mt_stream(uint32_t seed, int
             const uint32_t v = k8_next_word(st[cur], k);
             st[cur ^ 1][k] = v;
             dst[b * K8_MT_N + k] = k8_temper(v);
+            if (head) seeded[(b + 1) * K8_MT_N + k] = v;   // raw copy of the head's 33 blocks: what every jump of pass 0 reads
         }
         __syncthreads();
         cur ^= 1;
@@ -653,7 +663,7 @@ int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *
         int64_t draws = (int64_t)(e * margin + 16.0 * sqrt(2.0 * (double)n_max) + 8192.0);
         const int64_t n_blocks = ceil_div(draws, K8_MT_N);
         draws = n_blocks * K8_MT_N;
-        const size_t d_bytes = ((((size_t)draws * 4) + 255) & ~(size_t)255) + 4096;   // + the seeded state
+        const size_t d_bytes = ((((size_t)draws * 4) + 255) & ~(size_t)255) + K8_HEAD_BYTES;   // + the seeded state and the head's raw words
         // every category gets its own work area and (below) its own stream and host thread: the resolve is a chain of ~40
         // small dependent launches with an 8-byte read-back each, which leaves the device mostly idle — several categories
         // side by side cost little more than one
@@ -669,7 +679,7 @@ int k8_permutations(uint32_t seed, const int64_t *sizes, int n_sizes, uint32_t *
         int rc = get_scratch(d_bytes + work, &scr, st);
         if (rc) return rc;
         uint32_t *d = static_cast<uint32_t *>(scr);
-        uint32_t *seeded = reinterpret_cast<uint32_t *>(static_cast<char *>(scr) + d_bytes - 4096);   // 624 words behind the stream
+        uint32_t *seeded = reinterpret_cast<uint32_t *>(static_cast<char *>(scr) + d_bytes - K8_HEAD_BYTES);   // 34 x 624 raw words behind the stream
         // the first 33 blocks by one workgroup, then every pass of K8_JUMP_W chunks in parallel (a pass reads the one before)
         hipLaunchKernelGGL(k8_mt_stream, dim3(1), dim3(K8_MT_THREADS), 0, st, seed, 0, 1, n_blocks, seeded, d);
         DYD_HIP(hipGetLastError());
