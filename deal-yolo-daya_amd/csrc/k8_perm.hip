@@ -278,20 +278,25 @@ struct K8FlagFinal {       // scan input of the last pass: certain outcomes from
         return k == 2u ? (uint32_t)mark[t] : k;
     }
 };
-// output of the last pass: the exact count, checked against the band it was derived under
+// output of the last pass: the exact count, checked against the band it was derived under — and, since the count says which step the
+// draw belongs to, the partner of that step straight away (what k8_partners does for the full-length rounds)
 struct K8BandOut {
     uint32_t *dst;
-    const uint32_t *c0;
-    uint32_t *violated;
-    uint32_t base;
+    const uint32_t *c0, *d;
+    uint32_t *key, *violated;
+    uint32_t n, base;
     struct Ref {
-        uint32_t *p;
-        uint32_t c0v, t;
-        uint32_t *violated;
+        uint32_t *p, *key, *violated;
+        uint32_t c0v, dv, n, t;
         __device__ __forceinline__ Ref &operator=(uint32_t v) {
             const uint32_t K = k8_band(t, c0v);
             if ((v > c0v ? v - c0v : c0v - v) > K) *violated = 1u;
             *p = v;
+            if (t == 0u) key[0] = 0u;   // step 0 does not exist: a no-op
+            if (v < n - 1u) {
+                const uint32_t i = n - 1u - v, h = dv & k8_mask(i);
+                if (h <= i) key[i] = h;
+            }
             return *this;
         }
     };
@@ -300,10 +305,10 @@ struct K8BandOut {
     using difference_type = std::ptrdiff_t;
     using pointer = uint32_t *;
     using reference = Ref;
-    __host__ __device__ Ref operator[](difference_type i) const { return Ref{dst + i, c0[i], base + (uint32_t)i, violated}; }
+    __host__ __device__ Ref operator[](difference_type i) const { return Ref{dst + i, key, violated, c0[i], d[i], n, base + (uint32_t)i}; }
     __host__ __device__ Ref operator*() const { return (*this)[0]; }
-    __host__ __device__ K8BandOut operator+(difference_type i) const { return K8BandOut{dst + i, c0 + i, violated, base + (uint32_t)i}; }
-    __host__ __device__ K8BandOut &operator+=(difference_type i) { dst += i; c0 += i; base += (uint32_t)i; return *this; }
+    __host__ __device__ K8BandOut operator+(difference_type i) const { return K8BandOut{dst + i, c0 + i, d + i, key, violated, n, base + (uint32_t)i}; }
+    __host__ __device__ K8BandOut &operator+=(difference_type i) { dst += i; c0 += i; d += i; base += (uint32_t)i; return *this; }
 };
 // per uncertain draw: its base count and the first guess of "accepted uncertain draws before it"
 __global__ __launch_bounds__(256) void k8_small_init(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ base,
@@ -472,7 +477,7 @@ static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) 
                                       K8SplitOut{nullptr, nullptr, nullptr, nullptr, nullptr, n, 0u, 0u, 0u}, 0ull, (size_t)draws,
                                       rocprim::plus<unsigned long long>());
         (void)rocprim::exclusive_scan(nullptr, t3, rocprim::make_transform_iterator(cnt, K8FlagFinal{nullptr, nullptr, nullptr, n}),
-                                      K8BandOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
+                                      K8BandOut{nullptr, nullptr, nullptr, nullptr, nullptr, n, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
         (void)rocprim::exclusive_scan(nullptr, t4, rocprim::make_transform_iterator(cnt, K8FlagU{nullptr, nullptr, nullptr, nullptr, n}),
                                       K8DiffOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
         for (size_t t : {t1, t2, t3, t4}) tmp = t > tmp ? t : tmp;
@@ -511,7 +516,6 @@ static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t
     DYD_HIP(hipMemcpyAsync(&n_u, n_sel, 4, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
     if ((size_t)n_u > cap || (int64_t)n_u >= draws) return DYD_OK;   // not worth it (or no room): the full-length rounds
-    (void)key;
     DYD_HIP(hipMemsetAsync(mark, 0, (size_t)draws, st));
     int rounds = 0;
     if (n_u) {
@@ -543,15 +547,13 @@ static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t
     // exact counts (into cB, over the base counts that are no longer needed), checked against the band
     DYD_HIP(hipMemsetAsync(res + 2, 0, 4, st));
     tb = tmp_bytes;
-    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8FlagFinal{d, cA, mark, n}), K8BandOut{cB, cA, res + 2, 0u}, 0u,
+    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8FlagFinal{d, cA, mark, n}), K8BandOut{cB, cA, d, key, res + 2, n, 0u}, 0u,
                                     (size_t)draws, rocprim::plus<uint32_t>(), st));
     uint32_t violated = 1;
     DYD_HIP(hipMemcpyAsync(&violated, res + 2, 4, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
     if (rounds_out) *rounds_out = rounds;
-    if (violated) return DYD_OK;   // a count left its band somewhere: nothing above is trusted
-    hipLaunchKernelGGL(k8_partners, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, d, cB, n, (int64_t)0, draws, key);
-    DYD_HIP(hipGetLastError());
+    if (violated) return DYD_OK;   // a count left its band somewhere: nothing above is trusted (the full-length rounds rewrite every partner)
     *resolved = true;
     return DYD_OK;
 }
