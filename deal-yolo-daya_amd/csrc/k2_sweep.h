@@ -115,15 +115,20 @@ struct K2sView {
 // one of them or the limit is not finite (the row must then take the all-pairs code).
 // IB = bits of the key that carry the box index (8: rows of up to 256 boxes, 10: up to 1024): x1 is truncated DOWN by up to 2^IB - 1 ulp and
 // the limit pushed UP by 2^IB .. 2^(IB+1) - 1 ulp.
+// diag: sort axis = the top-left corner's diagonal, s = x1 + y1 against lim = (x2 - tl w) + (y2 - tl h) — the x bound and the same bound
+// in y added up.  Valid for the same reason, but without the x test the x order gives for free (twice the exact tests on ordinary
+// tables), so it is only the second attempt for a row whose x1 order degenerates (a column of boxes with equal x1, see k2s_retry_diag).
 template <int IB = 8>
-__device__ __forceinline__ bool k2s_prepare(const Corners &c, uint32_t k, double tl, uint32_t &key, uint32_t &lim, float2 &yy) {
+__device__ __forceinline__ bool k2s_prepare(const Corners &c, uint32_t k, double tl, uint32_t &key, uint32_t &lim, float2 &yy, bool diag = false) {
     constexpr uint32_t IM = (1u << IB) - 1u;
-    const double l = c.x2 - tl * (c.x2 - c.x1);
-    // all five finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends
-    // the row to the all-pairs code)
-    const bool ok = __builtin_fabs(c.x1) + __builtin_fabs(c.y1) + __builtin_fabs(c.x2) + __builtin_fabs(c.y2) + __builtin_fabs(l) <
-                    __builtin_inf();
-    key = (f32_order(f32_below(c.x1)) & ~IM) | k;
+    const double lx = c.x2 - tl * (c.x2 - c.x1);
+    const double sk = diag ? c.x1 + c.y1 : c.x1;
+    const double l = diag ? lx + (c.y2 - tl * (c.y2 - c.y1)) : lx;
+    // all finite?  one sum of magnitudes (NaN and inf propagate; a sum of huge finite values that overflows only sends the row to
+    // the all-pairs code)
+    const bool ok = __builtin_fabs(c.x1) + __builtin_fabs(c.y1) + __builtin_fabs(c.x2) + __builtin_fabs(c.y2) + __builtin_fabs(l) +
+                    __builtin_fabs(sk) < __builtin_inf();
+    key = (f32_order(f32_below(sk)) & ~IM) | k;
     lim = (f32_order(f32_above(l)) + (IM + 1u)) | IM;   // finite limit: at most 0xff7fffff + 2^IB, no wrap (padding keys stay above)
     yy = make_float2(f32_below(c.y1), f32_above(c.y2));
     return ok;
@@ -149,9 +154,11 @@ __device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, cons
 
 // The keys of a row's n boxes are in the lanes' registers (any order, padding 0xffffffff), limits and y intervals in LDS under
 // the box index: sort, sweep, exact tests.  Returns whether a pair reached thr; with WANT_MAX mxacc is every lane's running maximum.
+// budget > 0: give up (*aborted = true, nothing decided unless a hit was already found) once the loop has made more trips than that —
+// the sign of a row whose keys do not spread (every box in every other's window); the caller then tries the other sort axis.
 template <bool WANT_MAX, int E, int IB = 8>
 __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t base, int32_t n, const K2sView &V, uint32_t (&v)[E], double thr,
-                                                 double thr_lo, double &mxacc) {
+                                                 double thr_lo, double &mxacc, int32_t budget = 0, bool *aborted = nullptr) {
     constexpr int P = 64 * E;
     constexpr uint32_t IM = (1u << IB) - 1u;
     static_assert(P <= (1 << IB), "the box index must fit the key's low bits");
@@ -165,8 +172,9 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
 
     // ---- sweep: lane = sorted position p, partners p+1, p+2, ... while inside the window ---------------------------
     int qn = 0;
-    bool any_hit = false;
-    for (int32_t p0 = 0; p0 < n - 1; p0 += kWave) {
+    int32_t trips = 0;
+    bool any_hit = false, gave_up = false;
+    for (int32_t p0 = 0; p0 < n - 1 && !gave_up; p0 += kWave) {
         const int32_t p = p0 + lane;
         const bool have = p < n - 1;
         const int ia = (int)(V.skey[have ? p : 0] & IM);
@@ -180,6 +188,10 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
             n_it += 1;
 #endif
             if (!__any(inwin)) break;
+            if (budget > 0 && ++trips > budget) {   // wave-uniform
+                gave_up = true;
+                break;
+            }
             bool cand = false;
             const int ib = (int)(kj & IM);
             if (inwin) {
@@ -211,6 +223,10 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
         }
         if (!WANT_MAX && any_hit) break;
     }
+    if (gave_up && (WANT_MAX || !any_hit)) {   // the queued pairs are dropped: the second attempt meets them again
+        if (aborted) *aborted = true;
+        qn = 0;
+    }
     if (qn > 0 && (WANT_MAX || !any_hit)) {
         wave_sync();
 #ifdef K2S_DEBUG
@@ -225,6 +241,37 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
     K2S_DBG_MAX(5, n_it);
     wave_sync();
     return any_hit;
+}
+
+// Second attempt for a row that the x1 order could not spread (k2s_sweep_sorted gave up): the boxes are read back from memory, keyed by
+// the diagonal and swept without a budget.  Should the diagonal sums overflow, the x1 order runs again to the end instead.
+template <bool WANT_MAX, int E, int IB = 8>
+__device__ __forceinline__ bool k2s_retry_diag(const double *box4, int64_t base, int32_t n, const K2sView &V, double tl, double thr, double thr_lo,
+                                               double &mxacc) {
+    const int lane = threadIdx.x & 63;
+    K2S_DBG_ADD(9, 1);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool diag = attempt == 0;
+        uint32_t v[E];
+        bool bad = false;
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int32_t k = lane + kWave * r;
+            v[r] = 0xffffffffu;
+            if (k < n) {
+                const Corners c = load_corners(box4, base + k);
+                uint32_t lim;
+                float2 yy;
+                bad |= !k2s_prepare<IB>(c, (uint32_t)k, tl, v[r], lim, yy, diag);
+                V.slim[k] = lim;
+                V.syy[k] = yy;
+            }
+        }
+        if (diag && __any(bad)) continue;
+        return k2s_sweep_sorted<WANT_MAX, E, IB>(box4, base, n, V, v, thr, thr_lo, mxacc);
+    }
+    return false;
 }
 
 // A row whose boxes are in memory (the tile kernels): load, prepare, sweep.  false = not finite, nothing was decided.
@@ -264,7 +311,9 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
         return false;
     }
     double mxacc = 0.0;
-    const bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc);
+    bool aborted = false;
+    bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc, n, &aborted);
+    if (aborted) any_hit = k2s_retry_diag<WANT_MAX, E>(box4, base, n, V, tl, thr, thr_lo, mxacc);
     if (any_hit && n >= min_boxes && lane == 0) S.flag[row] = 1;
     if (WANT_MAX) {
         unsigned long long bits = (unsigned long long)__double_as_longlong(mxacc);   // IoU >= 0: the bit patterns order like the values

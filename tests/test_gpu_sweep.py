@@ -50,6 +50,9 @@ def _tables():
     col = np.repeat(rng.integers(0, 4, size=B) * 300.0, 1)
     yy = rng.random(B) * 5000
     out["columns"] = (_plant(rng, np.stack([col, yy, col + 200, yy + 30], axis=1), off), off)
+    # ONE column: the x1 order cannot spread the row at all — the sweep gives up after n trips and sorts along the diagonal instead
+    yy1 = rng.random(B) * 20000
+    out["one_column"] = (_plant(rng, np.stack([np.full(B, 100.0), yy1, np.full(B, 300.0), yy1 + 30], axis=1), off), off)
     # everything on one spot: the sweep degenerates to all pairs
     jit = rng.random((B, 4)) * 1e-3
     out["one_spot"] = (_plant(rng, np.array([100.0, 100.0, 180.0, 160.0]) + jit, off, every=3), off)
@@ -101,7 +104,7 @@ def test_sweep_flags_and_maximum(native, name, variant):
 
 def test_sweep_tables_do_hit(native):
     """sanity of the tables themselves: the planted partners make some rows HIGH and leave others not"""
-    for name in ("uniform", "columns", "beyond_f32", "small", "large"):
+    for name in ("uniform", "columns", "one_column", "beyond_f32", "small", "large"):
         box, off = TABLES[name]
         want = olib.iou_any_ge(box, off, 2, 0.98)
         assert 0 < want.sum() < len(want), name
@@ -252,3 +255,33 @@ def test_odd_thresholds_on_dense_rows(native, thr):
             native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
         _, oarg, ohigh = olib.bbox_iou_chain(tb.xy, tb.pt_off, tb.box_off, 2, thr)
         assert np.array_equal(arg, oarg) and np.array_equal(high, ohigh), (thr, variant)
+
+
+@pytest.mark.parametrize("variant", [-1, 4, 6, 9, 10])
+def test_fused_rows_in_one_column(native, variant):
+    """rows whose boxes all share x1 (text lines, table cells): the fused kernels' sweeps give up on the x1 order and the row is swept along
+    the diagonal (in place, or by the drain kernel for the wave kernels) — same flags as the chain oracle"""
+    rng = np.random.default_rng(9)
+    sizes = np.array([256, 200, 130, 100, 64, 50, 41, 300, 700, 20, 256, 256] * 4)
+    box_off = _offsets(sizes)
+    B = int(box_off[-1])
+    y = rng.random(B) * 30000
+    x0 = np.repeat(rng.integers(0, 3, size=len(sizes)) * 500.0, sizes)
+    corners = np.stack([x0, y, x0 + 200, y + 30], axis=1)
+    for r in range(0, len(sizes), 2):                          # a near copy somewhere in every other row
+        s0, e0 = int(box_off[r]), int(box_off[r + 1])
+        i, j = rng.choice(np.arange(s0, e0), size=2, replace=False)
+        corners[j] = corners[i]
+        corners[j, 3] -= 0.3 * ((r // 2) % 3)                   # identical, 1 % lower, 2 % lower
+    xy = corners[:, [0, 1, 2, 1, 2, 3, 0, 3]].reshape(-1, 2)    # four points per polygon
+    pt_off = (np.arange(B + 1) * 4).astype(np.int32)
+    L = native.lib()
+    native.check(L.dyd_set_option(b"fused_variant", variant), "opt")
+    try:
+        res = {thr: native.bbox_iou_fused(xy, pt_off, box_off, 2, thr) for thr in (0.98, 0.5)}
+    finally:
+        native.check(L.dyd_set_option(b"fused_variant", -1), "opt")
+    for thr, (arg, high) in res.items():
+        _, oarg, ohigh = olib.bbox_iou_chain(xy, pt_off, box_off, 2, thr)
+        assert np.array_equal(arg, oarg) and np.array_equal(high, ohigh), (variant, thr, np.flatnonzero(high != ohigh)[:5].tolist())
+        assert 0 < ohigh.sum() < len(sizes)
