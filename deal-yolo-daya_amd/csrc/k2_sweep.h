@@ -277,7 +277,7 @@ __device__ __forceinline__ bool k2s_retry_diag(const double *box4, int64_t base,
 // A row whose boxes are in memory (the tile kernels): load, prepare, sweep.  false = not finite, nothing was decided.
 template <bool WANT_MAX, int E, int WROWS, int WCAP>
 __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
-                                          int32_t min_boxes, double thr, double thr_lo) {
+                                          int32_t min_boxes, double thr, double thr_lo, int32_t budget, bool *aborted) {
     static_assert(64 * E <= WCAP && WCAP <= 256, "box index lives in 8 key bits");
     static_assert(sizeof(S.cf) >= 16 * (size_t)WCAP, "keys + limits + y intervals alias the float4 tile");
     const int lane = threadIdx.x & 63;
@@ -311,9 +311,11 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
         return false;
     }
     double mxacc = 0.0;
-    bool aborted = false;
-    bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc, n, &aborted);
-    if (aborted) any_hit = k2s_retry_diag<WANT_MAX, E>(box4, base, n, V, tl, thr, thr_lo, mxacc);
+    const bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc, budget, aborted);
+    if (aborted && *aborted) {   // nothing decided: the caller hands the row on (or calls again without a budget)
+        wave_sync();
+        return true;
+    }
     if (any_hit && n >= min_boxes && lane == 0) S.flag[row] = 1;
     if (WANT_MAX) {
         unsigned long long bits = (unsigned long long)__double_as_longlong(mxacc);   // IoU >= 0: the bit patterns order like the values
@@ -328,15 +330,16 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
     return true;
 }
 
+// budget / aborted: see k2s_sweep_sorted (0 / nullptr: sweep to the end whatever it takes)
 template <bool WANT_MAX, int WROWS, int WCAP>
 __device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
-                                        int32_t min_boxes, double thr, double thr_lo) {
+                                        int32_t min_boxes, double thr, double thr_lo, int32_t budget = 0, bool *aborted = nullptr) {
     static_assert(WCAP == 128 || WCAP == 256, "one, two or four keys per lane");
     if constexpr (WCAP == 256) {
-        if (n > 128) return k2s_row_e<WANT_MAX, 4>(box4, base, n, row, S, min_boxes, thr, thr_lo);
+        if (n > 128) return k2s_row_e<WANT_MAX, 4>(box4, base, n, row, S, min_boxes, thr, thr_lo, budget, aborted);
     }
-    if (n > 64) return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo);
-    return k2s_row_e<WANT_MAX, 1>(box4, base, n, row, S, min_boxes, thr, thr_lo);
+    if (n > 64) return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo, budget, aborted);
+    return k2s_row_e<WANT_MAX, 1>(box4, base, n, row, S, min_boxes, thr, thr_lo, budget, aborted);
 }
 
 }  // namespace dyd
