@@ -119,16 +119,12 @@ __device__ __forceinline__ void k2f_wave_rows(const double *box4, const int32_t 
         const int32_t base = __builtin_amdgcn_readlane(my_off, ra);
         {   // ---- a row of many boxes that fits the tile: sorted by x1 and swept (k2_sweep.h) -----
             const int32_t n0 = __builtin_amdgcn_readlane(my_off, ra + 1) - base;
-            if (n0 >= K2S_MIN && n0 <= WCAP && !zero_hits && (WANT_MAX || n0 >= min_boxes)) {
-                // a budget of n0 trips: a row the x1 order cannot spread (a column of boxes) goes to the drain kernel, which tries the
-                // diagonal (k2s_retry_diag); with a full queue the all-pairs code below takes the row (there is no budget without a queue)
-                bool ab = false;
-                bool done = k2s_row<WANT_MAX>(box4, (int64_t)base, n0, ra, S, min_boxes, thr, thr_lo, bigq ? n0 : 0, &ab);
-                if (done && ab && !midq_push(bigq, r0 + ra, n0)) done = false;   // the all-pairs code below
-                if (done) {
-                    ra += 1;
-                    continue;
-                }
+            // (no trip budget here, unlike the fused wave kernels: the bookkeeping costs these kernels 5-10 % on ordinary dense tables —
+            // 8 more VGPRs in the 256-box tiling — and a row the x1 order cannot spread is "only" back to all-pairs cost)
+            if (n0 >= K2S_MIN && n0 <= WCAP && !zero_hits && (WANT_MAX || n0 >= min_boxes) &&
+                k2s_row<WANT_MAX>(box4, (int64_t)base, n0, ra, S, min_boxes, thr, thr_lo)) {
+                ra += 1;
+                continue;
             }
         }
         const unsigned long long fits = __ballot(lane > ra && lane <= nr && my_off - base <= WCAP);
