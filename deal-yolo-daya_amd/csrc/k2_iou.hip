@@ -257,22 +257,22 @@ __global__ __launch_bounds__(K2_BLOCK) void k2_big_rows_kernel(const double *__r
                 bool ab = false;
                 if (n <= kWave) {
                     uint32_t v1[1] = {vk[0]};
-                    hit = k2s_sweep_sorted<WANT_MAX, 1>(box4, base, n, V, v1, thr, thr_lo, mx, n, &ab);
+                    hit = k2s_sweep_sorted<WANT_MAX, 1, 8, true>(box4, base, n, V, v1, thr, thr_lo, mx, n, &ab);
                     if (ab) hit = k2s_retry_diag<WANT_MAX, 1>(box4, base, n, V, tl, thr, thr_lo, mx);
                 } else if (n <= 2 * kWave) {
                     uint32_t v2[2] = {vk[0], vk[1]};
-                    hit = k2s_sweep_sorted<WANT_MAX, 2>(box4, base, n, V, v2, thr, thr_lo, mx, n, &ab);
+                    hit = k2s_sweep_sorted<WANT_MAX, 2, 8, true>(box4, base, n, V, v2, thr, thr_lo, mx, n, &ab);
                     if (ab) hit = k2s_retry_diag<WANT_MAX, 2>(box4, base, n, V, tl, thr, thr_lo, mx);
                 } else if (n <= 4 * kWave) {
                     uint32_t v4[4] = {vk[0], vk[1], vk[2], vk[3]};
-                    hit = k2s_sweep_sorted<WANT_MAX, 4>(box4, base, n, V, v4, thr, thr_lo, mx, n, &ab);
+                    hit = k2s_sweep_sorted<WANT_MAX, 4, 8, true>(box4, base, n, V, v4, thr, thr_lo, mx, n, &ab);
                     if (ab) hit = k2s_retry_diag<WANT_MAX, 4>(box4, base, n, V, tl, thr, thr_lo, mx);
                 } else if (n <= 8 * kWave) {
                     uint32_t v8[8] = {vk[0], vk[1], vk[2], vk[3], vk[4], vk[5], vk[6], vk[7]};
-                    hit = k2s_sweep_sorted<WANT_MAX, 8, 10>(box4, base, n, V, v8, thr, thr_lo, mx, n, &ab);
+                    hit = k2s_sweep_sorted<WANT_MAX, 8, 10, true>(box4, base, n, V, v8, thr, thr_lo, mx, n, &ab);
                     if (ab) hit = k2s_retry_diag<WANT_MAX, 8, 10>(box4, base, n, V, tl, thr, thr_lo, mx);
                 } else {
-                    hit = k2s_sweep_sorted<WANT_MAX, 16, 10>(box4, base, n, V, vk, thr, thr_lo, mx, n, &ab);
+                    hit = k2s_sweep_sorted<WANT_MAX, 16, 10, true>(box4, base, n, V, vk, thr, thr_lo, mx, n, &ab);
                     if (ab) hit = k2s_retry_diag<WANT_MAX, 16, 10>(box4, base, n, V, tl, thr, thr_lo, mx);
                 }
             }

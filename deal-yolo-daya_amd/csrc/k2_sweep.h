@@ -156,7 +156,7 @@ __device__ __forceinline__ bool k2s_drain(const double *box4, int64_t base, cons
 // the box index: sort, sweep, exact tests.  Returns whether a pair reached thr; with WANT_MAX mxacc is every lane's running maximum.
 // budget > 0: give up (*aborted = true, nothing decided unless a hit was already found) once the loop has made more trips than that —
 // the sign of a row whose keys do not spread (every box in every other's window); the caller then tries the other sort axis.
-template <bool WANT_MAX, int E, int IB = 8>
+template <bool WANT_MAX, int E, int IB = 8, bool BUDGET = false>
 __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t base, int32_t n, const K2sView &V, uint32_t (&v)[E], double thr,
                                                  double thr_lo, double &mxacc, int32_t budget = 0, bool *aborted = nullptr) {
     constexpr int P = 64 * E;
@@ -188,7 +188,7 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
             n_it += 1;
 #endif
             if (!__any(inwin)) break;
-            if (budget > 0 && ++trips > budget) {   // wave-uniform
+            if (BUDGET && budget > 0 && ++trips > budget) {   // wave-uniform
                 gave_up = true;
                 break;
             }
@@ -223,7 +223,7 @@ __device__ __forceinline__ bool k2s_sweep_sorted(const double *box4, int64_t bas
         }
         if (!WANT_MAX && any_hit) break;
     }
-    if (gave_up && (WANT_MAX || !any_hit)) {   // the queued pairs are dropped: the second attempt meets them again
+    if (BUDGET && gave_up && (WANT_MAX || !any_hit)) {   // the queued pairs are dropped: the second attempt meets them again
         if (aborted) *aborted = true;
         qn = 0;
     }
@@ -277,7 +277,7 @@ __device__ __forceinline__ bool k2s_retry_diag(const double *box4, int64_t base,
 // A row whose boxes are in memory (the tile kernels): load, prepare, sweep.  false = not finite, nothing was decided.
 template <bool WANT_MAX, int E, int WROWS, int WCAP>
 __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
-                                          int32_t min_boxes, double thr, double thr_lo, int32_t budget, bool *aborted) {
+                                          int32_t min_boxes, double thr, double thr_lo) {
     static_assert(64 * E <= WCAP && WCAP <= 256, "box index lives in 8 key bits");
     static_assert(sizeof(S.cf) >= 16 * (size_t)WCAP, "keys + limits + y intervals alias the float4 tile");
     const int lane = threadIdx.x & 63;
@@ -311,11 +311,7 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
         return false;
     }
     double mxacc = 0.0;
-    const bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc, budget, aborted);
-    if (aborted && *aborted) {   // nothing decided: the caller hands the row on (or calls again without a budget)
-        wave_sync();
-        return true;
-    }
+    const bool any_hit = k2s_sweep_sorted<WANT_MAX, E>(box4, base, n, V, v, thr, thr_lo, mxacc);
     if (any_hit && n >= min_boxes && lane == 0) S.flag[row] = 1;
     if (WANT_MAX) {
         unsigned long long bits = (unsigned long long)__double_as_longlong(mxacc);   // IoU >= 0: the bit patterns order like the values
@@ -330,16 +326,15 @@ __device__ __forceinline__ bool k2s_row_e(const double *box4, int64_t base, int3
     return true;
 }
 
-// budget / aborted: see k2s_sweep_sorted (0 / nullptr: sweep to the end whatever it takes)
 template <bool WANT_MAX, int WROWS, int WCAP>
 __device__ __forceinline__ bool k2s_row(const double *box4, int64_t base, int32_t n, int row, WaveLdsF<WROWS, WCAP> &S,
-                                        int32_t min_boxes, double thr, double thr_lo, int32_t budget = 0, bool *aborted = nullptr) {
+                                        int32_t min_boxes, double thr, double thr_lo) {
     static_assert(WCAP == 128 || WCAP == 256, "one, two or four keys per lane");
     if constexpr (WCAP == 256) {
-        if (n > 128) return k2s_row_e<WANT_MAX, 4>(box4, base, n, row, S, min_boxes, thr, thr_lo, budget, aborted);
+        if (n > 128) return k2s_row_e<WANT_MAX, 4>(box4, base, n, row, S, min_boxes, thr, thr_lo);
     }
-    if (n > 64) return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo, budget, aborted);
-    return k2s_row_e<WANT_MAX, 1>(box4, base, n, row, S, min_boxes, thr, thr_lo, budget, aborted);
+    if (n > 64) return k2s_row_e<WANT_MAX, 2>(box4, base, n, row, S, min_boxes, thr, thr_lo);
+    return k2s_row_e<WANT_MAX, 1>(box4, base, n, row, S, min_boxes, thr, thr_lo);
 }
 
 }  // namespace dyd
