@@ -34,6 +34,14 @@ namespace dyd {
 #endif
 constexpr int KW_ROWS = KW_ROWS_VALUE;    // image rows per wave
 constexpr int KW_CHUNK = 256;  // points per LDS piece (4 KiB)
+// The sweep's trip budget (k2_sweep.h: give up on the x1 order after n trips, hand the row to the drain kernel's diagonal attempt) in the
+// DENSE kernel: measured, not the default — it costs every dense table 2 % (configs[4]: 8.27-8.58 ms against 8.12-8.57, alternating on one
+// box) to turn a single-column row's 640 trips into ~320.  The drain kernel, where registers are free, keeps it.  -DK12_BUDGET_ON to A/B.
+#ifdef K12_BUDGET_ON
+constexpr bool K12_BUDGET = true;
+#else
+constexpr bool K12_BUDGET = false;
+#endif
 
 struct alignas(16) WaveFuse {
     union {
@@ -185,14 +193,14 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                         const int32_t budget = bigq ? n : 0;
                         if (n <= 2 * kWave) {
                             uint32_t v2[2] = {vk[0], vk[1]};
-                            hit = k2s_sweep_sorted<false, 2, 8, true>(out_box4, (int64_t)base, n, V, v2, thr, thr_lo, unused_mx, budget, &ab);
+                            hit = k2s_sweep_sorted<false, 2, 8, K12_BUDGET>(out_box4, (int64_t)base, n, V, v2, thr, thr_lo, unused_mx, budget, &ab);
                             if (ab && !midq_push(bigq, r0 + ra, n)) {
                                 uint32_t w2[2] = {vk[0], vk[1]};
                                 hit = k2s_sweep_sorted<false, 2>(out_box4, (int64_t)base, n, V, w2, thr, thr_lo, unused_mx);
                             }
                         } else {
                             uint32_t v4[4] = {vk[0], vk[1], vk[2], vk[3]};
-                            hit = k2s_sweep_sorted<false, 4, 8, true>(out_box4, (int64_t)base, n, V, v4, thr, thr_lo, unused_mx, budget, &ab);
+                            hit = k2s_sweep_sorted<false, 4, 8, K12_BUDGET>(out_box4, (int64_t)base, n, V, v4, thr, thr_lo, unused_mx, budget, &ab);
                             if (ab && !midq_push(bigq, r0 + ra, n)) hit = k2s_sweep_sorted<false, 4>(out_box4, (int64_t)base, n, V, vk, thr, thr_lo, unused_mx);
                         }
                         if (hit && lane == 0) S.flag[ra] = 1;
@@ -295,7 +303,7 @@ __device__ __forceinline__ void k12_wave_rows(const double2 *__restrict__ xy, co
                         }
                         bool ab = false;
                         uint32_t w1[1] = {v1[0]};
-                        bool hit = k2s_sweep_sorted<false, 1, 8, true>(out_box4, (int64_t)base, n, V, v1, thr, thr_lo, unused_mx, bigq ? n : 0, &ab);
+                        bool hit = k2s_sweep_sorted<false, 1, 8, K12_BUDGET>(out_box4, (int64_t)base, n, V, v1, thr, thr_lo, unused_mx, bigq ? n : 0, &ab);
                         if (ab && !midq_push(bigq, r0 + ra, n)) hit = k2s_sweep_sorted<false, 1>(out_box4, (int64_t)base, n, V, w1, thr, thr_lo, unused_mx);
                         if (hit && lane == 0) S.flag[ra] = 1;
                         wave_sync();

@@ -259,8 +259,8 @@ def test_odd_thresholds_on_dense_rows(native, thr):
 
 @pytest.mark.parametrize("variant", [-1, 4, 6, 9, 10])
 def test_fused_rows_in_one_column(native, variant):
-    """rows whose boxes all share x1 (text lines, table cells): the fused kernels' sweeps give up on the x1 order and the row is swept along
-    the diagonal (in place, or by the drain kernel for the wave kernels) — same flags as the chain oracle"""
+    """rows whose boxes all share x1 (text lines, table cells): the worst case of the x1 order (every box in every other's window) and, in the
+    drain kernel, the rows its trip budget sends to the diagonal order — same flags as the chain oracle through every fused variant"""
     rng = np.random.default_rng(9)
     sizes = np.array([256, 200, 130, 100, 64, 50, 41, 300, 700, 20, 256, 256] * 4)
     box_off = _offsets(sizes)
