@@ -411,13 +411,16 @@ def main():
         # tools/collect_profiles.py), FETCH_SIZE doubled as the microarch guide prescribes for gfx950.  It is NOT measured in
         # this run: the value is read from the committed summary of those passes and only for the workload they ran.
         traffic, traffic_src = None, None
-        tf = os.path.join(REPO, "profiles", "k12_traffic.json")
+        tname = "r02_c5_traffic.json" if args.workload == "c5" else "k12_traffic.json"
+        tf = os.path.join(REPO, "profiles", tname)
         if os.path.exists(tf):
             with open(tf) as fh:
                 tj = json.load(fh)
-            if tj.get("rows_per_gpu") == rows and tj.get("workload") == args.workload:
+            same = (tj.get("rows_per_gpu") == rows and tj.get("workload") == args.workload) or \
+                   (args.workload == "c5" and tj.get("algorithmic_bytes_per_launch") == 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N)
+            if same:
                 traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = f"profiles/k12_traffic.json <- {tj.get('source', 'rocprofv3 --pmc passes of this command')} (not measured in this run)"
+                traffic_src = f"profiles/{tname} <- {tj.get('source', 'rocprofv3 --pmc passes of this command')} (not measured in this run)"
         alg_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N     # K1's bytes + K2's offsets and flags; the boxes reach K2 through LDS
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         line = {
