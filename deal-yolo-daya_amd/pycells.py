@@ -34,7 +34,8 @@ class CellViews:
         self.len = np.empty(n, np.int64)
         self.missing = np.empty(n, np.uint8)
         if n:
-            _dydpy.str_views(arr.ctypes.data, n, self.ptr.ctypes.data, self.len.ctypes.data, self.missing.ctypes.data)
+            from .native_json import host_threads
+            _dydpy.str_views(arr.ctypes.data, n, self.ptr.ctypes.data, self.len.ctypes.data, self.missing.ctypes.data, host_threads())
 
     def __len__(self):
         return len(self.cells)
