@@ -929,9 +929,15 @@ def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold
     import time as _t
     be = _backend(backend)
     t0 = _t.perf_counter()
-    na = df[ANNOTATION_COL].isna()
-    kept = df[~na].copy()                                          # == dropna(subset=[col]).copy() (:249)
-    excluded = df[na].copy()                                       # :250
+    from .. import pycells
+    col = df[ANNOTATION_COL]
+    if len(df) >= 65536 and col.dtype == object and pycells.all_str(col.to_numpy()):
+        # a column of str cells: nothing to drop (isna walks a million objects to say so); the same frames as the masks below give
+        kept, excluded = df.copy(), df[np.zeros(len(df), dtype=bool)].copy()
+    else:
+        na = col.isna()
+        kept = df[~na].copy()                                      # == dropna(subset=[col]).copy() (:249)
+        excluded = df[na].copy()                                   # :250
     totals = {"cells": len(kept), "boxes": 0, "points": 0, "host_boxes": 0, "host_rows": 0, "python_cells": 0,
               "fused_launches": 0, "fast_cells": 0}
     t1 = _t.perf_counter()

@@ -98,6 +98,53 @@ static PyObject *str_views(PyObject *self, PyObject *args) {
     return PyLong_FromSsize_t(n_str);
 }
 
+/* all_exact_str(objs, n, n_threads): is every element of the object array an exact str?  (header reads on worker threads, the caller keeps
+ * the GIL) — a column of str cells holds no missing value, which spares DataFrame.isna its per-object walk */
+typedef struct {
+    PyObject **objs;
+    int64_t lo, hi;
+    int all_str;
+} allstr_t;
+
+static void *allstr_worker(void *arg) {
+    allstr_t *w = (allstr_t *)arg;
+    int ok = 1;
+    for (int64_t i = w->lo; i < w->hi && ok; ++i) {
+        PyObject *o = w->objs[i];
+        ok = (o != NULL && Py_TYPE(o) == &PyUnicode_Type);
+    }
+    w->all_str = ok;
+    return NULL;
+}
+
+static PyObject *all_exact_str(PyObject *self, PyObject *args) {
+    unsigned long long a_objs;
+    Py_ssize_t n;
+    int n_threads = 1;
+    if (!PyArg_ParseTuple(args, "Kn|i", &a_objs, &n, &n_threads)) return NULL;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (n < 65536) n_threads = 1;
+    allstr_t w[64];
+    pthread_t th[64];
+    int started[64];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].objs = (PyObject **)(uintptr_t)a_objs;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+        w[t].all_str = 1;
+        started[t] = (t > 0) && pthread_create(&th[t], NULL, allstr_worker, &w[t]) == 0;
+    }
+    for (int t = 0; t < n_threads; ++t)
+        if (!started[t]) allstr_worker(&w[t]);
+    int ok = 1;
+    for (int t = 0; t < n_threads; ++t) {
+        if (started[t]) pthread_join(th[t], NULL);
+        ok &= w[t].all_str;
+    }
+    return PyBool_FromLong(ok);
+}
+
 typedef struct {
     const char *text;
     const int64_t *off;
@@ -241,6 +288,7 @@ static PyObject *gather_utf8(PyObject *self, PyObject *args) {
 }
 
 static PyMethodDef methods[] = {
+    {"all_exact_str", all_exact_str, METH_VARARGS, "is every element of an object array an exact str"},
     {"gather_utf8", gather_utf8, METH_VARARGS, "copy (pointer, length) views into one flat buffer at given offsets"},
     {"str_views", str_views, METH_VARARGS, "UTF-8 views of the str elements of an object array"},
     {"strs_from_utf8", strs_from_utf8, METH_VARARGS, "str objects from flat UTF-8 + offsets into an object array"},

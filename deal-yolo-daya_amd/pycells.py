@@ -41,6 +41,18 @@ class CellViews:
         return len(self.cells)
 
 
+def all_str(arr: np.ndarray) -> bool:
+    """every element of the object array is an exact str (then the column holds no missing value): a parallel walk of the object
+    headers instead of ``Series.isna``'s per-object one.  False when the extension is missing or the array is not an object array."""
+    if not available() or not isinstance(arr, np.ndarray) or arr.dtype != object or arr.ndim != 1:
+        return False
+    arr = np.ascontiguousarray(arr)
+    if not len(arr):
+        return True
+    from .native_json import host_threads
+    return bool(_dydpy.all_exact_str(arr.ctypes.data, len(arr), host_threads()))
+
+
 def strings(text: np.ndarray, off: np.ndarray, na=None, n_threads: int = 0) -> np.ndarray:
     """object array of str (None where na != 0) from flat UTF-8 ``text`` and int64 ``off`` [n+1]"""
     from . import native_json as _nj
