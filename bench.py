@@ -14,7 +14,9 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline       dominant kernel (the fused K1+K2 kernel) — algorithmic bytes / HIP-event time vs 8 TB/s HBM peak
   cpu_baseline   the CPU port of the reference path (oracle/steps.py) timed on this box's host cores (rank 0, N=1 only)
   host_inclusive SURVEY §8d region 2: DataFrame in -> frames out through the product's step function
-                 (replace_and_filter_frame: scan + H2D + fused launch + D2H + emit) and its ratio to cpu_baseline
+                 (replace_and_filter_frame: scan + H2D + fused launch + D2H + emit) and its ratio to cpu_baseline;
+                 .pipeline = configs[2] through the product API: the five step functions in sequence on that table, per step
+                 seconds and the ratio to the same step of the CPU port
   full_pipeline  configs[2]: K3 -> K4 -> K5 -> K1+K2 -> permutation + K6 on the same 10M resident rows, per stage
 and, with --workload c4, the sharded dedup of configs[3] with its all-gather timed on its own.
 """
@@ -72,12 +74,12 @@ def cpu_baseline(sizes):
     }
 
 
-def host_inclusive(rows, dev):
-    """DataFrame in -> (kept, excluded, high, other) frames out through the product's fused step function."""
+def host_table(rows, dev):
+    """the DataFrame of the host-inclusive legs: `rows` annotation cells drawn on the device and emitted natively, URL ids ~
+    U{0..0.9 rows} (about 40 % duplicates), and the reference frame of every id divisible by 10"""
     import pandas as pd
     import torch
-    from deal_yolo_daya_amd import _native, native_json, synth
-    from deal_yolo_daya_amd.core import processor as P
+    from deal_yolo_daya_amd import synth
 
     t0 = time.perf_counter()
     parts = []
@@ -85,12 +87,25 @@ def host_inclusive(rows, dev):
         d = synth.generate_device(min(500_000, rows - s), synth.SEED + 77 + ci, dev)
         t = synth.table_from_device(d)
         del d
-        parts.append(pd.DataFrame({"source": synth.urls(t), synth.ANN_COL: synth.json_cells(t)}))
+        parts.append(synth.json_cells(t))
         del t
-    df = pd.concat(parts, ignore_index=True)
+    cells = np.concatenate(parts)
     del parts
+    ids = np.random.default_rng(synth.SEED + 5).integers(0, int(0.9 * rows) + 1, rows)
+    src = np.empty(rows, object)
+    src[:] = [f"http://img.example/{k}.jpg" for k in ids.tolist()]
+    df = pd.DataFrame({"source": src, synth.ANN_COL: cells})
+    ref = pd.DataFrame({"source": synth.reference_urls(rows)})
     torch.cuda.empty_cache()
-    gen_s = time.perf_counter() - t0
+    return df, ref, time.perf_counter() - t0
+
+
+def host_inclusive(df, gen_s):
+    """DataFrame in -> (kept, excluded, high, other) frames out through the product's fused step function."""
+    from deal_yolo_daya_amd import _native, native_json, synth
+    from deal_yolo_daya_amd.core import processor as P
+
+    rows = len(df)
     best, stats_best, n_high = None, None, 0
     for _ in range(2):
         stats = {}
@@ -103,13 +118,77 @@ def host_inclusive(rows, dev):
     json_bytes = int(df[synth.ANN_COL].str.len().sum())
     return {
         "region": "SURVEY §8d (2): DataFrame in -> kept / excluded / high / other frames out, replace_and_filter_frame "
-                  "(UTF-8 views of the str cells, native scan, H2D, ONE fused K1+K2 launch, D2H, native emit, str objects)",
+                  "(UTF-8 views of the str cells, native scan, H2D, ONE fused K1+K2 launch, D2H, native emit, str objects); best of 2",
         "rows": rows, "seconds": best, "value": rows / best, "unit": "rows/s", "high_rows": n_high,
         "json_gb": round(json_bytes / 1e9, 2), "host_threads": native_json.host_threads(),
         "phases_s": {k[2:]: round(v, 3) for k, v in stats_best.items() if k.startswith("s_")},
         "fast_lane_cells": stats_best.get("fast_cells"), "python_cells": stats_best.get("python_cells"),
         "table_generation_s": round(gen_s, 1), "kernel_ms": round(_native.last_kernel_ms(), 3),
     }
+
+
+def host_pipeline(df, ref, cpu_rows):
+    """configs[2] through the product's own API: the five step functions in sequence on ONE table, each handing its frame to the
+    next as the processing page does (reference ui/pages/processing.py:545-630; the replace and IoU steps as the one fused pass),
+    wall-clock per step, ONE run (no best-of).  Beside every step: the same step of the CPU port (oracle/steps.py, 1 core) on the first
+    `cpu_rows` rows of the same table."""
+    from deal_yolo_daya_amd import synth
+    from deal_yolo_daya_amd.core import processor as P
+    from oracle import steps as osteps
+
+    rules = synth.rules()
+    steps = []
+
+    def run(name, rows_in, fn):
+        a = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - a
+        steps.append({"step": name, "rows_in": int(rows_in), "seconds": round(dt, 4), "rows_per_s": round(rows_in / dt, 1)})
+        return out
+
+    t0 = time.perf_counter()
+    dd = run("dedup_frame (K3 + K4)", len(df), lambda: P.dedup_frame(df))
+    ff = run("ref_filter_frame (K3 + K5)", len(dd), lambda: P.ref_filter_frame(dd, ref))
+    rstats, sstats = {}, {}
+    kept, excluded, high, other = run("replace_and_filter_frame (scan, fused K1+K2, emit)", len(ff),
+                                      lambda: P.replace_and_filter_frame(ff, MIN_BOXES, THR, stats=rstats))
+    res = run("split_frames (native expansion, K8 + K6, frames)", len(other), lambda: P.split_frames(other, rules, stats=sstats))
+    total = time.perf_counter() - t0
+    steps[-1]["phases_s"] = {k: round(v, 3) for k, v in sstats.items() if k.endswith("_s") and not isinstance(v, dict)}
+    steps[-1]["records"] = sstats.get("records")
+    steps[-1]["category_counts"] = res["category_counts"]
+    steps[-1]["unclassified"] = int(len(res["unclassified"]))
+    steps[2]["high_rows"] = int(len(high))
+    rows_out = {"dedup": len(dd), "ref_filter": len(ff), "kept": len(kept), "other": len(other)}
+    del dd, ff, kept, excluded, high, other, res
+
+    cpu = None
+    if cpu_rows > 0:
+        sub = df.iloc[:cpu_rows].reset_index(drop=True)
+        cpu = []
+
+        def crun(name, rows_in, fn):
+            a = time.perf_counter()
+            out = fn()
+            cpu.append({"step": name, "rows_in": int(rows_in), "seconds": round(time.perf_counter() - a, 3),
+                        "rows_per_s": round(rows_in / (time.perf_counter() - a), 1)})
+            return out
+
+        c1 = crun("dedup", len(sub), lambda: osteps.dedup_frame(sub))
+        c2 = crun("ref_filter", len(c1), lambda: osteps.ref_filter_frame(c1, ref))
+        a = time.perf_counter()
+        _, projected, _ = osteps.replace_frame(c2)
+        _, c_other = osteps.iou_filter_frame(projected, MIN_BOXES, THR)
+        dt = time.perf_counter() - a
+        cpu.append({"step": "replace + iou_filter", "rows_in": len(c2), "seconds": round(dt, 3), "rows_per_s": round(len(c2) / dt, 1)})
+        crun("split", len(c_other), lambda: osteps.split_frames(c_other, rules))
+        for st, c in zip(steps, cpu):
+            st["vs_cpu_port"] = round(st["rows_per_s"] / c["rows_per_s"], 1)
+    return {"config": "configs[2] through the product API: dedup_frame -> ref_filter_frame -> replace_and_filter_frame -> split_frames "
+                      "on one table, host-inclusive (DataFrame in, DataFrames out), one run",
+            "rows": len(df), "seconds": round(total, 3), "rows_per_s": round(len(df) / total, 1), "rows_out": rows_out,
+            "steps": steps, "cpu_port": cpu,
+            "cpu_port_sample": f"first {cpu_rows} rows of the same table, 1 core" if cpu else None}
 
 
 def full_pipeline(tab, dev, L, ck, sp):
@@ -290,6 +369,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100000, help="largest CPU-baseline sample (0 = skip); 10000 rows are timed as well")
     ap.add_argument("--host-rows", type=int, default=1_000_000, help="rows of the host-inclusive DataFrame run (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = also time configs[2]'s full pipeline per stage (c3, N=1)")
+    ap.add_argument("--pipeline-cpu-rows", type=int, default=20000, help="rows of the CPU port's run of the five steps beside host_inclusive.pipeline (0 = skip)")
     ap.add_argument("--exchange", type=int, default=1,
                     help="1 = at N > 1 also time configs[3]'s sharded dedup / reference filter with its all-gathers (after the K steps)")
     ap.add_argument("--fused-variant", type=int, default=-1, help="A/B only: force a kernel variant of the fused launch (dyd_set_option)")
@@ -460,10 +540,12 @@ def main():
                 sizes = sorted({min(10000, args.cpu_sample), args.cpu_sample})
                 line["cpu_baseline"] = cpu_baseline(sizes)
             if args.host_rows > 0:
-                hi = host_inclusive(args.host_rows, dev)
+                df, ref, gen_s = host_table(args.host_rows, dev)
+                hi = host_inclusive(df, gen_s)
                 if line["cpu_baseline"]:
                     hi["vs_cpu_baseline"] = hi["value"] / line["cpu_baseline"]["value"]
-                    line["kernel_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+                if args.pipeline:
+                    hi["pipeline"] = host_pipeline(df, ref, min(args.pipeline_cpu_rows, args.host_rows))
                 line["host_inclusive"] = hi
         print(json.dumps(line, ensure_ascii=False))
     if dist.is_initialized():

@@ -128,6 +128,16 @@ SIGNATURES = {
     "dyd_split_event_kind": (C.c_void_p, [C.c_void_p]),
     "dyd_split_strings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "dyd_split_free": (None, [C.c_void_p]),
+    "dyd_json_split_expand_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int,
+                                          C.POINTER(C.c_void_p)]),
+    "dyd_split_rec_views": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "dyd_split_event_code": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_undefined": (C.c_int64, [C.c_void_p]),
+    "dyd_split_label_first": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_label_count": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_fast_cells": (C.c_int64, [C.c_void_p]),
+    "dyd_split_all_ascii": (C.c_int, [C.c_void_p]),
+    "dyd_split_seconds": (None, [C.c_void_p, C.c_void_p]),
     "dyd_json_relabel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_int, C.POINTER(C.c_void_p)]),
     "dyd_relabel_status": (C.c_void_p, [C.c_void_p]),

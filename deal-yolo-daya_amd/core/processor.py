@@ -38,6 +38,7 @@ import pandas as pd
 from .. import flatten as _fl
 from .. import fastcsv as _fc
 from .. import native_json as _nj
+from .. import pycells as _pycells
 from ..backend import resolve as _backend
 from .utils import (_ensure_image_cached, _extract_boxes_with_labels, _parse_data_objects, _safe_image_stem,
                     _split_label_cell, _split_object_labels, safe_filename)
@@ -1100,122 +1101,280 @@ def _expand_cell_python(cell, label_to_category):
     return None, combo, rows, events, "；".join(sorted(reasons))
 
 
-def _expand_rows(cells, label_to_category: dict) -> dict:
-    """Expansion of all rows: native for the regular cells (csrc/host_json.cpp), ``_expand_cell_python`` for the
-    rest, merged back into row order."""
-    n = len(cells)
+class _Expansion:
+    """Every row of the split step expanded (:712-792): records (source row, label code, JSON text) in row order, the per-row
+    bookkeeping of split_counts and the unclassified entries in the reference's append order.  The record texts are str objects
+    only once somebody asks for them (``json_take``): at table scale they stay in the native handle until the frames are built,
+    and are then created directly in shuffled order."""
+
+    def json_take(self, idx=None) -> np.ndarray:
+        """object array of the records' JSON text, record idx[i] at place i (all records in row order without idx)"""
+        if self.json_objs is not None:
+            return self.json_objs if idx is None else _pycells.take(self.json_objs, idx)
+        if self.native is None or not self.n_records:
+            return np.empty(0, object)
+        return self.native.record_strings(idx)
+
+    def json_at_slots(self, slot: np.ndarray, arrow: bool = False):
+        """the records' JSON text with record e at place slot[e] (a permutation): an object array of str made in ONE row-ordered
+        walk over the native buffers, or (``arrow``) one gathered utf-8 buffer + offsets [n+1] for Arrow string columns"""
+        if arrow:
+            if self.json_objs is None and self.native is not None and self.n_records:
+                return self.native.record_text(None, slot)
+            objs = self.json_take()
+            raw = [t.encode("utf-8") for t in objs.tolist()]
+            lens = np.zeros(len(raw), np.int64)
+            lens[slot] = [len(r) for r in raw]
+            off = np.zeros(len(raw) + 1, np.int64)
+            np.cumsum(lens, out=off[1:])
+            text = np.zeros(max(int(off[-1]), 1), np.uint8)
+            for e, r in enumerate(raw):
+                text[off[slot[e]]:off[slot[e]] + len(r)] = np.frombuffer(r, np.uint8)
+            return text[:int(off[-1])], off
+        if self.json_objs is not None:
+            return _pycells.take(self.json_objs, None, slot=slot, checked=True)
+        if self.native is None or not self.n_records:
+            return np.empty(0, object)
+        return self.native.record_strings(None, slot)
+
+    def close(self):
+        if self.native is not None:
+            self.native.close()
+
+
+def _expand_table(n: int, cell_of, label_to_category: dict, cells=None, views=None) -> _Expansion:
+    """Expansion of all rows: native for the regular cells (csrc/host_json.cpp + host_split_fast.h), ``_expand_cell_python`` for
+    the rest, merged back into row order.  ``views`` = (ptr, len, missing) of the picked cells (the DataFrame's own str objects),
+    else ``cells`` is the list of picked cells; ``cell_of(i)`` returns row i's picked cell for the Python path."""
     labels = list(label_to_category)
-    combo = np.full(n, "", object)
-    reasons = np.full(n, "", object)
-    n_out = np.zeros(n, np.int64)
-    error = np.full(n, None, object)
-    row_src, row_label, row_json = [np.zeros(0, np.int64)], [np.empty(0, object)], [np.empty(0, object)]
-    ev_src, ev_kind, ev_label = [np.zeros(0, np.int64)], [np.zeros(0, np.uint8)], [np.empty(0, object)]
-    python_rows = range(n)
+    label_ix = {lab: i for i, lab in enumerate(labels)}
+    ex = None
     if n and _nj.enabled():
         try:
-            ex = _nj.split_expand(cells, labels)
+            ex = _nj.split_expand_views(*views, labels) if views is not None else _nj.split_expand(cells, labels)
         except UnicodeEncodeError:                             # a lone surrogate somewhere: CPython handles every cell
             ex = None
-        if ex is not None:
-            regular = ex.status != _nj.SP_IRREGULAR
-            combo[regular], reasons[regular], n_out[regular] = ex.combo[regular], ex.reasons[regular], ex.n_expanded[regular]
-            for code, text in _SPLIT_ERRORS.items():
-                error[ex.status == code] = text
-            lab_arr = np.asarray(labels, object) if labels else np.empty(0, object)
-            row_src.append(ex.row_cell); row_label.append(lab_arr[ex.row_label] if len(ex.row_label) else np.empty(0, object))
-            row_json.append(ex.row_json)
-            ev_src.append(ex.event_cell); ev_kind.append(ex.event_kind); ev_label.append(ex.event_label)
-            python_rows = np.flatnonzero(~regular).tolist()
-    for ri in python_rows:
-        err, cmb, rows, events, why = _expand_cell_python(cells[ri], label_to_category)
-        error[ri], combo[ri], reasons[ri], n_out[ri] = err, cmb, why, len(rows)
-        if rows:
-            row_src.append(np.full(len(rows), ri, np.int64))
-            row_label.append(np.asarray([r[0] for r in rows], object)); row_json.append(np.asarray([r[1] for r in rows], object))
-        if events:
-            ev_src.append(np.full(len(events), ri, np.int64))
-            ev_kind.append(np.asarray([e[0] for e in events], np.uint8)); ev_label.append(np.asarray([e[1] or "" for e in events], object))
-    src = np.concatenate(row_src)
-    order = np.argsort(src, kind="stable")
-    src, lab, txt = src[order], np.concatenate(row_label)[order], np.concatenate(row_json)[order]
+    out = _Expansion()
+    out.native, out.json_objs, out.labels = ex, None, labels
+    if ex is not None:
+        status = ex.status
+        combo, reasons, n_out = ex.combo, ex.reasons, ex.n_expanded.astype(np.int64)
+        has_reason = ex.reasons_nonempty.copy()
+        src, code = ex.row_cell, ex.row_label
+        e_src, e_kind, e_code, undef = ex.event_cell, ex.event_kind, ex.event_code, list(ex.undefined)
+        python_rows = np.flatnonzero(status == _nj.SP_IRREGULAR).tolist()
+    else:
+        status = np.zeros(n, np.uint8)
+        combo, reasons, n_out = np.full(n, "", object), np.full(n, "", object), np.zeros(n, np.int64)
+        has_reason = np.zeros(n, bool)
+        src, code = np.zeros(0, np.int64), np.zeros(0, np.int32)
+        e_src, e_kind, e_code, undef = np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.int32), []
+        python_rows = range(n)
+    error = np.empty(n, object)                                # None everywhere
+    for c, text in _SPLIT_ERRORS.items():
+        hit = status == c
+        if hit.any():
+            error[hit] = text
+    failed = (status >= 1) & (status <= 4)
+
+    if len(python_rows):
+        undef_ix = {lab: i for i, lab in enumerate(undef)}
+        p_src, p_code, p_json, pe_src, pe_kind, pe_code = [], [], [], [], [], []
+        for ri in python_rows:
+            err, cmb, rows, events, why = _expand_cell_python(cell_of(ri), label_to_category)
+            if err is not None:
+                error[ri], failed[ri] = err, True
+            combo[ri], reasons[ri], n_out[ri], has_reason[ri] = cmb, why, len(rows), bool(why)
+            for lab, text in rows:
+                p_src.append(ri); p_code.append(label_ix[lab]); p_json.append(text)
+            for kind, lab in events:
+                c = -1
+                if kind == _nj.EV_UNDEFINED:
+                    c = undef_ix.get(lab)
+                    if c is None:
+                        c = undef_ix[lab] = len(undef)
+                        undef.append(lab)
+                pe_src.append(ri); pe_kind.append(kind); pe_code.append(c)
+        if p_src:
+            texts = np.empty(len(p_json), object)
+            texts[:] = p_json
+            src = np.concatenate([src, np.asarray(p_src, np.int64)])
+            order = np.argsort(src, kind="stable")
+            src = src[order]
+            code = np.concatenate([code, np.asarray(p_code, np.int32)])[order]
+            out.json_objs = np.concatenate([ex.record_strings() if ex is not None and ex.n_records else np.empty(0, object), texts])[order]
+        if pe_src:
+            e_src = np.concatenate([e_src, np.asarray(pe_src, np.int64)])
+            order = np.argsort(e_src, kind="stable")
+            e_src = e_src[order]
+            e_kind = np.concatenate([e_kind, np.asarray(pe_kind, np.uint8)])[order]
+            e_code = np.concatenate([e_code, np.asarray(pe_code, np.int32)])[order]
+    if ex is not None and out.json_objs is None:
+        out.label_first, out.label_count = ex.label_stats(len(labels))
+    else:
+        out.label_count = np.bincount(code, minlength=len(labels)).astype(np.int64)
+        out.label_first = np.full(len(labels), -1, np.int64)
+        if len(code):
+            uniq, first = np.unique(code, return_index=True)
+            out.label_first[uniq] = first
+    out.n_records, out.src_row, out.label_code = len(src), src, code
+
     # unclassified entries in the reference's append order: per row its events, an error row contributes itself
-    e_src, e_kind, e_label = np.concatenate(ev_src), np.concatenate(ev_kind), np.concatenate(ev_label)
-    err_rows = np.flatnonzero(np.asarray([e is not None for e in error], bool)) if n else np.zeros(0, np.int64)
-    all_src = np.concatenate([e_src, err_rows])
-    all_kind = np.concatenate([e_kind, np.zeros(len(err_rows), np.uint8)])
-    all_label = np.concatenate([e_label, np.full(len(err_rows), "", object)])
-    eorder = np.argsort(all_src, kind="stable")
-    unc_row, unc_kind, unc_label = all_src[eorder], all_kind[eorder], all_label[eorder]
-    # reason text per entry, built per distinct value rather than per entry
-    unc_reason = np.full(len(unc_row), "标注框缺少name字段", object)                      # EV_NO_NAME (:747)
+    err_rows = np.flatnonzero(failed)
+    if len(err_rows):
+        all_src = np.concatenate([e_src, err_rows])
+        eorder = np.argsort(all_src, kind="stable")
+        unc_row = all_src[eorder]
+        unc_kind = np.concatenate([e_kind, np.zeros(len(err_rows), np.uint8)])[eorder]
+        unc_code = np.concatenate([e_code, np.full(len(err_rows), -1, np.int32)])[eorder]
+    else:
+        unc_row, unc_kind, unc_code = e_src, e_kind, e_code
+    # reason text per entry, built per distinct value rather than per entry: a table of the fixed texts and one text per
+    # distinct undefined label, entries whose text is their row's own (errors, joined reasons) patched in afterwards
     is_err, is_undef, is_none = unc_kind == 0, unc_kind == _nj.EV_UNDEFINED, unc_kind == _nj.EV_NOTHING_CLASSIFIED
+    table = np.empty(len(undef) + 2, object)
+    table[0] = "标注框缺少name字段"                                                          # EV_NO_NAME (:747)
+    table[1] = "标签无法匹配规则"                                                            # :779, a row without reasons
+    table[2:] = [f"标签{lab}未在规则中定义" for lab in undef]                                 # :755
+    tcode = np.where(is_undef, unc_code + 2, np.where(is_none, 1, 0)).astype(np.int32)
+    unc_reason = _pycells.take_small(table, tcode)
     if is_err.any():
         unc_reason[is_err] = error[unc_row[is_err]]
-    if is_undef.any():
-        uniq, inverse = np.unique(unc_label[is_undef].astype(str), return_inverse=True)
-        unc_reason[is_undef] = np.asarray([f"标签{lab}未在规则中定义" for lab in uniq], object)[inverse]   # :755
     if is_none.any():
-        why = reasons[unc_row[is_none]]
-        unc_reason[is_none] = np.where(why == "", "标签无法匹配规则", why)                  # :779
-    unc_label = np.where(is_undef, unc_label, None)
-    failed = np.asarray([e is not None for e in error], bool) if n else np.zeros(0, bool)
-    verdict = np.where(failed | (n_out == 0), "否", np.where(reasons != "", "部分可分类", "是")).astype(object)
-    reasons_of_row = reasons.copy()
-    for ri in np.flatnonzero(failed).tolist():
-        reasons_of_row[ri] = error[ri]                         # split_counts carries the error text there (:726)
-    return {"src_row": src, "label": lab, "json": txt, "combo_of_row": combo, "n_out": n_out, "verdict": verdict,
-            "reasons_of_row": reasons_of_row, "unc_row": unc_row, "unc_reason": unc_reason, "unc_label": unc_label}
+        rows_none = unc_row[is_none]
+        named = has_reason[rows_none]
+        if named.any():
+            where = np.flatnonzero(is_none)[named]
+            unc_reason[where] = reasons[rows_none[named]]
+    undef_arr = np.empty(len(undef) + 1, object)                                            # [-1] stays None
+    undef_arr[:len(undef)] = undef
+    out.unc_row, out.unc_reason, out.unc_has_label = unc_row, unc_reason, is_undef
+    out.unc_label = _pycells.take_small(undef_arr, np.where(is_undef, unc_code, len(undef)).astype(np.int32))   # None unless the entry names a label
+    out.verdict_code = np.where(failed | (n_out == 0), 0, np.where(has_reason, 1, 2)).astype(np.int8)
+    reasons_of_row = reasons
+    if failed.any():
+        reasons_of_row = reasons.copy()
+        reasons_of_row[failed] = error[failed]                 # split_counts carries the error text there (:726)
+    out.combo_of_row, out.n_out, out.reasons_of_row, out.failed = combo, n_out, reasons_of_row, failed
+    return out
+
+
+_VERDICTS = np.asarray(["否", "部分可分类", "是"], object)          # :782-784
+
+
+def _expand_rows(cells, label_to_category: dict) -> dict:
+    """The expansion over a plain list of picked cells, everything materialised (tests and small callers)."""
+    cells = list(cells)
+    ex = _expand_table(len(cells), cells.__getitem__, label_to_category, cells=cells)
+    lab_arr = np.empty(len(ex.labels), object)
+    lab_arr[:] = ex.labels
+    res = {"src_row": ex.src_row, "label": lab_arr[ex.label_code] if ex.n_records else np.empty(0, object),
+           "json": ex.json_take(), "combo_of_row": ex.combo_of_row, "n_out": ex.n_out, "verdict": _VERDICTS[ex.verdict_code],
+           "reasons_of_row": ex.reasons_of_row, "unc_row": ex.unc_row, "unc_reason": ex.unc_reason, "unc_label": ex.unc_label}
+    ex.close()
+    return res
+
+
+def _column_values(df: pd.DataFrame, name) -> np.ndarray:
+    col = df[name]
+    if isinstance(col, pd.DataFrame):                          # duplicated column name: the last one, as row[name] would be ambiguous
+        col = col.iloc[:, -1]
+    return col.to_numpy()
+
+
+def _take_column(df: pd.DataFrame, name, idx: np.ndarray, slot=None, idx_at_slot=None):
+    """out[slot[i]] = df[name].iloc[idx[i]] as an array for DataFrame(dict): object columns and plain numeric ones through the
+    threaded builders (idx is walked in order: pass it sorted), extension arrays through their own take (``idx_at_slot`` =
+    idx already permuted, made once by the caller)"""
+    col = df[name]
+    if isinstance(col, pd.DataFrame):
+        col = col.iloc[:, -1]
+    arr = col.array
+    if isinstance(arr, pd.arrays.NumpyExtensionArray) or isinstance(col.dtype, np.dtype):
+        return _pycells.take(col.to_numpy(), idx, checked=True, slot=slot)
+    return arr.take(idx if slot is None else idx_at_slot())
+
+
+def _picked_cells(df: pd.DataFrame, json_columns: list):
+    """Per row the first non-empty str among the JSON columns (:713-718).  -> (views or None, cells list or None, cell_of)"""
+    n = len(df)
+    present = [c for c in json_columns if c in df.columns]
+    arrays = [np.asarray(_column_values(df, c), dtype=object) for c in present]
+    if n and _pycells.available() and _nj.enabled():
+        ptr, length, missing = np.zeros(n, np.uint64), np.zeros(n, np.int64), np.ones(n, np.uint8)
+        which = np.full(n, -1, np.int8)
+        for k, arr in enumerate(arrays):
+            v = _pycells.CellViews(arr)
+            use = (missing != 0) & (v.missing == 0) & (v.len > 0)
+            if k == 0 and use.all():
+                ptr, length, missing, which = v.ptr, v.len, v.missing, np.zeros(n, np.int8)
+                break
+            ptr[use], length[use], missing[use], which[use] = v.ptr[use], v.len[use], 0, k
+        def cell_of(i):
+            return arrays[which[i]][i] if which[i] >= 0 else None
+        return (ptr, length, missing), None, cell_of, arrays          # arrays keep the str objects alive
+    cells = [None] * n
+    for arr in reversed(arrays):
+        for ri in range(n):
+            v = arr[ri]
+            if isinstance(v, str) and v:
+                cells[ri] = v
+    return None, cells, cells.__getitem__, arrays
 
 
 def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Optional[list] = None,
                  train_ratio: float = 0.8, val_ratio: float = 0.1, test_ratio: float = 0.1,
-                 random_seed: int = 42, backend=None) -> dict:
+                 random_seed: int = 42, backend=None, stats: Optional[dict] = None, text_dtype: str = "object") -> dict:
     """In-memory twin of the split step (no Excel I/O).
 
     Host: expand every row into one record per (object, label in the rules), in object-then-label
-    order (:741-775).  Device: K6 ranks each record inside its category, applies the MT19937
-    permutation of ``sample(frac=1, random_state=seed)`` and assigns train/val/test (:800-806).
+    order (:741-775) — natively, straight from the DataFrame's str objects.  Device: K8 + K6 rank each record inside its
+    category, apply the MT19937 permutation of ``sample(frac=1, random_state=seed)`` and assign train/val/test (:800-806).
+    Host: per category ONE gathered take per column in shuffled order (the record texts become str objects right there), and
+    the three sheets are slices of that frame, as in the reference (:804-806).
+
+    ``text_dtype="arrow"`` returns the JSON columns of the category frames as pandas' Arrow-backed ``string`` dtype over one
+    gathered buffer per category (same values, no str objects); the default keeps the reference's object columns of str.
 
     -> {"categories": {cat: (train, val, test)}, "unclassified": frame, "split_counts": frame,
         "category_counts": {cat: n}, "expanded": {src_row, category_id, position, split}}"""
+    import time as _time
+
+    if text_dtype not in ("object", "arrow"):
+        raise ValueError('text_dtype must be "object" or "arrow"')
     be = _backend(backend)
+    t0 = _time.perf_counter()
     if json_columns is None:                                        # :680-685
         json_columns = [c for c in (BBOX_COL, ANNOTATION_COL) if c in df.columns]
     present_json = [c for c in json_columns if c in df.columns]
-
     cols = list(df.columns)
-    col_pos = {c: i for i, c in enumerate(cols)}
-    values = df.to_numpy(dtype=object) if len(df) else np.empty((0, len(cols)), object)
-    source_pos = col_pos.get("source")
     n = len(df)
-    cells = [None] * n                    # the first non-empty str among the JSON columns (:713-718)
-    for c in reversed([c for c in json_columns if c in col_pos]):
-        column = values[:, col_pos[c]]
-        for ri in range(n):
-            v = column[ri]
-            if isinstance(v, str) and v:
-                cells[ri] = v
 
-    ex = _expand_rows(cells, label_to_category)
-    src_arr, new_json, new_label, new_combo = ex["src_row"], ex["json"], ex["label"], ex["combo_of_row"][ex["src_row"]] if n else ex["json"]
-    cat_names = np.asarray([label_to_category[lab] for lab in new_label], dtype=object) if len(new_label) else np.empty(0, object)
-    names_in_order = list(pd.unique(cat_names)) if len(cat_names) else []          # first-appearance order (:773 dict order)
-    categories = {name: i for i, name in enumerate(names_in_order)}
-    cat_id = np.asarray([categories[c] for c in cat_names], np.int32) if len(cat_names) else np.zeros(0, np.int32)
-    sources = values[:, source_pos] if source_pos is not None else np.full(n, None, object)
-    counts = pd.DataFrame({"source": sources, "原始标签组合": ex["combo_of_row"], "拆分条数": ex["n_out"],
-                           "是否可分类": ex["verdict"], "无法分类原因": ex["reasons_of_row"]}) if n else pd.DataFrame()
+    views, cells, cell_of, keep_alive = _picked_cells(df, json_columns)
+    ex = _expand_table(n, cell_of, label_to_category, cells=cells, views=views)
+    t1 = _time.perf_counter()
 
-    # ---- device stage: rank in category -> shuffled position -> split id --------------------
-    cat_arr = cat_id
+    # ---- categories in first-appearance order (:773, dict insertion order); category id per record -----------------
+    labels = ex.labels
+    cat_first = {}
+    for li in np.argsort(np.where(ex.label_first < 0, np.iinfo(np.int64).max, ex.label_first), kind="stable").tolist():
+        if ex.label_first[li] < 0:
+            break
+        cat_first.setdefault(label_to_category[labels[li]], len(cat_first))
+    categories = cat_first                                          # name -> id
     n_cat = len(categories)
-    sizes = np.bincount(cat_arr, minlength=n_cat).astype(np.int64) if n_cat else np.zeros(0, np.int64)
+    cat_of_label = np.asarray([categories.get(label_to_category[lab], -1) for lab in labels], np.int32) if labels else np.zeros(0, np.int32)
+    cat_arr = cat_of_label[ex.label_code] if ex.n_records else np.zeros(0, np.int32)
+    sizes = np.zeros(n_cat, np.int64)
+    if n_cat:
+        np.add.at(sizes, cat_of_label[cat_of_label >= 0], ex.label_count[cat_of_label >= 0])
     cat_off = np.zeros(n_cat + 1, np.int64)
     np.cumsum(sizes, out=cat_off[1:])
     cuts = [split_cut_sizes(int(s), train_ratio, val_ratio, test_ratio) for s in sizes]
     n_train = np.asarray([c[0] for c in cuts], np.int64)
     n_val = np.asarray([c[1] for c in cuts], np.int64)
+
+    # ---- device stage: rank in category -> shuffled position -> split id --------------------
     if not len(cat_arr):
         split, pos = np.zeros(0, np.uint8), np.zeros(0, np.int64)
     elif hasattr(be, "split_ids_seeded"):
@@ -1225,37 +1384,100 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
         perms = [be.mt19937_permutation(random_seed, int(s)) for s in sizes]
         split, pos = be.split_ids(cat_arr, np.concatenate(perms) if perms else np.zeros(0, np.int64), cat_off,
                                   n_train, n_val)
+    t2 = _time.perf_counter()
 
-    # ---- emit: per-category frames in shuffled order, cut by split id ------------------------
+    # ---- emit: ONE row-ordered walk per column scatters every record to its (category, shuffled position) slot; a category's
+    # frame is a slice of those columns and its three sheets are slices of the frame, cut where the device's split id changes ----
+    n_rec = ex.n_records
+    slot = _pycells.category_slots(cat_arr, pos, cat_off)
+    per_split = np.bincount(cat_arr.astype(np.int64) * 3 + split, minlength=3 * n_cat).reshape(n_cat, 3) if n_cat else np.zeros((0, 3), np.int64)
+    fine = {"slots_s": _time.perf_counter() - t2}
+    ta = _time.perf_counter()
+    arrow = text_dtype == "arrow"
+    text = ex.json_at_slots(slot, arrow=arrow) if n_rec else None
+    fine["text_s"] = _time.perf_counter() - ta
+    ta = _time.perf_counter()
+    lab_arr = np.empty(len(labels), object)
+    lab_arr[:] = labels
+    cat_arr_names = np.empty(n_cat, object)
+    cat_arr_names[:] = list(categories)
+    extra = ["分类标签", "分类类别", "原始标签组合"]
+    src_at_slot = []
+
+    def idx_at_slot():
+        if not src_at_slot:
+            src_at_slot.append(_pycells.take(ex.src_row, None, checked=True, slot=slot))
+        return src_at_slot[0]
+
+    columns = {}
+    if n_rec:
+        for c in cols:
+            if c not in extra and c not in present_json:
+                columns[c] = _take_column(df, c, ex.src_row, slot, idx_at_slot)
+        columns["分类标签"] = _pycells.take_small(lab_arr, ex.label_code, None, slot=slot, checked=True)
+        columns["分类类别"] = _pycells.take_small(cat_arr_names, cat_arr, None, slot=slot, checked=True)
+        columns["原始标签组合"] = _pycells.take(ex.combo_of_row, ex.src_row, checked=True, slot=slot)
+    fine["columns_s"] = _time.perf_counter() - ta
+    ta = _time.perf_counter()
     out_cats, cat_counts = {}, {}
     for category, cid in categories.items():
-        members = np.flatnonzero(cat_arr == cid)
-        order = np.empty(len(members), np.int64)
-        order[pos[members]] = members                        # shuffled position -> expanded record
-        frame = df.iloc[src_arr[order]].copy()
-        text = pd.Series(new_json[order], index=frame.index, dtype=object)
-        for c in present_json:
-            frame[c] = text
-        frame["分类标签"] = new_label[order]
-        frame["分类类别"] = category
-        frame["原始标签组合"] = new_combo[order]
-        frame = frame.reset_index(drop=True)
-        sp = split[order]
-        out_cats[category] = (frame[sp == 0], frame[sp == 1], frame[sp == 2])
-        cat_counts[category] = int(len(members))
+        lo, hi = int(cat_off[cid]), int(cat_off[cid + 1])
+        if arrow:
+            import pyarrow as pa
 
-    if len(ex["unc_row"]):                # rows in the reference's append order (:724, :748, :756, :780)
-        unc = df.iloc[ex["unc_row"]].copy()
-        unc["无法分类原因"] = ex["unc_reason"]
-        has_label = np.asarray([v is not None for v in ex["unc_label"]], bool)
+            tbuf, toff = text
+            piece = pd.arrays.ArrowStringArray(pa.chunked_array([pa.LargeStringArray.from_buffers(
+                hi - lo, pa.py_buffer(toff[lo:hi + 1]), pa.py_buffer(tbuf))]))
+        else:
+            piece = text[lo:hi]
+        data = {}
+        for c in cols:                                               # a column named like a new one is overwritten in place (:769-771)
+            data[c] = piece if (c in present_json and c not in extra) else columns[c][lo:hi]
+        for c in extra:
+            data[c] = columns[c][lo:hi]
+        frame = pd.DataFrame(data, copy=False)
+        a, b = int(per_split[cid, 0]), int(per_split[cid, 0] + per_split[cid, 1])
+        out_cats[category] = (frame.iloc[:a], frame.iloc[a:b], frame.iloc[b:])
+        cat_counts[category] = hi - lo
+    fine["frames_s"] = _time.perf_counter() - ta
+    t3 = _time.perf_counter()
+
+    if n:
+        sources = _column_values(df, "source") if "source" in df.columns else np.full(n, None, object)
+        counts = pd.DataFrame({"source": sources, "原始标签组合": ex.combo_of_row, "拆分条数": ex.n_out,
+                               "是否可分类": _VERDICTS[ex.verdict_code], "无法分类原因": ex.reasons_of_row}, copy=False)
+    else:
+        counts = pd.DataFrame()
+    if len(ex.unc_row):                   # rows in the reference's append order (:724, :748, :756, :780)
+        data = {c: _take_column(df, c, ex.unc_row) for c in cols if c != "无法分类原因" and c != "无法分类标签"}
+        tail = {"无法分类原因": ex.unc_reason}
+        has_label = ex.unc_has_label
         if has_label.any():
-            unc["无法分类标签"] = np.where(has_label, ex["unc_label"], np.nan)
+            tail["无法分类标签"] = np.where(has_label, ex.unc_label, np.nan)
+        elif "无法分类标签" in cols:
+            tail["无法分类标签"] = _take_column(df, "无法分类标签", ex.unc_row)
+        for c in cols:
+            if c in tail:
+                data[c] = tail.pop(c)
+        data.update(tail)
+        unc = pd.DataFrame(data, copy=False)
+        unc.index = df.index.take(ex.unc_row)                      # DataFrame(list of row copies) keeps the rows' labels
     else:
         unc = pd.DataFrame()
-    return {"categories": out_cats, "unclassified": unc, "split_counts": counts,
-            "category_counts": cat_counts,
-            "expanded": {"src_row": src_arr, "category_id": cat_arr, "position": pos, "split": split,
-                         "category_names": list(categories)}}
+    result = {"categories": out_cats, "unclassified": unc, "split_counts": counts,
+              "category_counts": cat_counts,
+              "expanded": {"src_row": ex.src_row, "category_id": cat_arr, "position": pos, "split": split,
+                           "category_names": list(categories)}}
+    ex.close()
+    del keep_alive
+    if stats is not None:
+        t4 = _time.perf_counter()
+        stats.update({"expand_s": t1 - t0, "device_s": t2 - t1, "category_frames_s": t3 - t2, "side_tables_s": t4 - t3,
+                      "records": int(n_rec), "fast_cells": int(ex.native.fast_cells) if ex.native is not None else 0})
+        stats["category_frames_fine"] = {k: round(v, 4) for k, v in fine.items()}
+        if ex.native is not None:
+            stats["native_s"] = dict(ex.native.seconds)
+    return result
 
 
 def split_dataset_by_rules(

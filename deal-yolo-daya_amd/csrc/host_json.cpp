@@ -25,6 +25,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -1834,30 +1836,44 @@ SplitStatus split_cell(Span cell, int64_t ci, const LabelMap &map, SplitPart &pt
     return SP_OK;
 }
 
+#include "host_split_fast.h"
+
 }  // namespace
 
 struct dyd_split {
     int64_t n_cells = 0;
     std::vector<uint8_t> status;
     std::vector<int32_t> n_expanded;
-    std::string combo, reasons, json, ev_text;
-    std::vector<int64_t> combo_off, reasons_off, json_off, ev_text_off, row_cell, ev_cell;
-    std::vector<int32_t> row_label;
-    std::vector<uint8_t> ev_kind;
+    std::vector<std::unique_ptr<SplitPartF>> parts;     // own the record texts (rec_ptr points into them)
+    // gathered by all threads at once
+    Raw<int64_t> row_cell, ev_cell, rec_len;
+    Raw<uint64_t> rec_ptr;
+    Raw<int32_t> row_label, ev_code;
+    Raw<uint8_t> ev_kind;
+    Raw<char> combo, reasons;
+    std::vector<int64_t> combo_off, reasons_off;
+    std::vector<std::string> undef_names;               // distinct undefined labels, first-appearance order over the parts
+    std::string undef_text;
+    std::vector<int64_t> undef_off;
+    std::vector<int64_t> label_first, label_count;      // per label of the rules: first record carrying it (-1), records
+    int64_t fast_cells = 0;
+    bool all_ascii = true;                              // every record text is pure ASCII
+    // on request (the older accessors): one flat copy of the record texts / one text per event
+    Raw<char> json_flat;
+    std::vector<int64_t> json_off;
+    std::string ev_text;
+    std::vector<int64_t> ev_text_off;
+    double t_parse = 0, t_gather = 0;
 };
 
-extern "C" {
+namespace {
 
-// labels: the keys of label_to_category, concatenated UTF-8 with offsets.  `missing[i]` != 0 marks a row without
-// a usable JSON cell (status SP_EMPTY).  The handle owns every output.
-int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
-                          const uint8_t *label_text, const int64_t *label_off, int32_t n_labels, int n_threads,
-                          dyd_split **out) {
-    if (!out || n_cells < 0 || n_labels < 0 || (n_cells > 0 && !cell_off) || (n_labels > 0 && (!label_text || !label_off)))
-        return DYD_ERR_INVALID;
+int split_expand_src(const CellSrc &src, const uint8_t *missing, int64_t n_cells, const uint8_t *label_text, const int64_t *label_off,
+                     int32_t n_labels, int n_threads, dyd_split **out) {
     dyd_split *h = new (std::nothrow) dyd_split();
     if (!h) return DYD_ERR_OOM;
     try {
+        const auto T0 = std::chrono::steady_clock::now();
         h->n_cells = n_cells;
         h->status.assign((size_t)n_cells, SP_OK);
         h->n_expanded.assign((size_t)n_cells, 0);
@@ -1865,46 +1881,90 @@ int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const ui
         map.reserve((size_t)n_labels * 2 + 1);
         for (int32_t i = 0; i < n_labels; ++i)
             map.emplace(std::string_view((const char *)label_text + label_off[i], (size_t)(label_off[i + 1] - label_off[i])), i);
-        std::vector<SplitPart> parts(64);
-        std::vector<int64_t> combo_len((size_t)n_cells, 0), reasons_len((size_t)n_cells, 0);
-        parallel_cells(n_cells, n_threads, [&](int t, int64_t lo, int64_t hi) {
-            SplitPart &pt = parts[(size_t)t];
-            pt.lo = lo; pt.hi = hi;
-            for (int64_t i = lo; i < hi; ++i) {
-                if (missing && missing[i]) { h->status[(size_t)i] = SP_EMPTY; continue; }
-                const size_t m_json = pt.json.size(), m_je = pt.json_end.size(), m_ev = pt.ev_cell.size(), m_et = pt.ev_text.size(),
-                             m_combo = pt.combo.size(), m_reasons = pt.reasons.size();
-                int32_t n_out = 0;
-                try {
-                    h->status[(size_t)i] = split_cell(Span{(const char *)text + cell_off[i], (const char *)text + cell_off[i + 1]}, i,
-                                                      map, pt, n_out);
-                    h->n_expanded[(size_t)i] = n_out;
-                } catch (Fail f) {
-                    pt.json.resize(m_json); pt.json_end.resize(m_je); pt.row_cell.resize(m_je); pt.row_label.resize(m_je);
-                    pt.ev_cell.resize(m_ev); pt.ev_kind.resize(m_ev); pt.ev_text_end.resize(m_ev); pt.ev_text.resize(m_et);
-                    pt.combo.resize(m_combo); pt.reasons.resize(m_reasons);
-                    h->status[(size_t)i] = (f.code == 1) ? SP_UNDECODABLE : SP_IRREGULAR;
-                }
-                combo_len[(size_t)i] = (int64_t)(pt.combo.size() - m_combo);
-                reasons_len[(size_t)i] = (int64_t)(pt.reasons.size() - m_reasons);
-            }
-        });
-        std::sort(parts.begin(), parts.end(), [](const SplitPart &a, const SplitPart &b) { return a.lo < b.lo; });
-        h->json_off.push_back(0);
-        h->ev_text_off.push_back(0);
-        for (auto &pt : parts) {
-            const int64_t jb = (int64_t)h->json.size(), eb = (int64_t)h->ev_text.size();
-            h->json += pt.json;
-            h->ev_text += pt.ev_text;
-            h->combo += pt.combo;
-            h->reasons += pt.reasons;
-            for (int64_t e : pt.json_end) h->json_off.push_back(jb + e);
-            for (int64_t e : pt.ev_text_end) h->ev_text_off.push_back(eb + e);
-            h->row_cell.insert(h->row_cell.end(), pt.row_cell.begin(), pt.row_cell.end());
-            h->row_label.insert(h->row_label.end(), pt.row_label.begin(), pt.row_label.end());
-            h->ev_cell.insert(h->ev_cell.end(), pt.ev_cell.begin(), pt.ev_cell.end());
-            h->ev_kind.insert(h->ev_kind.end(), pt.ev_kind.begin(), pt.ev_kind.end());
+        if (n_threads <= 0) n_threads = default_threads();
+        n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n_cells / 256));
+        n_threads = std::min(n_threads, 64);
+        for (int t = 0; t < n_threads; ++t) {
+            h->parts.emplace_back(new SplitPartF());
+            h->parts.back()->lo = n_cells * t / n_threads;
+            h->parts.back()->hi = n_cells * (t + 1) / n_threads;
         }
+        std::vector<int64_t> combo_len((size_t)n_cells, 0), reasons_len((size_t)n_cells, 0);
+        const bool use_fast = use_fast_lane();
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                SplitPartF &pt = *h->parts[(size_t)k];
+                SplitLane L;
+                pt.label_first.assign((size_t)n_labels, -1);
+                pt.label_count.assign((size_t)n_labels, 0);
+                const size_t bytes = src.bytes(pt.lo, pt.hi);
+                pt.json.need(bytes + bytes / 2 + 64);
+                pt.json_end.need(bytes / 128 + 64);
+                pt.row_cell.need(bytes / 128 + 64);
+                pt.row_label.need(bytes / 128 + 64);
+                for (int64_t i = pt.lo; i < pt.hi; ++i) {
+                    if (missing && missing[i]) { h->status[(size_t)i] = SP_EMPTY; continue; }
+                    const Span cell = src.get(i);
+                    if (cell.e == cell.b) { h->status[(size_t)i] = SP_EMPTY; continue; }     // "" is not a usable cell (:716)
+                    uint8_t st = SP_OK;
+                    int32_t n_out = 0;
+                    const size_t m_json = pt.json.n, m_rec = pt.json_end.n, m_ev = pt.ev_cell.n, m_combo = pt.combo.n, m_reasons = pt.reasons.n;
+                    if (use_fast && split_cell_fast(cell, i, map, L, pt, st, n_out, combo_len[(size_t)i], reasons_len[(size_t)i])) {
+                        ++pt.fast_cells;
+                    } else {
+                        // a bail may have left nothing behind: the lane writes to pt only after its parse succeeded
+                        try {
+                            split_cell_slow(cell, i, map, L, pt, st, n_out, combo_len[(size_t)i], reasons_len[(size_t)i]);
+                        } catch (Fail f) {
+                            pt.json.n = m_json; pt.json_end.n = m_rec; pt.row_cell.n = m_rec; pt.row_label.n = m_rec;
+                            pt.ev_cell.n = m_ev; pt.ev_kind.n = m_ev; pt.ev_code.n = m_ev; pt.combo.n = m_combo; pt.reasons.n = m_reasons;
+                            st = (f.code == 1) ? SP_UNDECODABLE : SP_IRREGULAR;
+                            n_out = 0;
+                            combo_len[(size_t)i] = reasons_len[(size_t)i] = 0;
+                        }
+                    }
+                    h->status[(size_t)i] = st;
+                    h->n_expanded[(size_t)i] = n_out;
+                }
+                pt.ascii = all_ascii(pt.json.p, pt.json.p + pt.json.n);
+            }))
+            throw std::bad_alloc();
+        const auto T1 = std::chrono::steady_clock::now();
+        // ---- gather: bases, the table of undefined labels, then every thread copies its part's fixed-width arrays ------------
+        size_t n_rec = 0, n_ev = 0;
+        std::map<std::string, int32_t, std::less<>> undef_ix;
+        std::vector<std::vector<int32_t>> remap(h->parts.size());
+        h->label_first.assign((size_t)n_labels, -1);
+        h->label_count.assign((size_t)n_labels, 0);
+        for (size_t k = 0; k < h->parts.size(); ++k) {
+            SplitPartF &pt = *h->parts[k];
+            pt.rec_base = n_rec; pt.ev_base = n_ev;
+            n_rec += pt.json_end.n; n_ev += pt.ev_cell.n;
+            h->fast_cells += pt.fast_cells;
+            h->all_ascii = h->all_ascii && pt.ascii;
+            remap[k].resize(pt.undef_names.size());
+            for (size_t u = 0; u < pt.undef_names.size(); ++u) {
+                auto it = undef_ix.find(pt.undef_names[u]);
+                if (it == undef_ix.end()) {
+                    it = undef_ix.emplace(pt.undef_names[u], (int32_t)h->undef_names.size()).first;
+                    h->undef_names.push_back(pt.undef_names[u]);
+                }
+                remap[k][u] = it->second;
+            }
+            for (int32_t l = 0; l < n_labels; ++l) {
+                if (pt.label_first[(size_t)l] >= 0 && h->label_first[(size_t)l] < 0)
+                    h->label_first[(size_t)l] = (int64_t)pt.rec_base + pt.label_first[(size_t)l];
+                h->label_count[(size_t)l] += pt.label_count[(size_t)l];
+            }
+        }
+        h->undef_off.push_back(0);
+        for (const std::string &u : h->undef_names) { h->undef_text += u; h->undef_off.push_back((int64_t)h->undef_text.size()); }
+        h->row_cell.need(n_rec + 1); h->row_cell.n = n_rec;
+        h->row_label.need(n_rec + 1); h->row_label.n = n_rec;
+        h->rec_ptr.need(n_rec + 1); h->rec_ptr.n = n_rec;
+        h->rec_len.need(n_rec + 1); h->rec_len.n = n_rec;
+        h->ev_cell.need(n_ev + 1); h->ev_cell.n = n_ev;
+        h->ev_kind.need(n_ev + 1); h->ev_kind.n = n_ev;
+        h->ev_code.need(n_ev + 1); h->ev_code.n = n_ev;
         h->combo_off.resize((size_t)n_cells + 1);
         h->reasons_off.resize((size_t)n_cells + 1);
         h->combo_off[0] = h->reasons_off[0] = 0;
@@ -1912,6 +1972,38 @@ int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const ui
             h->combo_off[(size_t)i + 1] = h->combo_off[(size_t)i] + combo_len[(size_t)i];
             h->reasons_off[(size_t)i + 1] = h->reasons_off[(size_t)i] + reasons_len[(size_t)i];
         }
+        h->combo.need((size_t)h->combo_off[(size_t)n_cells] + 1); h->combo.n = (size_t)h->combo_off[(size_t)n_cells];
+        h->reasons.need((size_t)h->reasons_off[(size_t)n_cells] + 1); h->reasons.n = (size_t)h->reasons_off[(size_t)n_cells];
+        if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                SplitPartF &pt = *h->parts[(size_t)k];
+                const size_t nr = pt.json_end.n, ne = pt.ev_cell.n;
+                if (nr) {
+                    memcpy(h->row_cell.p + pt.rec_base, pt.row_cell.p, nr * sizeof(int64_t));
+                    memcpy(h->row_label.p + pt.rec_base, pt.row_label.p, nr * sizeof(int32_t));
+                    int64_t prev = 0;
+                    for (size_t r = 0; r < nr; ++r) {
+                        h->rec_ptr.p[pt.rec_base + r] = (uint64_t)(uintptr_t)(pt.json.p + prev);
+                        h->rec_len.p[pt.rec_base + r] = pt.json_end.p[r] - prev;
+                        prev = pt.json_end.p[r];
+                    }
+                }
+                if (ne) {
+                    memcpy(h->ev_cell.p + pt.ev_base, pt.ev_cell.p, ne * sizeof(int64_t));
+                    memcpy(h->ev_kind.p + pt.ev_base, pt.ev_kind.p, ne);
+                    for (size_t e = 0; e < ne; ++e) {
+                        const int32_t c = pt.ev_code.p[e];
+                        h->ev_code.p[pt.ev_base + e] = c < 0 ? -1 : remap[(size_t)k][(size_t)c];
+                    }
+                }
+                if (pt.combo.n) memcpy(h->combo.p + h->combo_off[(size_t)pt.lo], pt.combo.p, pt.combo.n);
+                if (pt.reasons.n) memcpy(h->reasons.p + h->reasons_off[(size_t)pt.lo], pt.reasons.p, pt.reasons.n);
+                pt.row_cell.clear_free(); pt.row_label.clear_free(); pt.ev_cell.clear_free(); pt.ev_kind.clear_free();
+                pt.ev_code.clear_free(); pt.combo.clear_free(); pt.reasons.clear_free();
+            }))
+            throw std::bad_alloc();
+        const auto T2 = std::chrono::steady_clock::now();
+        h->t_parse = std::chrono::duration<double>(T1 - T0).count();
+        h->t_gather = std::chrono::duration<double>(T2 - T1).count();
     } catch (const std::bad_alloc &) {
         delete h;
         return DYD_ERR_OOM;
@@ -1920,24 +2012,102 @@ int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const ui
     return DYD_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+// labels: the keys of label_to_category, concatenated UTF-8 with offsets.  `missing[i]` != 0 marks a row without
+// a usable JSON cell (status SP_EMPTY; so does an empty cell).  The handle owns every output.
+int dyd_json_split_expand(const uint8_t *text, const int64_t *cell_off, const uint8_t *missing, int64_t n_cells,
+                          const uint8_t *label_text, const int64_t *label_off, int32_t n_labels, int n_threads,
+                          dyd_split **out) {
+    if (!out || n_cells < 0 || n_labels < 0 || (n_cells > 0 && !cell_off) || (n_labels > 0 && (!label_text || !label_off)))
+        return DYD_ERR_INVALID;
+    CellSrc src;
+    src.text = text; src.off = cell_off;
+    return split_expand_src(src, missing, n_cells, label_text, label_off, n_labels, n_threads, out);
+}
+
+// the same over one (pointer, length) view per cell (the str objects of a DataFrame column: nothing is copied); the views
+// must stay valid for the call only — the handle keeps no reference to the cells
+int dyd_json_split_expand_v(const uint8_t *const *cell_ptr, const int64_t *cell_len, const uint8_t *missing, int64_t n_cells,
+                            const uint8_t *label_text, const int64_t *label_off, int32_t n_labels, int n_threads,
+                            dyd_split **out) {
+    if (!out || n_cells < 0 || n_labels < 0 || (n_cells > 0 && (!cell_ptr || !cell_len)) || (n_labels > 0 && (!label_text || !label_off)))
+        return DYD_ERR_INVALID;
+    CellSrc src;
+    src.ptr = cell_ptr; src.len = cell_len;
+    return split_expand_src(src, missing, n_cells, label_text, label_off, n_labels, n_threads, out);
+}
+
 const uint8_t *dyd_split_status(const dyd_split *h) { return h->status.data(); }
 const int32_t *dyd_split_n_expanded(const dyd_split *h) { return h->n_expanded.data(); }
-int64_t dyd_split_rows(const dyd_split *h) { return (int64_t)h->row_cell.size(); }
-const int64_t *dyd_split_row_cell(const dyd_split *h) { return h->row_cell.data(); }
-const int32_t *dyd_split_row_label(const dyd_split *h) { return h->row_label.data(); }
-int64_t dyd_split_events(const dyd_split *h) { return (int64_t)h->ev_cell.size(); }
-const int64_t *dyd_split_event_cell(const dyd_split *h) { return h->ev_cell.data(); }
-const uint8_t *dyd_split_event_kind(const dyd_split *h) { return h->ev_kind.data(); }
-// which: 0 record JSON [rows], 1 label combination per cell [n_cells], 2 joined reasons per cell [n_cells],
-// 3 label of each event [events]
-int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const int64_t **off) {
+int64_t dyd_split_rows(const dyd_split *h) { return (int64_t)h->row_cell.n; }
+const int64_t *dyd_split_row_cell(const dyd_split *h) { return h->row_cell.p; }
+const int32_t *dyd_split_row_label(const dyd_split *h) { return h->row_label.p; }
+int64_t dyd_split_events(const dyd_split *h) { return (int64_t)h->ev_cell.n; }
+const int64_t *dyd_split_event_cell(const dyd_split *h) { return h->ev_cell.p; }
+const uint8_t *dyd_split_event_kind(const dyd_split *h) { return h->ev_kind.p; }
+const int32_t *dyd_split_event_code(const dyd_split *h) { return h->ev_code.p; }
+int64_t dyd_split_undefined(const dyd_split *h) { return (int64_t)h->undef_names.size(); }
+const int64_t *dyd_split_label_first(const dyd_split *h) { return h->label_first.data(); }
+const int64_t *dyd_split_label_count(const dyd_split *h) { return h->label_count.data(); }
+int64_t dyd_split_fast_cells(const dyd_split *h) { return h->fast_cells; }
+int dyd_split_all_ascii(const dyd_split *h) { return h->all_ascii ? 1 : 0; }
+void dyd_split_seconds(const dyd_split *h, double *parse_gather2) {
+    if (h && parse_gather2) { parse_gather2[0] = h->t_parse; parse_gather2[1] = h->t_gather; }
+}
+// one (address, length) view per record, in row order; valid until dyd_split_free
+int dyd_split_rec_views(const dyd_split *h, const uint64_t **ptr, const int64_t **len) {
+    if (!h || !ptr || !len) return DYD_ERR_INVALID;
+    *ptr = h->rec_ptr.p;
+    *len = h->rec_len.p;
+    return DYD_OK;
+}
+// which: 0 record JSON [rows] (a flat copy made on the first request), 1 label combination per cell [n_cells], 2 joined
+// reasons per cell [n_cells], 3 label of each event [events] (made on the first request), 4 the distinct undefined labels
+// [dyd_split_undefined] that dyd_split_event_code indexes
+int dyd_split_strings(dyd_split *h, int which, const uint8_t **data, const int64_t **off) {
     if (!h || !data || !off) return DYD_ERR_INVALID;
-    switch (which) {
-        case 0: *data = (const uint8_t *)h->json.data(); *off = h->json_off.data(); return DYD_OK;
-        case 1: *data = (const uint8_t *)h->combo.data(); *off = h->combo_off.data(); return DYD_OK;
-        case 2: *data = (const uint8_t *)h->reasons.data(); *off = h->reasons_off.data(); return DYD_OK;
-        case 3: *data = (const uint8_t *)h->ev_text.data(); *off = h->ev_text_off.data(); return DYD_OK;
-        default: return DYD_ERR_INVALID;
+    try {
+        switch (which) {
+            case 0: {
+                if (h->json_off.empty()) {
+                    const size_t n_rec = h->row_cell.n;
+                    h->json_off.resize(n_rec + 1);
+                    h->json_off[0] = 0;
+                    for (size_t r = 0; r < n_rec; ++r) h->json_off[r + 1] = h->json_off[r] + h->rec_len.p[r];
+                    h->json_flat.need((size_t)h->json_off[n_rec] + 1);
+                    h->json_flat.n = (size_t)h->json_off[n_rec];
+                    if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
+                            const SplitPartF &pt = *h->parts[(size_t)k];
+                            if (pt.json.n) memcpy(h->json_flat.p + h->json_off[pt.rec_base], pt.json.p, pt.json.n);
+                        }))
+                        return DYD_ERR_OOM;
+                }
+                *data = (const uint8_t *)h->json_flat.p; *off = h->json_off.data();
+                return DYD_OK;
+            }
+            case 1: *data = (const uint8_t *)h->combo.p; *off = h->combo_off.data(); return DYD_OK;
+            case 2: *data = (const uint8_t *)h->reasons.p; *off = h->reasons_off.data(); return DYD_OK;
+            case 3: {
+                if (h->ev_text_off.empty()) {
+                    h->ev_text_off.reserve(h->ev_cell.n + 1);
+                    h->ev_text_off.push_back(0);
+                    for (size_t e = 0; e < h->ev_cell.n; ++e) {
+                        const int32_t c = h->ev_code.p[e];
+                        if (c >= 0) h->ev_text += h->undef_names[(size_t)c];
+                        h->ev_text_off.push_back((int64_t)h->ev_text.size());
+                    }
+                }
+                *data = (const uint8_t *)h->ev_text.data(); *off = h->ev_text_off.data();
+                return DYD_OK;
+            }
+            case 4: *data = (const uint8_t *)h->undef_text.data(); *off = h->undef_off.data(); return DYD_OK;
+            default: return DYD_ERR_INVALID;
+        }
+    } catch (const std::bad_alloc &) {
+        return DYD_ERR_OOM;
     }
 }
 void dyd_split_free(dyd_split *h) { delete h; }

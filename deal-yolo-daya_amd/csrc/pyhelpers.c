@@ -3,7 +3,7 @@
  *
  * The annotation column of a DataFrame is an array of str objects of ~4 KB each.  Joining and encoding them in
  * Python (native_json.cells_to_buffers) costs more than scanning them, and a million 2 KB result strings created
- * one by one cost more than emitting them.  Two functions, both taking raw addresses (numpy `.ctypes.data`):
+ * one by one cost more than emitting them.  The functions take raw addresses (numpy `.ctypes.data`); the two oldest:
  *
  *   str_views(objs, n, ptr_out, len_out, missing_out[, n_threads])
  *       per element: a str -> the address and length of its UTF-8 form (the object's own buffer for ASCII text, its
@@ -11,11 +11,12 @@
  *       `not isinstance(json_str, str)`).  The views live as long as the str objects do.
  *   strs_from_utf8(text, off, n, na, objs_out, n_threads)
  *       per element with na == 0: a new str of text[off[i]:off[i+1]] stored into the object array (which must hold
- *       None everywhere).  ASCII cells are allocated with the GIL held and filled by worker threads without it.
+ *       None everywhere).  See "The str builder" below for who allocates.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -145,103 +146,6 @@ static PyObject *all_exact_str(PyObject *self, PyObject *args) {
     return PyBool_FromLong(ok);
 }
 
-typedef struct {
-    const char *text;
-    const int64_t *off;
-    const uint8_t *na;
-    PyObject **objs;
-    uint8_t *ascii; /* per cell: 1 = pure ASCII */
-    int64_t lo, hi;
-    int phase;
-} work_t;
-
-static void *worker(void *arg) {
-    work_t *w = (work_t *)arg;
-    if (w->phase == 0) { /* classify */
-        for (int64_t i = w->lo; i < w->hi; ++i) {
-            if (w->na && w->na[i]) { w->ascii[i] = 0; continue; }
-            const unsigned char *s = (const unsigned char *)w->text + w->off[i];
-            const int64_t k = w->off[i + 1] - w->off[i];
-            uint64_t acc = 0;
-            int64_t j = 0;
-            for (; j + 8 <= k; j += 8) {
-                uint64_t v;
-                memcpy(&v, s + j, 8);
-                acc |= v;
-            }
-            for (; j < k; ++j) acc |= s[j];
-            w->ascii[i] = (acc & 0x8080808080808080ull) ? 0 : 1;
-        }
-    } else { /* fill the ASCII objects */
-        for (int64_t i = w->lo; i < w->hi; ++i) {
-            if (!w->ascii[i]) continue;
-            memcpy(PyUnicode_1BYTE_DATA(w->objs[i]), w->text + w->off[i], (size_t)(w->off[i + 1] - w->off[i]));
-        }
-    }
-    return NULL;
-}
-
-static void run_phase(work_t *proto, int64_t n, int n_threads, int phase) {
-    if (n_threads < 1) n_threads = 1;
-    if (n_threads > 64) n_threads = 64;
-    if (n < 4096) n_threads = 1;
-    pthread_t th[64];
-    work_t w[64];
-    int started[64];
-    for (int t = 0; t < n_threads; ++t) {
-        w[t] = *proto;
-        w[t].lo = n * t / n_threads;
-        w[t].hi = n * (t + 1) / n_threads;
-        w[t].phase = phase;
-        started[t] = (t > 0) && pthread_create(&th[t], NULL, worker, &w[t]) == 0;
-    }
-    for (int t = 0; t < n_threads; ++t)
-        if (!started[t]) worker(&w[t]);
-    for (int t = 0; t < n_threads; ++t)
-        if (started[t]) pthread_join(th[t], NULL);
-}
-
-static PyObject *strs_from_utf8(PyObject *self, PyObject *args) {
-    unsigned long long a_text, a_off, a_na, a_objs;
-    Py_ssize_t n;
-    int n_threads;
-    if (!PyArg_ParseTuple(args, "KKnKKi", &a_text, &a_off, &n, &a_na, &a_objs, &n_threads)) return NULL;
-    work_t w;
-    memset(&w, 0, sizeof(w));
-    w.text = (const char *)(uintptr_t)a_text;
-    w.off = (const int64_t *)(uintptr_t)a_off;
-    w.na = (const uint8_t *)(uintptr_t)a_na;
-    w.objs = (PyObject **)(uintptr_t)a_objs;
-    if (n == 0) Py_RETURN_NONE;
-    w.ascii = (uint8_t *)PyMem_RawMalloc((size_t)n);
-    if (!w.ascii) return PyErr_NoMemory();
-    Py_BEGIN_ALLOW_THREADS
-    run_phase(&w, (int64_t)n, n_threads, 0);
-    Py_END_ALLOW_THREADS
-    for (Py_ssize_t i = 0; i < n; ++i) {
-        if (w.na && w.na[i]) continue;
-        const int64_t k = w.off[i + 1] - w.off[i];
-        PyObject *s = w.ascii[i] ? PyUnicode_New((Py_ssize_t)k, 127)
-                                 : PyUnicode_DecodeUTF8(w.text + w.off[i], (Py_ssize_t)k, "strict");
-        if (!s) {
-            /* objects created so far stay in the array (owned by it); the ASCII ones among them are still unfilled, so
-             * fill them before reporting */
-            for (Py_ssize_t j = i; j < n; ++j) w.ascii[j] = 0;
-            run_phase(&w, (int64_t)n, 1, 1);
-            PyMem_RawFree(w.ascii);
-            return NULL;
-        }
-        PyObject *old = w.objs[i];
-        w.objs[i] = s;
-        Py_XDECREF(old);
-    }
-    Py_BEGIN_ALLOW_THREADS
-    run_phase(&w, (int64_t)n, n_threads, 1);
-    Py_END_ALLOW_THREADS
-    PyMem_RawFree(w.ascii);
-    Py_RETURN_NONE;
-}
-
 /* gather_utf8(ptr, len, off, n, out, n_threads): out[off[i] .. off[i] + len[i]) = the bytes at ptr[i] — the flat buffer K3 hashes,
  * copied by worker threads without the GIL (the views come from str_views; off is the caller's prefix sum of len) */
 typedef struct {
@@ -287,11 +191,545 @@ static PyObject *gather_utf8(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+/* =====================================================================================================================
+ * Column builders of the split step (core/processor.py split_frames): 15 M records, each wanting a str of its JSON text, its
+ * source row's cells, its label ... at the place the shuffle gave it.  All of them have the form
+ *
+ *     out[slot ? slot[i] : i] = f(idx ? idx[i] : i)           i = 0 .. n-1, on worker threads over ranges of i
+ *
+ * so the caller can walk the records in ROW order (idx absent or non-decreasing: sequential reads, the same source object
+ * many times in a row) and scatter eight bytes to the shuffled place, instead of gathering from random places.
+ * ===================================================================================================================== */
+#include <dlfcn.h>
+#include <stdlib.h>
+
+#define MAXT 64
+typedef void *(*worker_fn)(void *);
+
+static int clamp_threads(int n_threads, int64_t n, int64_t small) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > MAXT) n_threads = MAXT;
+    if (n < small) n_threads = 1;
+    return n_threads;
+}
+
+/* runs fn over `count` argument blocks of `stride` bytes: block 0 on this thread, the others on their own */
+static void run_workers(worker_fn fn, void *blocks, size_t stride, int count) {
+    pthread_t th[MAXT];
+    int started[MAXT];
+    for (int t = 1; t < count; ++t) started[t] = pthread_create(&th[t], NULL, fn, (char *)blocks + stride * (size_t)t) == 0;
+    fn(blocks);
+    for (int t = 1; t < count; ++t) {
+        if (started[t]) pthread_join(th[t], NULL);
+        else fn((char *)blocks + stride * (size_t)t);
+    }
+}
+
+/* ---- str objects allocated by worker threads ------------------------------------------------------------------------
+ * PyUnicode_New needs the GIL, so creating N str objects is one thread's work however many cores fill them: ~60 ns each, 0.9 s
+ * for the 14 M records of a 1 M-row table — the largest single item of the split step.  CPython's object allocator hands every
+ * request above 512 bytes to the raw allocator (malloc) and its free() sends every block that does not lie in one of its own
+ * arenas back there (Objects/obmalloc.c: pymalloc_free -> address_in_range fails -> PyMem_RawFree): a block from
+ * PyMem_RawMalloc IS a valid home for an object of any size.  malloc is thread-safe and needs no GIL, so the workers allocate,
+ * initialise (the compact-ASCII header PyUnicode_New writes) and fill their share of the strings themselves.
+ * Used only when the interpreter runs its stock allocators ("pymalloc" or "malloc": no debug hooks — they prefix every block —
+ * and no tracemalloc / custom hooks, whose name is NULL), on a release build of CPython 3.8 .. 3.12, and not when
+ * DYD_STR_ALLOC=python; otherwise the strings are allocated by the calling thread with PyUnicode_New as before. */
+static int raw_alloc_allowed(void) {
+#if defined(Py_TRACE_REFS) || defined(Py_REF_DEBUG) || defined(Py_GIL_DISABLED) || PY_VERSION_HEX < 0x03080000 || PY_VERSION_HEX >= 0x030D0000
+    return 0;
+#else
+    const char *e = getenv("DYD_STR_ALLOC");
+    if (e && strcmp(e, "python") == 0) return 0;
+    typedef const char *(*name_fn)(void);
+    static name_fn get_name = NULL;
+    static int looked = 0;
+    if (!looked) {
+        get_name = (name_fn)dlsym(RTLD_DEFAULT, "_PyMem_GetCurrentAllocatorName");
+        looked = 1;
+    }
+    if (!get_name) return 0;
+    const char *name = get_name();                 /* asked on every call: hooks can be installed at any time */
+    return name != NULL && (strcmp(name, "pymalloc") == 0 || strcmp(name, "malloc") == 0);
+#endif
+}
+
+static inline PyObject *raw_ascii_str(const char *text, Py_ssize_t size) {
+    PyASCIIObject *u = (PyASCIIObject *)PyMem_RawMalloc(sizeof(PyASCIIObject) + (size_t)size + 1);
+    if (!u) return NULL;
+    u->ob_base.ob_refcnt = 1;
+    u->ob_base.ob_type = &PyUnicode_Type;          /* a static type: instances hold no reference to it */
+    u->length = size;
+    u->hash = -1;
+    memset(&u->state, 0, sizeof(u->state));
+    u->state.kind = PyUnicode_1BYTE_KIND;
+    u->state.compact = 1;
+    u->state.ascii = 1;
+#if PY_VERSION_HEX < 0x030C0000
+    u->state.ready = 1;
+    u->wstr = NULL;
+#endif
+    char *data = (char *)(u + 1);
+    memcpy(data, text, (size_t)size);
+    data[size] = 0;
+    return (PyObject *)u;
+}
+
+static inline int text_is_ascii(const unsigned char *s, int64_t n) {
+    uint64_t acc = 0;
+    int64_t j = 0;
+    for (; j + 8 <= n; j += 8) {
+        uint64_t v;
+        memcpy(&v, s + j, 8);
+        acc |= v;
+    }
+    for (; j < n; ++j) acc |= s[j];
+    return !(acc & 0x8080808080808080ull);
+}
+
+/* The str builder.  Text k is given either as a view (ptr[k], len[k]) or as base[off[k] .. off[k+1]); element i of the walk
+ * takes text k = idx[i] (idx absent: k = i) and its str goes to objs[slot[i]] (slot absent: i); na[i] != 0 skips the element
+ * (its slot keeps what it holds).  The output slots must be fresh (NULL / None). */
+#define VCHUNK 16384
+typedef struct {
+    const char *const *ptr;
+    const int64_t *len;
+    const char *base;
+    const int64_t *off;
+    const int64_t *idx, *slot;
+    const uint8_t *na;
+    PyObject **objs;
+    uint8_t *ascii;              /* per i: 1 = ASCII text (NULL: all are) */
+    int64_t n;
+    int64_t next_chunk;          /* atomic: next chunk a worker takes */
+    int64_t ready;               /* atomic: elements [0, ready) are allocated (python mode) */
+    int mode;                    /* 0 classify, 1 fill behind the allocating thread, 2 allocate + fill (raw mode) */
+    int abort_fill, oom;
+} vshared_t;
+
+static inline const unsigned char *vtext(const vshared_t *w, int64_t i, int64_t *n) {
+    const int64_t k = w->idx ? w->idx[i] : i;
+    if (w->off) { *n = w->off[k + 1] - w->off[k]; return (const unsigned char *)w->base + w->off[k]; }
+    *n = w->len[k];
+    return (const unsigned char *)w->ptr[k];
+}
+
+static void *vworker(void *arg) {
+    vshared_t *w = (vshared_t *)arg;
+    const int64_t n_chunks = (w->n + VCHUNK - 1) / VCHUNK;
+    for (;;) {
+        const int64_t c = __atomic_fetch_add(&w->next_chunk, 1, __ATOMIC_RELAXED);
+        if (c >= n_chunks) break;
+        const int64_t lo = c * VCHUNK, hi = (lo + VCHUNK < w->n) ? lo + VCHUNK : w->n;
+        if (w->mode == 1) {
+            while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {
+                if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;
+                sched_yield();
+            }
+        }
+        for (int64_t i = lo; i < hi; ++i) {
+            if (w->na && w->na[i]) continue;
+            int64_t n;
+            const unsigned char *s = vtext(w, i, &n);
+            if (w->mode == 0) {
+                w->ascii[i] = (uint8_t)text_is_ascii(s, n);
+            } else if (w->mode == 1) {
+                if (!w->ascii || w->ascii[i]) memcpy(PyUnicode_1BYTE_DATA(w->objs[w->slot ? w->slot[i] : i]), s, (size_t)n);
+            } else {
+                const int is_ascii = w->ascii ? (w->ascii[i] = (uint8_t)text_is_ascii(s, n)) : 1;
+                if (!is_ascii) continue;                       /* decoded by the calling thread afterwards */
+                PyObject *o = raw_ascii_str((const char *)s, (Py_ssize_t)n);
+                if (!o) { __atomic_store_n(&w->oom, 1, __ATOMIC_RELAXED); return NULL; }
+                w->objs[w->slot ? w->slot[i] : i] = o;
+            }
+        }
+    }
+    return NULL;
+}
+
+static void vrun_all(vshared_t *w, int n_threads, int mode) {   /* without the GIL: every thread works through the chunks */
+    pthread_t th[MAXT];
+    int k = 0;
+    w->mode = mode;
+    w->next_chunk = 0;
+    for (int t = 1; t < n_threads; ++t)
+        if (pthread_create(&th[k], NULL, vworker, w) == 0) ++k;
+    vworker(w);
+    for (int t = 0; t < k; ++t) pthread_join(th[t], NULL);
+}
+
+/* w: the texts, idx / slot / na, objs and n filled in.  Returns 0, or -1 with an exception set (what was created stays in the
+ * array, which owns it; ASCII objects not yet filled hold garbage text). */
+static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
+    const int64_t n = w->n;
+    if (n == 0) return 0;
+    n_threads = clamp_threads(n_threads, n, 4096);
+    for (int64_t i = 0; i < n; ++i) {             /* fresh slots only; the None references they hold are released here */
+        if (w->na && w->na[i]) continue;
+        PyObject **q = &w->objs[w->slot ? w->slot[i] : i];
+        if (*q == NULL) continue;
+        if (*q != Py_None) { PyErr_SetString(PyExc_ValueError, "str builder: the output array must be freshly allocated"); return -1; }
+        *q = NULL;
+        Py_DECREF(Py_None);
+    }
+    if (!all_ascii) {
+        w->ascii = (uint8_t *)PyMem_RawMalloc((size_t)n);
+        if (!w->ascii) { PyErr_NoMemory(); return -1; }
+    }
+    int failed = 0;
+    if (raw_alloc_allowed()) {
+        Py_BEGIN_ALLOW_THREADS
+        vrun_all(w, n_threads, 2);
+        Py_END_ALLOW_THREADS
+        if (w->oom) failed = 1;
+        if (!failed && w->ascii) {                 /* the few texts that are not ASCII */
+            for (int64_t i = 0; i < n; ++i) {
+                if (w->ascii[i] || (w->na && w->na[i])) continue;
+                int64_t k;
+                const unsigned char *s = vtext(w, i, &k);
+                PyObject *o = PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
+                if (!o) { failed = 2; break; }
+                w->objs[w->slot ? w->slot[i] : i] = o;
+            }
+        }
+    } else {
+        if (w->ascii) {
+            Py_BEGIN_ALLOW_THREADS
+            vrun_all(w, n_threads, 0);
+            Py_END_ALLOW_THREADS
+        }
+        /* allocate (this thread, with the GIL) while the workers fill what is already there */
+        pthread_t th[MAXT];
+        int fillers = 0;
+        w->mode = 1;
+        w->next_chunk = 0;
+        for (int t = 1; t < n_threads; ++t)
+            if (pthread_create(&th[fillers], NULL, vworker, w) == 0) ++fillers;
+        for (int64_t i = 0; i < n; ++i) {
+            if (!(w->na && w->na[i])) {
+                int64_t k;
+                const unsigned char *s = vtext(w, i, &k);
+                PyObject *o = (!w->ascii || w->ascii[i]) ? PyUnicode_New((Py_ssize_t)k, 127)
+                                                         : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
+                if (!o) { failed = 2; break; }
+                w->objs[w->slot ? w->slot[i] : i] = o;
+            }
+            if (((i + 1) & (VCHUNK - 1)) == 0) __atomic_store_n(&w->ready, i + 1, __ATOMIC_RELEASE);
+        }
+        if (failed) __atomic_store_n(&w->abort_fill, 1, __ATOMIC_RELAXED);
+        else __atomic_store_n(&w->ready, n, __ATOMIC_RELEASE);
+        Py_BEGIN_ALLOW_THREADS
+        if (!failed) vworker(w);                   /* help with what is left */
+        for (int t = 0; t < fillers; ++t) pthread_join(th[t], NULL);
+        Py_END_ALLOW_THREADS
+    }
+    if (w->ascii) { PyMem_RawFree(w->ascii); w->ascii = NULL; }
+    if (failed == 1) PyErr_NoMemory();
+    return failed ? -1 : 0;
+}
+
+/* map_strs(ptr, len, idx, slot, n, out, n_threads[, all_ascii]): out[slot[i]] = str(the len[k] bytes at ptr[k]), k = idx[i];
+ * all_ascii != 0: the caller vouches that every text is ASCII */
+static PyObject *map_strs(PyObject *self, PyObject *args) {
+    unsigned long long a_ptr, a_len, a_idx, a_slot, a_objs;
+    Py_ssize_t n;
+    int n_threads, all_ascii = 0;
+    if (!PyArg_ParseTuple(args, "KKKKnKi|i", &a_ptr, &a_len, &a_idx, &a_slot, &n, &a_objs, &n_threads, &all_ascii)) return NULL;
+    vshared_t w;
+    memset(&w, 0, sizeof(w));
+    w.ptr = (const char *const *)(uintptr_t)a_ptr;
+    w.len = (const int64_t *)(uintptr_t)a_len;
+    w.idx = (const int64_t *)(uintptr_t)a_idx;
+    w.slot = (const int64_t *)(uintptr_t)a_slot;
+    w.objs = (PyObject **)(uintptr_t)a_objs;
+    w.n = (int64_t)n;
+    if (build_strs(&w, n_threads, all_ascii) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+/* strs_from_utf8(text, off, n, na, objs_out, n_threads): objs_out[i] = str(text[off[i] : off[i+1]]) where na[i] == 0 (na may be 0) */
+static PyObject *strs_from_utf8(PyObject *self, PyObject *args) {
+    unsigned long long a_text, a_off, a_na, a_objs;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKnKKi", &a_text, &a_off, &n, &a_na, &a_objs, &n_threads)) return NULL;
+    vshared_t w;
+    memset(&w, 0, sizeof(w));
+    w.base = (const char *)(uintptr_t)a_text;
+    w.off = (const int64_t *)(uintptr_t)a_off;
+    w.na = (const uint8_t *)(uintptr_t)a_na;
+    w.objs = (PyObject **)(uintptr_t)a_objs;
+    w.n = (int64_t)n;
+    if (build_strs(&w, n_threads, 0) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+/* map_objects(src, idx, slot, n, out, n_threads): out[slot[i]] = src[idx[i]] for object arrays.  The caller KEEPS the GIL (no
+ * other Python thread runs) and the workers count references with atomic adds — one per RUN of equal objects, so a row-ordered
+ * walk (the ~15 records of a source row follow each other) touches each source object's header once instead of bouncing its
+ * cache line between cores once per record.  out must be freshly allocated (NULL / None slots). */
+typedef struct {
+    PyObject **src, **out;
+    const int64_t *idx, *slot;
+    int64_t lo, hi;
+} mobj_t;
+
+static void *mobj_worker(void *arg) {
+    mobj_t *w = (mobj_t *)arg;
+    PyObject *run = NULL;
+    Py_ssize_t count = 0;
+    for (int64_t i = w->lo; i < w->hi; ++i) {
+        PyObject *o = w->src[w->idx ? w->idx[i] : i];
+        if (o == NULL) o = Py_None;
+        if (o != run) {
+            if (run) __atomic_fetch_add(&run->ob_refcnt, count, __ATOMIC_RELAXED);
+            run = o;
+            count = 0;
+        }
+        ++count;
+        w->out[w->slot ? w->slot[i] : i] = o;
+    }
+    if (run) __atomic_fetch_add(&run->ob_refcnt, count, __ATOMIC_RELAXED);
+    return NULL;
+}
+
+/* fresh output slots: NULL, or None whose references are handed back here */
+static int release_fresh_slots(PyObject **out, Py_ssize_t n, const char *who) {
+    Py_ssize_t nones = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (out[i] == Py_None) ++nones;
+        else if (out[i] != NULL) { PyErr_Format(PyExc_ValueError, "%s: the output array must be freshly allocated", who); return -1; }
+    }
+    if (nones) {
+        for (Py_ssize_t i = 0; i < n; ++i) out[i] = NULL;
+        Py_SET_REFCNT(Py_None, Py_REFCNT(Py_None) - nones);
+    }
+    return 0;
+}
+
+static PyObject *map_objects(PyObject *self, PyObject *args) {
+    unsigned long long a_src, a_idx, a_slot, a_out;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKKnKi", &a_src, &a_idx, &a_slot, &n, &a_out, &n_threads)) return NULL;
+    n_threads = clamp_threads(n_threads, (int64_t)n, 65536);
+    if (release_fresh_slots((PyObject **)(uintptr_t)a_out, n, "map_objects") < 0) return NULL;
+    mobj_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].src = (PyObject **)(uintptr_t)a_src;
+        w[t].out = (PyObject **)(uintptr_t)a_out;
+        w[t].idx = (const int64_t *)(uintptr_t)a_idx;
+        w[t].slot = (const int64_t *)(uintptr_t)a_slot;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+    }
+    run_workers(mobj_worker, w, sizeof(w[0]), n_threads);
+    Py_RETURN_NONE;
+}
+
+/* map_small(table, m, codes, idx, slot, n, out, n_threads): out[slot[i]] = table[codes[idx[i]]] for a SMALL table of m objects
+ * (the labels of the rules, the category names): sixteen threads adding to twenty reference counts one element at a time would
+ * pass those cache lines around 15 M times, so every worker counts its uses per entry and adds each sum once.  codes are int32
+ * in [0, m) (checked by the caller); out must be freshly allocated.  The caller keeps the GIL. */
+typedef struct {
+    PyObject **table, **out;
+    const int32_t *codes;
+    const int64_t *idx, *slot;
+    int64_t m, lo, hi;
+    int64_t *count;
+} msmall_t;
+
+static void *msmall_worker(void *arg) {
+    msmall_t *w = (msmall_t *)arg;
+    for (int64_t i = w->lo; i < w->hi; ++i) {
+        const int32_t c = w->codes[w->idx ? w->idx[i] : i];
+        PyObject *o = w->table[c];
+        ++w->count[c];
+        w->out[w->slot ? w->slot[i] : i] = o ? o : Py_None;
+    }
+    for (int64_t c = 0; c < w->m; ++c)
+        if (w->count[c]) {
+            PyObject *o = w->table[c] ? w->table[c] : Py_None;
+            __atomic_fetch_add(&o->ob_refcnt, (Py_ssize_t)w->count[c], __ATOMIC_RELAXED);
+        }
+    return NULL;
+}
+
+static PyObject *map_small(PyObject *self, PyObject *args) {
+    unsigned long long a_table, a_codes, a_idx, a_slot, a_out;
+    Py_ssize_t m, n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KnKKKnKi", &a_table, &m, &a_codes, &a_idx, &a_slot, &n, &a_out, &n_threads)) return NULL;
+    n_threads = clamp_threads(n_threads, (int64_t)n, 65536);
+    if (release_fresh_slots((PyObject **)(uintptr_t)a_out, n, "map_small") < 0) return NULL;
+    const size_t mm = (size_t)(m > 0 ? m : 1);
+    int64_t *counts = (int64_t *)PyMem_RawCalloc((size_t)n_threads * mm, sizeof(int64_t));
+    if (!counts) return PyErr_NoMemory();
+    msmall_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].table = (PyObject **)(uintptr_t)a_table;
+        w[t].codes = (const int32_t *)(uintptr_t)a_codes;
+        w[t].idx = (const int64_t *)(uintptr_t)a_idx;
+        w[t].slot = (const int64_t *)(uintptr_t)a_slot;
+        w[t].out = (PyObject **)(uintptr_t)a_out;
+        w[t].m = (int64_t)m;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+        w[t].count = counts + (size_t)t * mm;
+    }
+    run_workers(msmall_worker, w, sizeof(w[0]), n_threads);
+    PyMem_RawFree(counts);
+    Py_RETURN_NONE;
+}
+
+/* map_fixed(src, itemsize, idx, slot, n, out, n_threads): out[slot[i]] = src[idx[i]] for items of 1 / 2 / 4 / 8 bytes, by worker
+ * threads without the GIL (numpy's take is one thread; the split step moves a dozen 15 M-element columns) */
+typedef struct {
+    const char *src;
+    char *out;
+    const int64_t *idx, *slot;
+    int64_t itemsize, lo, hi;
+} mfix_t;
+
+#define MFIX_LOOP(T)                                                                          \
+    {                                                                                         \
+        const T *s = (const T *)w->src;                                                       \
+        T *o = (T *)w->out;                                                                   \
+        if (idx && slot) for (int64_t i = w->lo; i < w->hi; ++i) o[slot[i]] = s[idx[i]];      \
+        else if (idx) for (int64_t i = w->lo; i < w->hi; ++i) o[i] = s[idx[i]];               \
+        else if (slot) for (int64_t i = w->lo; i < w->hi; ++i) o[slot[i]] = s[i];             \
+        else for (int64_t i = w->lo; i < w->hi; ++i) o[i] = s[i];                             \
+    }
+
+static void *mfix_worker(void *arg) {
+    mfix_t *w = (mfix_t *)arg;
+    const int64_t *idx = w->idx, *slot = w->slot;
+    switch (w->itemsize) {
+        case 8: MFIX_LOOP(uint64_t) break;
+        case 4: MFIX_LOOP(uint32_t) break;
+        case 2: MFIX_LOOP(uint16_t) break;
+        default: MFIX_LOOP(uint8_t) break;
+    }
+    return NULL;
+}
+
+static PyObject *map_fixed(PyObject *self, PyObject *args) {
+    unsigned long long a_src, a_idx, a_slot, a_out;
+    Py_ssize_t itemsize, n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KnKKnKi", &a_src, &itemsize, &a_idx, &a_slot, &n, &a_out, &n_threads)) return NULL;
+    if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) { PyErr_SetString(PyExc_ValueError, "map_fixed: itemsize 1, 2, 4 or 8"); return NULL; }
+    n_threads = clamp_threads(n_threads, (int64_t)n, 65536);
+    mfix_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].src = (const char *)(uintptr_t)a_src;
+        w[t].out = (char *)(uintptr_t)a_out;
+        w[t].idx = (const int64_t *)(uintptr_t)a_idx;
+        w[t].slot = (const int64_t *)(uintptr_t)a_slot;
+        w[t].itemsize = (int64_t)itemsize;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+    }
+    Py_BEGIN_ALLOW_THREADS
+    run_workers(mfix_worker, w, sizeof(w[0]), n_threads);
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
+/* category_slots(cat, pos, cat_off, n, out, n_threads): out[e] = cat_off[cat[e]] + pos[e] — where record e stands once the
+ * categories are laid out one after the other, each in its shuffled order.  cat int32, the rest int64. */
+typedef struct {
+    const int32_t *cat;
+    const int64_t *pos, *cat_off;
+    int64_t *out;
+    int64_t lo, hi;
+} cslot_t;
+
+static void *cslot_worker(void *arg) {
+    cslot_t *w = (cslot_t *)arg;
+    for (int64_t e = w->lo; e < w->hi; ++e) w->out[e] = w->cat_off[w->cat[e]] + w->pos[e];
+    return NULL;
+}
+
+static PyObject *category_slots(PyObject *self, PyObject *args) {
+    unsigned long long a_cat, a_pos, a_off, a_out;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKKnKi", &a_cat, &a_pos, &a_off, &n, &a_out, &n_threads)) return NULL;
+    n_threads = clamp_threads(n_threads, (int64_t)n, 65536);
+    cslot_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].cat = (const int32_t *)(uintptr_t)a_cat;
+        w[t].pos = (const int64_t *)(uintptr_t)a_pos;
+        w[t].cat_off = (const int64_t *)(uintptr_t)a_off;
+        w[t].out = (int64_t *)(uintptr_t)a_out;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+    }
+    Py_BEGIN_ALLOW_THREADS
+    run_workers(cslot_worker, w, sizeof(w[0]), n_threads);
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
+/* map_text(ptr, len, idx, slot, n, out_off, out_text, n_threads): the len[k] bytes at ptr[k], k = idx[i], copied to
+ * out_text + out_off[slot[i]] — out_off is the caller's prefix sum of the lengths in OUTPUT order: one contiguous UTF-8 buffer
+ * in the wanted order, for an Arrow string column laid over it */
+typedef struct {
+    const char *const *ptr;
+    const int64_t *len, *idx, *slot, *off;
+    char *out;
+    int64_t lo, hi;
+} mtext_t;
+
+static void *mtext_worker(void *arg) {
+    mtext_t *w = (mtext_t *)arg;
+    for (int64_t i = w->lo; i < w->hi; ++i) {
+        const int64_t k = w->idx ? w->idx[i] : i;
+        if (w->len[k]) memcpy(w->out + w->off[w->slot ? w->slot[i] : i], w->ptr[k], (size_t)w->len[k]);
+    }
+    return NULL;
+}
+
+static PyObject *map_text(PyObject *self, PyObject *args) {
+    unsigned long long a_ptr, a_len, a_idx, a_slot, a_off, a_out;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKKKnKKi", &a_ptr, &a_len, &a_idx, &a_slot, &n, &a_off, &a_out, &n_threads)) return NULL;
+    n_threads = clamp_threads(n_threads, (int64_t)n, 65536);
+    mtext_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].ptr = (const char *const *)(uintptr_t)a_ptr;
+        w[t].len = (const int64_t *)(uintptr_t)a_len;
+        w[t].idx = (const int64_t *)(uintptr_t)a_idx;
+        w[t].slot = (const int64_t *)(uintptr_t)a_slot;
+        w[t].off = (const int64_t *)(uintptr_t)a_off;
+        w[t].out = (char *)(uintptr_t)a_out;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+    }
+    Py_BEGIN_ALLOW_THREADS
+    run_workers(mtext_worker, w, sizeof(w[0]), n_threads);
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
+static PyObject *str_alloc_mode(PyObject *self, PyObject *args) {
+    return PyUnicode_FromString(raw_alloc_allowed() ? "raw" : "python");
+}
+
 static PyMethodDef methods[] = {
     {"all_exact_str", all_exact_str, METH_VARARGS, "is every element of an object array an exact str"},
     {"gather_utf8", gather_utf8, METH_VARARGS, "copy (pointer, length) views into one flat buffer at given offsets"},
     {"str_views", str_views, METH_VARARGS, "UTF-8 views of the str elements of an object array"},
     {"strs_from_utf8", strs_from_utf8, METH_VARARGS, "str objects from flat UTF-8 + offsets into an object array"},
+    {"map_strs", map_strs, METH_VARARGS, "out[slot[i]] = str(text idx[i]) from (pointer, length) views"},
+    {"map_objects", map_objects, METH_VARARGS, "out[slot[i]] = src[idx[i]] for object arrays, on worker threads"},
+    {"map_small", map_small, METH_VARARGS, "out[slot[i]] = table[codes[idx[i]]] for a small table of objects"},
+    {"map_fixed", map_fixed, METH_VARARGS, "out[slot[i]] = src[idx[i]] for 1/2/4/8-byte items, on worker threads"},
+    {"map_text", map_text, METH_VARARGS, "texts given as views -> one contiguous buffer at given offsets"},
+    {"category_slots", category_slots, METH_VARARGS, "out[e] = cat_off[cat[e]] + pos[e]"},
+    {"str_alloc_mode", str_alloc_mode, METH_NOARGS, "'raw' when str objects are allocated by worker threads, else 'python'"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_dydpy", "pandas object column <-> flat UTF-8 buffers", -1, methods};

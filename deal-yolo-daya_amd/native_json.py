@@ -374,43 +374,147 @@ def _strings(data_ptr, off_ptr, count) -> np.ndarray:
 
 
 class SplitExpansion:
-    """Result of split_expand, copied out of the native handle."""
+    """Result of split_expand.  The fixed-width arrays are copied out; the record texts stay in the native handle's per-thread
+    buffers (``rec_ptr`` / ``rec_len``: one view per record) until ``close()`` — ``record_strings`` turns them into str objects, in
+    any order, without a flat copy of the text in between."""
 
     def __init__(self, handle, n_cells):
         L = _native.load_library()
-        try:
-            self.status = _view(L.dyd_split_status(handle), np.uint8, n_cells).copy()
-            self.n_expanded = _view(L.dyd_split_n_expanded(handle), np.int32, n_cells).copy()
-            rows, events = int(L.dyd_split_rows(handle)), int(L.dyd_split_events(handle))
-            self.row_cell = _view(L.dyd_split_row_cell(handle), np.int64, rows).copy()
-            self.row_label = _view(L.dyd_split_row_label(handle), np.int32, rows).copy()
-            self.event_cell = _view(L.dyd_split_event_cell(handle), np.int64, events).copy()
-            self.event_kind = _view(L.dyd_split_event_kind(handle), np.uint8, events).copy()
-            d, o = C.c_void_p(), C.c_void_p()
-            out = []
-            for which, count in ((0, rows), (1, n_cells), (2, n_cells), (3, events)):
-                _native.check(L.dyd_split_strings(handle, which, C.byref(d), C.byref(o)), "dyd_split_strings")
-                out.append(_strings(d.value, o.value, count))
-            self.row_json, self.combo, self.reasons, self.event_label = out
-        finally:
-            L.dyd_split_free(handle)
+        self._h = handle
+        self.n_cells = n_cells
+        self.status = _view(L.dyd_split_status(handle), np.uint8, n_cells).copy()
+        self.n_expanded = _view(L.dyd_split_n_expanded(handle), np.int32, n_cells).copy()
+        rows, events = int(L.dyd_split_rows(handle)), int(L.dyd_split_events(handle))
+        self.n_records = rows
+        self.row_cell = _view(L.dyd_split_row_cell(handle), np.int64, rows).copy()
+        self.row_label = _view(L.dyd_split_row_label(handle), np.int32, rows).copy()
+        self.event_cell = _view(L.dyd_split_event_cell(handle), np.int64, events).copy()
+        self.event_kind = _view(L.dyd_split_event_kind(handle), np.uint8, events).copy()
+        self.event_code = _view(L.dyd_split_event_code(handle), np.int32, events).copy()
+        p, ln = C.c_void_p(), C.c_void_p()
+        _native.check(L.dyd_split_rec_views(handle, C.byref(p), C.byref(ln)), "dyd_split_rec_views")
+        self.rec_ptr = _view(p.value, np.uint64, rows)            # views into the handle
+        self.rec_len = _view(ln.value, np.int64, rows)
+        self.fast_cells = int(L.dyd_split_fast_cells(handle))
+        self.all_ascii = bool(L.dyd_split_all_ascii(handle))
+        secs = np.zeros(2, np.float64)
+        L.dyd_split_seconds(handle, secs.ctypes.data)
+        self.seconds = {"parse": float(secs[0]), "gather": float(secs[1])}
+        self.combo = self._strings(1, n_cells)
+        self.reasons = self._strings(2, n_cells)
+        self.reasons_nonempty = np.diff(self._buffers(2, n_cells)[1]) > 0 if n_cells else np.zeros(0, bool)
+        self.undefined = self._strings(4, int(L.dyd_split_undefined(handle)))      # distinct labels event_code indexes
+        self._n_labels = None
+
+    def _buffers(self, which, count):
+        d, o = C.c_void_p(), C.c_void_p()
+        _native.check(_native.load_library().dyd_split_strings(self._h, which, C.byref(d), C.byref(o)), "dyd_split_strings")
+        off = _view(o.value, np.int64, count + 1)
+        return _view(d.value, np.uint8, int(off[-1]) if count else 0), off
+
+    def _strings(self, which, count) -> np.ndarray:
+        if count == 0:
+            return np.empty(0, object)
+        text, off = self._buffers(which, count)
+        return strings_from_buffers(text, off)
+
+    def label_stats(self, n_labels: int):
+        """per label of the rules: (index of the first record carrying it or -1, number of records)"""
+        L = _native.load_library()
+        return (_view(L.dyd_split_label_first(self._h), np.int64, n_labels).copy(),
+                _view(L.dyd_split_label_count(self._h), np.int64, n_labels).copy())
+
+    def record_strings(self, idx=None, slot=None) -> np.ndarray:
+        """object array of the records' JSON text (str): out[slot[i]] = record idx[i] (either optional; all records in row order
+        without both)"""
+        from . import pycells
+
+        if self._h is None:
+            raise ValueError("the expansion was closed")
+        if pycells.available():
+            return pycells.strings_from_views(self.rec_ptr, self.rec_len, idx, all_ascii=self.all_ascii, slot=slot, checked=slot is not None and idx is None)
+        text, off = self._buffers(0, self.n_records)                # portable route: one flat copy, then pyarrow
+        got = strings_from_buffers(text, off)
+        if idx is not None:
+            got = got[idx]
+        if slot is None:
+            return got
+        out = np.empty(len(got), object)
+        out[slot] = got
+        return out
+
+    def record_text(self, idx=None, slot=None):
+        """(contiguous utf-8 buffer, offsets [n+1]) with record idx[i] at place slot[i] — for an Arrow string column"""
+        from . import pycells
+
+        if self._h is None:
+            raise ValueError("the expansion was closed")
+        if pycells.available():
+            return pycells.gather_text(self.rec_ptr, self.rec_len, idx, slot=slot)
+        text, off = self._buffers(0, self.n_records)
+        order = np.arange(self.n_records, dtype=np.int64) if idx is None else np.asarray(idx, np.int64)
+        if slot is not None:
+            inv = np.empty(len(order), np.int64)
+            inv[slot] = order
+            order = inv
+        lens = np.diff(off)[order]
+        out_off = np.zeros(len(order) + 1, np.int64)
+        np.cumsum(lens, out=out_off[1:])
+        pieces = [text[off[k]:off[k + 1]] for k in order.tolist()]
+        return (np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)), out_off
+
+    @property
+    def row_json(self) -> np.ndarray:
+        return self.record_strings()
+
+    @property
+    def event_label(self) -> np.ndarray:
+        """per event the undefined label ("" for the other kinds)"""
+        table = np.concatenate([self.undefined, np.asarray([""], object)])
+        return table[self.event_code]                               # code -1 -> the trailing ""
+
+    def close(self):
+        if self._h:
+            self.rec_ptr = self.rec_len = None
+            _native.load_library().dyd_split_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _label_buffers(labels):
+    lab = [s.encode("utf-8") for s in labels]
+    lab_off = np.zeros(len(lab) + 1, np.int64)
+    np.cumsum([len(b) for b in lab], out=lab_off[1:])
+    return np.frombuffer(b"".join(lab) or b"\0", dtype=np.uint8), lab_off
 
 
 def split_expand(cells, labels: list, n_threads: int = 0) -> SplitExpansion:
     """cells: per row the JSON cell the reference would pick (str) or None; labels: keys of label_to_category"""
     L = _native.load_library()
     buf, off, missing, keep = cells_to_buffers(cells)
-    for i, c in enumerate(cells):                       # "" is not a usable cell either (processor.py:716)
-        if c == "":
+    for i, c in enumerate(cells):                       # "" is not a usable cell either (processor.py:716); in the joined buffer it
+        if c == "":                                     # is followed by its separator blank, so say so here
             missing[i] = 1
-    lab = [s.encode("utf-8") for s in labels]
-    lab_off = np.zeros(len(lab) + 1, np.int64)
-    np.cumsum([len(b) for b in lab], out=lab_off[1:])
-    lab_buf = np.frombuffer(b"".join(lab) or b"\0", dtype=np.uint8)
+    lab_buf, lab_off = _label_buffers(labels)
     h = C.c_void_p()
     _native.check(L.dyd_json_split_expand(buf.ctypes.data, off.ctypes.data, missing.ctypes.data, len(cells), lab_buf.ctypes.data,
-                                          lab_off.ctypes.data, len(lab), n_threads, C.byref(h)), "dyd_json_split_expand")
+                                          lab_off.ctypes.data, len(labels), n_threads, C.byref(h)), "dyd_json_split_expand")
     return SplitExpansion(h, len(cells))
+
+
+def split_expand_views(ptr: np.ndarray, length: np.ndarray, missing: np.ndarray, labels: list, n_threads: int = 0) -> SplitExpansion:
+    """the same over one (address, length) view per cell (pycells.CellViews of the DataFrame's own str objects)"""
+    L = _native.load_library()
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    missing = np.ascontiguousarray(missing, dtype=np.uint8)
+    lab_buf, lab_off = _label_buffers(labels)
+    h = C.c_void_p()
+    _native.check(L.dyd_json_split_expand_v(ptr.ctypes.data, length.ctypes.data, missing.ctypes.data, len(ptr), lab_buf.ctypes.data,
+                                            lab_off.ctypes.data, len(labels), n_threads, C.byref(h)), "dyd_json_split_expand_v")
+    return SplitExpansion(h, len(ptr))
 
 
 # ------------------------------------------------------------------------------------------ label_replace step

@@ -69,6 +69,144 @@ def strings(text: np.ndarray, off: np.ndarray, na=None, n_threads: int = 0) -> n
     return out
 
 
+def _threads(n_threads: int) -> int:
+    from . import native_json as _nj
+
+    return n_threads or _nj.host_threads()
+
+
+def _checked_index(idx, size) -> np.ndarray:
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    if len(idx) and (int(idx.min()) < 0 or int(idx.max()) >= size):
+        raise IndexError("index out of range")
+    return idx
+
+
+def _addr(a) -> int:
+    return 0 if a is None else a.ctypes.data
+
+
+# The column builders below all compute   out[slot[i]] = f(idx[i])   (either index optional) on worker threads: the split step
+# walks its records in row order — sequential reads, a source row's objects many times in a row — and scatters to the place the
+# shuffle gave each record.  ``slot`` must be a permutation of range(n) (every output element written once); ``checked=True``
+# says the index arrays were made by this package and need no range check.
+
+
+def str_alloc_mode() -> str:
+    """"raw": str objects are allocated by the worker threads themselves (csrc/pyhelpers.c, map_strs); "python": by the calling
+    thread through PyUnicode_New (debug / traced / custom allocators, DYD_STR_ALLOC=python, or no extension)"""
+    return _dydpy.str_alloc_mode() if available() else "python"
+
+
+def strings_from_views(ptr: np.ndarray, length: np.ndarray, idx=None, n_threads: int = 0, all_ascii: bool = False, slot=None,
+                       checked: bool = False) -> np.ndarray:
+    """object array of str from one (address, length) view per text: out[slot[i]] = text idx[i] — the split step's records,
+    straight from the native handle's buffers (no flat copy of the text in either order).
+    ``all_ascii``: the caller vouches that every text is ASCII (saves the classifying pass)."""
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    n = len(ptr) if idx is None else len(idx)
+    if idx is not None:
+        idx = np.ascontiguousarray(idx, dtype=np.int64) if checked else _checked_index(idx, len(ptr))
+    if slot is not None:
+        slot = np.ascontiguousarray(slot, dtype=np.int64) if checked else _checked_index(slot, n)
+        if len(slot) != n:
+            raise ValueError("slot and idx differ in length")
+    out = np.empty(n, object)
+    if n:
+        _dydpy.map_strs(ptr.ctypes.data, length.ctypes.data, _addr(idx), _addr(slot), n, out.ctypes.data, _threads(n_threads),
+                        1 if all_ascii else 0)
+    return out
+
+
+def take(values: np.ndarray, idx=None, n_threads: int = 0, checked: bool = False, slot=None) -> np.ndarray:
+    """out[slot[i]] = values[idx[i]] on worker threads: 1-D object arrays (references counted with one atomic add per run of equal
+    objects — numpy walks the scattered object headers on one thread) and 1-D arrays of 1 / 2 / 4 / 8-byte items; anything else,
+    and short index arrays, through numpy."""
+    n = len(values) if idx is None else len(idx)
+    if (not available() or not isinstance(values, np.ndarray) or values.ndim != 1 or n < 65536
+            or not (values.dtype == object or (values.dtype.kind in "iufb" and values.dtype.itemsize in (1, 2, 4, 8)))):
+        got = values if idx is None else values[idx]
+        if slot is None:
+            return got
+        out = np.empty(n, got.dtype)
+        out[slot] = got
+        return out
+    values = np.ascontiguousarray(values)
+    if idx is not None:
+        idx = np.ascontiguousarray(idx, dtype=np.int64) if checked else _checked_index(idx, len(values))
+    if slot is not None:
+        slot = np.ascontiguousarray(slot, dtype=np.int64) if checked else _checked_index(slot, n)
+        if len(slot) != n:
+            raise ValueError("slot and idx differ in length")
+    out = np.empty(n, values.dtype)
+    if values.dtype == object:
+        _dydpy.map_objects(values.ctypes.data, _addr(idx), _addr(slot), n, out.ctypes.data, _threads(n_threads))
+    else:
+        _dydpy.map_fixed(values.ctypes.data, values.dtype.itemsize, _addr(idx), _addr(slot), n, out.ctypes.data, _threads(n_threads))
+    return out
+
+
+def take_small(table: np.ndarray, codes: np.ndarray, idx=None, n_threads: int = 0, slot=None, checked: bool = False) -> np.ndarray:
+    """out[slot[i]] = table[codes[idx[i]]] for a SMALL object table (the labels of the rules) and int32 codes: every worker adds
+    its uses of an entry to the reference count once instead of once per element"""
+    n = len(codes) if idx is None else len(idx)
+    if not available() or n < 65536 or len(table) > 65536:
+        got = table[codes if idx is None else codes[idx]]
+        if slot is None:
+            return got
+        out = np.empty(n, object)
+        out[slot] = got
+        return out
+    table = np.ascontiguousarray(table, dtype=object)
+    codes = np.ascontiguousarray(codes, dtype=np.int32)
+    if len(codes) and (int(codes.min()) < 0 or int(codes.max()) >= len(table)):
+        raise IndexError("take_small: code out of range")
+    if idx is not None:
+        idx = np.ascontiguousarray(idx, dtype=np.int64) if checked else _checked_index(idx, len(codes))
+    if slot is not None:
+        slot = np.ascontiguousarray(slot, dtype=np.int64) if checked else _checked_index(slot, n)
+    out = np.empty(n, object)
+    _dydpy.map_small(table.ctypes.data, len(table), codes.ctypes.data, _addr(idx), _addr(slot), n, out.ctypes.data, _threads(n_threads))
+    return out
+
+
+def category_slots(cat: np.ndarray, pos: np.ndarray, cat_off: np.ndarray, n_threads: int = 0) -> np.ndarray:
+    """slot[e] = cat_off[cat[e]] + pos[e]: where record e stands once the categories are laid out one after the other, each in
+    its shuffled order (K6's positions are a permutation inside each category, so slot is a permutation of range(n))"""
+    n = len(cat)
+    if not available() or n < 65536:
+        slot = cat_off[cat].astype(np.int64) if n else np.zeros(0, np.int64)
+        slot += pos
+        return slot
+    out = np.empty(n, np.int64)
+    cat = np.ascontiguousarray(cat, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    cat_off = np.ascontiguousarray(cat_off, dtype=np.int64)
+    if int(cat.min()) < 0 or int(cat.max()) >= len(cat_off) - 1:
+        raise IndexError("category_slots: category out of range")
+    _dydpy.category_slots(cat.ctypes.data, pos.ctypes.data, cat_off.ctypes.data, n, out.ctypes.data, _threads(n_threads))
+    return out
+
+
+def gather_text(ptr: np.ndarray, length: np.ndarray, idx=None, n_threads: int = 0, slot=None, checked: bool = False):
+    """(contiguous utf-8 buffer u8, offsets i64 [n+1]) with text idx[i] at place slot[i], the texts given as (address, length) views"""
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    n = len(ptr) if idx is None else len(idx)
+    if idx is not None:
+        idx = np.ascontiguousarray(idx, dtype=np.int64) if checked else _checked_index(idx, len(ptr))
+    if slot is not None:
+        slot = np.ascontiguousarray(slot, dtype=np.int64) if checked else _checked_index(slot, n)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(take(length, idx, checked=True, slot=slot), out=off[1:])
+    data = np.empty(max(int(off[-1]), 1), np.uint8)
+    if n:
+        _dydpy.map_text(ptr.ctypes.data, length.ctypes.data, _addr(idx), _addr(slot), n, off.ctypes.data, data.ctypes.data,
+                        _threads(n_threads))
+    return data[:int(off[-1])], off
+
+
 def flat_utf8(col_values: np.ndarray, na: np.ndarray, na_as_text: bool = False):
     """(flat utf-8 bytes u8, offsets i64 [n+1]) of an object array whose present cells are ALL str — or None when some present
     cell is something else (the caller's tagged spelling handles those).  Missing cells come out empty, or — ``na_as_text``,

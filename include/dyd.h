@@ -319,8 +319,25 @@ const int32_t *dyd_split_row_label(const dyd_split *h);       /* [rows] */
 int64_t dyd_split_events(const dyd_split *h);
 const int64_t *dyd_split_event_cell(const dyd_split *h);      /* [events] */
 const uint8_t *dyd_split_event_kind(const dyd_split *h);      /* [events] */
-/* which: 0 record JSON [rows], 1 label combination [n_cells], 2 joined reasons [n_cells], 3 event label [events] */
-int dyd_split_strings(const dyd_split *h, int which, const uint8_t **data, const int64_t **off);
+/* which: 0 record JSON [rows] (a flat copy, made on the first request), 1 label combination [n_cells], 2 joined reasons
+ * [n_cells], 3 event label [events] (made on the first request), 4 the distinct undefined labels [dyd_split_undefined] */
+int dyd_split_strings(dyd_split *h, int which, const uint8_t **data, const int64_t **off);
+/* the same expansion over one (pointer, length) view per cell — the str objects of a DataFrame column, nothing copied */
+int dyd_json_split_expand_v(const uint8_t *const *cell_ptr, const int64_t *cell_len, const uint8_t *missing, int64_t n_cells,
+                            const uint8_t *label_text, const int64_t *label_off, int32_t n_labels, int n_threads,
+                            dyd_split **out);
+/* table-scale accessors: the record texts stay in the worker threads' buffers, one (address, length) view per record in row
+ * order (valid until dyd_split_free); an event of kind 2 carries the index of its label in the table of distinct undefined
+ * labels (-1 otherwise); per label of the rules the first record carrying it (-1: none) and its number of records — the
+ * first-appearance order of the categories (processor.py:773) without a pass over the records */
+int dyd_split_rec_views(const dyd_split *h, const uint64_t **ptr, const int64_t **len);
+const int32_t *dyd_split_event_code(const dyd_split *h);      /* [events] */
+int64_t dyd_split_undefined(const dyd_split *h);
+const int64_t *dyd_split_label_first(const dyd_split *h);     /* [n_labels] */
+const int64_t *dyd_split_label_count(const dyd_split *h);     /* [n_labels] */
+int64_t dyd_split_fast_cells(const dyd_split *h);             /* cells the single-parse lane took */
+int dyd_split_all_ascii(const dyd_split *h);                  /* 1: every record text is pure ASCII */
+void dyd_split_seconds(const dyd_split *h, double *parse_gather2);
 void dyd_split_free(dyd_split *h);
 
 /* ---- native relabelling of the label_replace step (HOST code, multithreaded) ------------------------------
