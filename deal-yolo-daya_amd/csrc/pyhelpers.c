@@ -206,11 +206,21 @@ static PyObject *gather_utf8(PyObject *self, PyObject *args) {
 #define MAXT 64
 typedef void *(*worker_fn)(void *);
 
+static int64_t min_parallel = -1;    /* >= 0: overrides every builder's "too small for threads" size (tests) */
+
 static int clamp_threads(int n_threads, int64_t n, int64_t small) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > MAXT) n_threads = MAXT;
-    if (n < small) n_threads = 1;
+    if (n < (min_parallel >= 0 ? min_parallel : small)) n_threads = 1;
+    if ((int64_t)n_threads > n) n_threads = n > 0 ? (int)n : 1;
     return n_threads;
+}
+
+static PyObject *set_min_parallel(PyObject *self, PyObject *args) {
+    long long k;
+    if (!PyArg_ParseTuple(args, "L", &k)) return NULL;
+    min_parallel = (int64_t)k;
+    Py_RETURN_NONE;
 }
 
 /* runs fn over `count` argument blocks of `stride` bytes: block 0 on this thread, the others on their own */
@@ -225,16 +235,19 @@ static void run_workers(worker_fn fn, void *blocks, size_t stride, int count) {
     }
 }
 
-/* ---- str objects allocated by worker threads ------------------------------------------------------------------------
- * PyUnicode_New needs the GIL, so creating N str objects is one thread's work however many cores fill them: ~60 ns each, 0.9 s
- * for the 14 M records of a 1 M-row table — the largest single item of the split step.  CPython's object allocator hands every
- * request above 512 bytes to the raw allocator (malloc) and its free() sends every block that does not lie in one of its own
- * arenas back there (Objects/obmalloc.c: pymalloc_free -> address_in_range fails -> PyMem_RawFree): a block from
- * PyMem_RawMalloc IS a valid home for an object of any size.  malloc is thread-safe and needs no GIL, so the workers allocate,
- * initialise (the compact-ASCII header PyUnicode_New writes) and fill their share of the strings themselves.
+/* ---- large str objects allocated by worker threads ---------------------------------------------------------------------
+ * PyUnicode_New needs the GIL, so creating N str objects is one thread's work however many cores fill them.  CPython's object
+ * allocator hands every request above 512 bytes to the raw allocator (malloc) and its free() sends every block that does not
+ * lie in one of its own arenas back there (Objects/obmalloc.c: pymalloc_free -> address_in_range fails -> PyMem_RawFree), so
+ * for a LARGE str — the 2 KB bbox text of a row — PyUnicode_New is malloc + a header, and malloc is thread-safe and needs no
+ * GIL: the workers allocate, initialise (the compact-ASCII header PyUnicode_New writes) and fill those strings themselves, and
+ * they are released exactly as before.  Small strings (the split step's 160-byte records) stay with the calling thread and
+ * pymalloc: measured on the GPU box's host, 14 M of them from malloc on 16 threads are created in 0.6 s instead of 0.9 — and
+ * then take 3.5 s to free instead of 1.0 (glibc coalesces each one under the owning arena's lock).
  * Used only when the interpreter runs its stock allocators ("pymalloc" or "malloc": no debug hooks — they prefix every block —
  * and no tracemalloc / custom hooks, whose name is NULL), on a release build of CPython 3.8 .. 3.12, and not when
- * DYD_STR_ALLOC=python; otherwise the strings are allocated by the calling thread with PyUnicode_New as before. */
+ * DYD_STR_ALLOC=python; otherwise every string is allocated by the calling thread. */
+#define RAW_MIN_TEXT 464         /* sizeof(PyASCIIObject) + text + NUL > 512: beyond pymalloc's small-object threshold */
 static int raw_alloc_allowed(void) {
 #if defined(Py_TRACE_REFS) || defined(Py_REF_DEBUG) || defined(Py_GIL_DISABLED) || PY_VERSION_HEX < 0x03080000 || PY_VERSION_HEX >= 0x030D0000
     return 0;
@@ -303,7 +316,8 @@ typedef struct {
     int64_t n;
     int64_t next_chunk;          /* atomic: next chunk a worker takes */
     int64_t ready;               /* atomic: elements [0, ready) are allocated (python mode) */
-    int mode;                    /* 0 classify, 1 fill behind the allocating thread, 2 allocate + fill (raw mode) */
+    int mode;                    /* 0 classify, 1 create / fill */
+    int raw;                     /* large strings are allocated by the workers */
     int abort_fill, oom;
 } vshared_t;
 
@@ -321,27 +335,30 @@ static void *vworker(void *arg) {
         const int64_t c = __atomic_fetch_add(&w->next_chunk, 1, __ATOMIC_RELAXED);
         if (c >= n_chunks) break;
         const int64_t lo = c * VCHUNK, hi = (lo + VCHUNK < w->n) ? lo + VCHUNK : w->n;
-        if (w->mode == 1) {
-            while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {
-                if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;
-                sched_yield();
-            }
-        }
+        int waited = 0;
         for (int64_t i = lo; i < hi; ++i) {
             if (w->na && w->na[i]) continue;
             int64_t n;
             const unsigned char *s = vtext(w, i, &n);
             if (w->mode == 0) {
                 w->ascii[i] = (uint8_t)text_is_ascii(s, n);
-            } else if (w->mode == 1) {
-                if (!w->ascii || w->ascii[i]) memcpy(PyUnicode_1BYTE_DATA(w->objs[w->slot ? w->slot[i] : i]), s, (size_t)n);
-            } else {
-                const int is_ascii = w->ascii ? (w->ascii[i] = (uint8_t)text_is_ascii(s, n)) : 1;
-                if (!is_ascii) continue;                       /* decoded by the calling thread afterwards */
+                continue;
+            }
+            if (w->ascii && !w->ascii[i]) continue;            /* decoded by the calling thread */
+            if (w->raw && n >= RAW_MIN_TEXT) {                 /* a large string: this thread's own */
                 PyObject *o = raw_ascii_str((const char *)s, (Py_ssize_t)n);
                 if (!o) { __atomic_store_n(&w->oom, 1, __ATOMIC_RELAXED); return NULL; }
                 w->objs[w->slot ? w->slot[i] : i] = o;
+                continue;
             }
+            if (!waited) {                                     /* a small one: filled behind the allocating thread */
+                while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {
+                    if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;
+                    sched_yield();
+                }
+                waited = 1;
+            }
+            memcpy(PyUnicode_1BYTE_DATA(w->objs[w->slot ? w->slot[i] : i]), s, (size_t)n);
         }
     }
     return NULL;
@@ -375,54 +392,40 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     if (!all_ascii) {
         w->ascii = (uint8_t *)PyMem_RawMalloc((size_t)n);
         if (!w->ascii) { PyErr_NoMemory(); return -1; }
+        Py_BEGIN_ALLOW_THREADS
+        vrun_all(w, n_threads, 0);
+        Py_END_ALLOW_THREADS
     }
+    /* this thread allocates the small strings (and decodes the non-ASCII ones) with the GIL and publishes how far it got; the
+     * workers fill them behind it and create the large ones on their own */
+    w->raw = raw_alloc_allowed();
     int failed = 0;
-    if (raw_alloc_allowed()) {
-        Py_BEGIN_ALLOW_THREADS
-        vrun_all(w, n_threads, 2);
-        Py_END_ALLOW_THREADS
-        if (w->oom) failed = 1;
-        if (!failed && w->ascii) {                 /* the few texts that are not ASCII */
-            for (int64_t i = 0; i < n; ++i) {
-                if (w->ascii[i] || (w->na && w->na[i])) continue;
-                int64_t k;
-                const unsigned char *s = vtext(w, i, &k);
-                PyObject *o = PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
+    pthread_t th[MAXT];
+    int fillers = 0;
+    w->mode = 1;
+    w->next_chunk = 0;
+    for (int t = 1; t < n_threads; ++t)
+        if (pthread_create(&th[fillers], NULL, vworker, w) == 0) ++fillers;
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(w->na && w->na[i])) {
+            int64_t k;
+            const unsigned char *s = vtext(w, i, &k);
+            const int is_ascii = !w->ascii || w->ascii[i];
+            if (!(is_ascii && w->raw && k >= RAW_MIN_TEXT)) {
+                PyObject *o = is_ascii ? PyUnicode_New((Py_ssize_t)k, 127) : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
                 if (!o) { failed = 2; break; }
                 w->objs[w->slot ? w->slot[i] : i] = o;
             }
         }
-    } else {
-        if (w->ascii) {
-            Py_BEGIN_ALLOW_THREADS
-            vrun_all(w, n_threads, 0);
-            Py_END_ALLOW_THREADS
-        }
-        /* allocate (this thread, with the GIL) while the workers fill what is already there */
-        pthread_t th[MAXT];
-        int fillers = 0;
-        w->mode = 1;
-        w->next_chunk = 0;
-        for (int t = 1; t < n_threads; ++t)
-            if (pthread_create(&th[fillers], NULL, vworker, w) == 0) ++fillers;
-        for (int64_t i = 0; i < n; ++i) {
-            if (!(w->na && w->na[i])) {
-                int64_t k;
-                const unsigned char *s = vtext(w, i, &k);
-                PyObject *o = (!w->ascii || w->ascii[i]) ? PyUnicode_New((Py_ssize_t)k, 127)
-                                                         : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
-                if (!o) { failed = 2; break; }
-                w->objs[w->slot ? w->slot[i] : i] = o;
-            }
-            if (((i + 1) & (VCHUNK - 1)) == 0) __atomic_store_n(&w->ready, i + 1, __ATOMIC_RELEASE);
-        }
-        if (failed) __atomic_store_n(&w->abort_fill, 1, __ATOMIC_RELAXED);
-        else __atomic_store_n(&w->ready, n, __ATOMIC_RELEASE);
-        Py_BEGIN_ALLOW_THREADS
-        if (!failed) vworker(w);                   /* help with what is left */
-        for (int t = 0; t < fillers; ++t) pthread_join(th[t], NULL);
-        Py_END_ALLOW_THREADS
+        if (((i + 1) & (VCHUNK - 1)) == 0) __atomic_store_n(&w->ready, i + 1, __ATOMIC_RELEASE);
     }
+    if (failed) __atomic_store_n(&w->abort_fill, 1, __ATOMIC_RELAXED);
+    else __atomic_store_n(&w->ready, n, __ATOMIC_RELEASE);
+    Py_BEGIN_ALLOW_THREADS
+    if (!failed) vworker(w);                       /* help with what is left */
+    for (int t = 0; t < fillers; ++t) pthread_join(th[t], NULL);
+    Py_END_ALLOW_THREADS
+    if (w->oom) failed = 1;
     if (w->ascii) { PyMem_RawFree(w->ascii); w->ascii = NULL; }
     if (failed == 1) PyErr_NoMemory();
     return failed ? -1 : 0;
@@ -729,7 +732,8 @@ static PyMethodDef methods[] = {
     {"map_fixed", map_fixed, METH_VARARGS, "out[slot[i]] = src[idx[i]] for 1/2/4/8-byte items, on worker threads"},
     {"map_text", map_text, METH_VARARGS, "texts given as views -> one contiguous buffer at given offsets"},
     {"category_slots", category_slots, METH_VARARGS, "out[e] = cat_off[cat[e]] + pos[e]"},
-    {"str_alloc_mode", str_alloc_mode, METH_NOARGS, "'raw' when str objects are allocated by worker threads, else 'python'"},
+    {"set_min_parallel", set_min_parallel, METH_VARARGS, "tests: element count from which the builders use their threads (-1 = defaults)"},
+    {"str_alloc_mode", str_alloc_mode, METH_NOARGS, "'raw' when large str objects are allocated by worker threads, else 'python'"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_dydpy", "pandas object column <-> flat UTF-8 buffers", -1, methods};

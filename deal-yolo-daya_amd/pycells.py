@@ -69,6 +69,17 @@ def strings(text: np.ndarray, off: np.ndarray, na=None, n_threads: int = 0) -> n
     return out
 
 
+MIN_THREADED = 65536          # below this many elements the wrappers leave a gather to numpy (see set_min_threaded)
+
+
+def set_min_threaded(n: int = 65536) -> None:
+    """tests: run the threaded builders from ``n`` elements on (default 65536) — here and inside the extension"""
+    global MIN_THREADED
+    MIN_THREADED = n
+    if available():
+        _dydpy.set_min_parallel(-1 if n == 65536 else n)
+
+
 def _threads(n_threads: int) -> int:
     from . import native_json as _nj
 
@@ -93,8 +104,9 @@ def _addr(a) -> int:
 
 
 def str_alloc_mode() -> str:
-    """"raw": str objects are allocated by the worker threads themselves (csrc/pyhelpers.c, map_strs); "python": by the calling
-    thread through PyUnicode_New (debug / traced / custom allocators, DYD_STR_ALLOC=python, or no extension)"""
+    """"raw": LARGE str objects (beyond pymalloc's 512-byte threshold) are allocated by the worker threads themselves
+    (csrc/pyhelpers.c, "large str objects allocated by worker threads"); "python": every str by the calling thread through
+    PyUnicode_New (debug / traced / custom allocators, DYD_STR_ALLOC=python, or no extension)"""
     return _dydpy.str_alloc_mode() if available() else "python"
 
 
@@ -124,7 +136,7 @@ def take(values: np.ndarray, idx=None, n_threads: int = 0, checked: bool = False
     objects — numpy walks the scattered object headers on one thread) and 1-D arrays of 1 / 2 / 4 / 8-byte items; anything else,
     and short index arrays, through numpy."""
     n = len(values) if idx is None else len(idx)
-    if (not available() or not isinstance(values, np.ndarray) or values.ndim != 1 or n < 65536
+    if (not available() or not isinstance(values, np.ndarray) or values.ndim != 1 or n < MIN_THREADED
             or not (values.dtype == object or (values.dtype.kind in "iufb" and values.dtype.itemsize in (1, 2, 4, 8)))):
         got = values if idx is None else values[idx]
         if slot is None:
@@ -151,7 +163,7 @@ def take_small(table: np.ndarray, codes: np.ndarray, idx=None, n_threads: int = 
     """out[slot[i]] = table[codes[idx[i]]] for a SMALL object table (the labels of the rules) and int32 codes: every worker adds
     its uses of an entry to the reference count once instead of once per element"""
     n = len(codes) if idx is None else len(idx)
-    if not available() or n < 65536 or len(table) > 65536:
+    if not available() or n < MIN_THREADED or len(table) > 65536:
         got = table[codes if idx is None else codes[idx]]
         if slot is None:
             return got
@@ -175,7 +187,7 @@ def category_slots(cat: np.ndarray, pos: np.ndarray, cat_off: np.ndarray, n_thre
     """slot[e] = cat_off[cat[e]] + pos[e]: where record e stands once the categories are laid out one after the other, each in
     its shuffled order (K6's positions are a permutation inside each category, so slot is a permutation of range(n))"""
     n = len(cat)
-    if not available() or n < 65536:
+    if not available() or n < MIN_THREADED:
         slot = cat_off[cat].astype(np.int64) if n else np.zeros(0, np.int64)
         slot += pos
         return slot

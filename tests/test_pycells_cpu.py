@@ -1,0 +1,178 @@
+"""The threaded column builders of csrc/pyhelpers.c (pycells.py) against numpy / CPython itself: values, identity of the objects
+handed out, and the reference counts they leave behind.  Host glue only — no device involved."""
+import gc
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from deal_yolo_daya_amd import pycells
+
+pytestmark = pytest.mark.skipif(not pycells.available(), reason="_dydpy is not built for this interpreter")
+
+
+def _views(texts):
+    raw = [t.encode("utf-8") for t in texts]
+    buf = np.frombuffer(b"".join(raw) or b"\0", np.uint8)
+    lens = np.array([len(r) for r in raw], np.int64)
+    off = np.zeros(len(raw) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    return (buf.ctypes.data + off[:-1]).astype(np.uint64), lens, buf, off, raw
+
+
+def _texts(n, rng, big_every=11):
+    out = []
+    for i in range(n):
+        if i % 97 == 5:
+            out.append("中文，标签；" * (i % 5 + 1))
+        elif i % 53 == 7:
+            out.append("")
+        elif i % big_every == 0:
+            out.append(("{\"k\": %d, " % i) * 60)                      # > 512 bytes: the worker-allocated kind
+        else:
+            out.append("r%d-" % i * (i % 9 + 1))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["raw", "python"])
+def test_strings_from_views_in_any_order_are_real_strs(mode, monkeypatch):
+    monkeypatch.setenv("DYD_STR_ALLOC", mode)
+    rng = np.random.default_rng(1)
+    texts = _texts(120_000, rng)
+    ptr, lens, keep, _, raw = _views(texts)
+    assert pycells.str_alloc_mode() == mode
+    idx, slot = rng.permutation(len(texts)), rng.permutation(len(texts))
+    got = pycells.strings_from_views(ptr, lens, idx)
+    assert got.tolist() == [texts[k] for k in idx.tolist()]
+    got2 = pycells.strings_from_views(ptr, lens, None, slot=slot)
+    want = [None] * len(texts)
+    for i, k in enumerate(slot.tolist()):
+        want[k] = texts[i]
+    assert got2.tolist() == want
+    got3 = pycells.strings_from_views(ptr, lens, idx, slot=slot)
+    want3 = [None] * len(texts)
+    for i, k in enumerate(slot.tolist()):
+        want3[k] = texts[idx[i]]
+    assert got3.tolist() == want3
+    # they behave like the strings CPython makes: hash, size, concatenation (in-place resize when unshared), pickling, dict keys
+    for k in (0, 11, 22, 5, 102, len(texts) - 1):
+        s, t = got2[slot[k]], texts[k]
+        assert type(s) is str and s == t and hash(s) == hash(t) and sys.getsizeof(s) == sys.getsizeof(t)
+        assert s.encode("utf-8") == raw[k] and pickle.loads(pickle.dumps(s)) == t and s.isascii() == t.isascii()
+    grown = pycells.strings_from_views(ptr, lens, np.array([0, 11, 22] * 30000, np.int64))
+    acc = grown[1]
+    grown = None
+    acc += "tail"                                                     # refcount 1: unicode_resize -> PyObject_Realloc of our block
+    assert acc == texts[11] + "tail"
+    d = {s: i for i, s in enumerate(got.tolist()[:5000])}
+    assert all(d[texts[idx[i]]] >= 0 for i in range(0, 5000, 37))
+    ascii_ix = np.flatnonzero(np.array([t.isascii() for t in texts]))
+    got4 = pycells.strings_from_views(ptr, lens, ascii_ix, all_ascii=True)
+    assert got4.tolist() == [texts[k] for k in ascii_ix.tolist()]
+    del got, got2, got3, got4, d, acc
+    gc.collect()
+
+
+@pytest.mark.parametrize("mode", ["raw", "python"])
+def test_strings_from_flat_buffers_with_missing_cells(mode, monkeypatch):
+    monkeypatch.setenv("DYD_STR_ALLOC", mode)
+    rng = np.random.default_rng(2)
+    texts = _texts(70_000, rng, big_every=3)
+    _, _, buf, off, _ = _views(texts)
+    na = (rng.random(len(texts)) < 0.1).astype(np.uint8)
+    got = pycells.strings(buf, off, na)
+    assert got.tolist() == [None if m else t for t, m in zip(texts, na.tolist())]
+    assert pycells.strings(buf, off).tolist() == texts
+
+
+def test_many_rounds_of_worker_allocated_strings_leave_nothing_behind(monkeypatch):
+    monkeypatch.setenv("DYD_STR_ALLOC", "raw")
+    texts = ["x" * 600 + str(i) for i in range(20_000)]
+    ptr, lens, keep, _, _ = _views(texts)
+    idx = np.tile(np.arange(len(texts), dtype=np.int64), 4)
+    plain = np.array(["y" * 600 + str(i) for i in range(10)], object)
+    for _ in range(5):
+        got = pycells.strings_from_views(ptr, lens, idx, all_ascii=True)
+        assert got[3] == texts[3] and got[-1] == texts[-1] and sys.getrefcount(got[7]) == sys.getrefcount(plain[7])
+        survivor = got[123]
+        del got
+        assert survivor == texts[123]
+        del survivor
+    gc.collect()
+
+
+def test_object_take_counts_every_reference_once():
+    rng = np.random.default_rng(3)
+    vals = np.array([f"s{i}" for i in range(50_000)] + [None, 1.5, ("t",)], object)
+    row = np.sort(rng.integers(0, len(vals), 400_000))
+    slot = rng.permutation(len(row))
+    before = [sys.getrefcount(vals[k]) for k in (5, 49_999, len(vals) - 1)]
+    none_before = sys.getrefcount(None)
+    a = pycells.take(vals, row)
+    b = pycells.take(vals, row, slot=slot)
+    want = vals[row]
+    want_b = np.empty(len(row), object)
+    want_b[slot] = want
+    same = all(x is y for x, y in zip(a, want)) and all(x is y for x, y in zip(b, want_b))
+    assert same
+    for k, r0 in zip((5, 49_999, len(vals) - 1), before):
+        delta = sys.getrefcount(vals[k]) - r0
+        assert delta == 4 * int((row == k).sum())       # a, b, want, want_b
+    del a, b, want, want_b
+    gc.collect()
+    assert [sys.getrefcount(vals[k]) for k in (5, 49_999, len(vals) - 1)] == before
+    assert abs(sys.getrefcount(None) - none_before) < 50
+    with pytest.raises(IndexError):
+        pycells.take(vals, np.full(70_000, len(vals), np.int64))
+
+
+def test_small_table_take_and_numeric_take_and_slots():
+    rng = np.random.default_rng(4)
+    table = np.array([f"lab{i}" for i in range(20)] + [None], object)
+    codes = rng.integers(0, len(table), 300_000).astype(np.int32)
+    idx, slot = rng.permutation(len(codes)), rng.permutation(len(codes))
+    r0 = sys.getrefcount(table[3])
+    a = pycells.take_small(table, codes, idx, slot=slot)
+    want = np.empty(len(codes), object)
+    want[slot] = table[codes[idx]]
+    same = all(x is y for x, y in zip(a, want))
+    delta = sys.getrefcount(table[3]) - r0
+    assert same and delta == 2 * int((codes == 3).sum())
+    del a, want
+    delta = sys.getrefcount(table[3]) - r0
+    assert delta == 0
+    with pytest.raises(IndexError):
+        pycells.take_small(table, np.full(70_000, 99, np.int32))
+    for dtype in (np.float64, np.int64, np.int32, np.uint8, np.bool_, np.float32, np.int16):
+        v = (rng.random(90_000) * 100).astype(dtype)
+        i2 = rng.integers(0, len(v), 200_000)
+        s2 = rng.permutation(len(i2))
+        assert np.array_equal(pycells.take(v, i2), v[i2])
+        w = np.empty(len(i2), dtype)
+        w[s2] = v[i2]
+        assert np.array_equal(pycells.take(v, i2, slot=s2), w)
+    cat = rng.integers(0, 3, 250_000).astype(np.int32)
+    sizes = np.bincount(cat, minlength=3)
+    off = np.zeros(4, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    pos = np.empty(len(cat), np.int64)
+    for c in range(3):
+        m = np.flatnonzero(cat == c)
+        pos[m] = rng.permutation(len(m))
+    slots = pycells.category_slots(cat, pos, off)
+    assert np.array_equal(slots, off[cat] + pos) and np.array_equal(np.sort(slots), np.arange(len(cat)))
+
+
+def test_gathered_text_for_arrow_columns():
+    rng = np.random.default_rng(5)
+    texts = _texts(80_000, rng)
+    ptr, lens, keep, _, raw = _views(texts)
+    idx, slot = rng.permutation(len(texts)), rng.permutation(len(texts))
+    data, off = pycells.gather_text(ptr, lens, idx)
+    assert bytes(data) == b"".join(raw[k] for k in idx.tolist()) and off[-1] == len(data)
+    data, off = pycells.gather_text(ptr, lens, None, slot=slot)
+    order = np.empty(len(texts), np.int64)
+    order[slot] = np.arange(len(texts))
+    assert bytes(data) == b"".join(raw[k] for k in order.tolist())
+    assert np.array_equal(np.diff(off), lens[order])
