@@ -200,7 +200,6 @@ static PyObject *gather_utf8(PyObject *self, PyObject *args) {
  * so the caller can walk the records in ROW order (idx absent or non-decreasing: sequential reads, the same source object
  * many times in a row) and scatter eight bytes to the shuffled place, instead of gathering from random places.
  * ===================================================================================================================== */
-#include <dlfcn.h>
 #include <stdlib.h>
 
 #define MAXT 64
@@ -235,59 +234,6 @@ static void run_workers(worker_fn fn, void *blocks, size_t stride, int count) {
     }
 }
 
-/* ---- large str objects allocated by worker threads ---------------------------------------------------------------------
- * PyUnicode_New needs the GIL, so creating N str objects is one thread's work however many cores fill them.  CPython's object
- * allocator hands every request above 512 bytes to the raw allocator (malloc) and its free() sends every block that does not
- * lie in one of its own arenas back there (Objects/obmalloc.c: pymalloc_free -> address_in_range fails -> PyMem_RawFree), so
- * for a LARGE str — the 2 KB bbox text of a row — PyUnicode_New is malloc + a header, and malloc is thread-safe and needs no
- * GIL: the workers allocate, initialise (the compact-ASCII header PyUnicode_New writes) and fill those strings themselves, and
- * they are released exactly as before.  Small strings (the split step's 160-byte records) stay with the calling thread and
- * pymalloc: measured on the GPU box's host, 14 M of them from malloc on 16 threads are created in 0.6 s instead of 0.9 — and
- * then take 3.5 s to free instead of 1.0 (glibc coalesces each one under the owning arena's lock).
- * Used only when the interpreter runs its stock allocators ("pymalloc" or "malloc": no debug hooks — they prefix every block —
- * and no tracemalloc / custom hooks, whose name is NULL), on a release build of CPython 3.8 .. 3.12, and not when
- * DYD_STR_ALLOC=python; otherwise every string is allocated by the calling thread. */
-#define RAW_MIN_TEXT 464         /* sizeof(PyASCIIObject) + text + NUL > 512: beyond pymalloc's small-object threshold */
-static int raw_alloc_allowed(void) {
-#if defined(Py_TRACE_REFS) || defined(Py_REF_DEBUG) || defined(Py_GIL_DISABLED) || PY_VERSION_HEX < 0x03080000 || PY_VERSION_HEX >= 0x030D0000
-    return 0;
-#else
-    const char *e = getenv("DYD_STR_ALLOC");
-    if (e && strcmp(e, "python") == 0) return 0;
-    typedef const char *(*name_fn)(void);
-    static name_fn get_name = NULL;
-    static int looked = 0;
-    if (!looked) {
-        get_name = (name_fn)dlsym(RTLD_DEFAULT, "_PyMem_GetCurrentAllocatorName");
-        looked = 1;
-    }
-    if (!get_name) return 0;
-    const char *name = get_name();                 /* asked on every call: hooks can be installed at any time */
-    return name != NULL && (strcmp(name, "pymalloc") == 0 || strcmp(name, "malloc") == 0);
-#endif
-}
-
-static inline PyObject *raw_ascii_str(const char *text, Py_ssize_t size) {
-    PyASCIIObject *u = (PyASCIIObject *)PyMem_RawMalloc(sizeof(PyASCIIObject) + (size_t)size + 1);
-    if (!u) return NULL;
-    u->ob_base.ob_refcnt = 1;
-    u->ob_base.ob_type = &PyUnicode_Type;          /* a static type: instances hold no reference to it */
-    u->length = size;
-    u->hash = -1;
-    memset(&u->state, 0, sizeof(u->state));
-    u->state.kind = PyUnicode_1BYTE_KIND;
-    u->state.compact = 1;
-    u->state.ascii = 1;
-#if PY_VERSION_HEX < 0x030C0000
-    u->state.ready = 1;
-    u->wstr = NULL;
-#endif
-    char *data = (char *)(u + 1);
-    memcpy(data, text, (size_t)size);
-    data[size] = 0;
-    return (PyObject *)u;
-}
-
 static inline int text_is_ascii(const unsigned char *s, int64_t n) {
     uint64_t acc = 0;
     int64_t j = 0;
@@ -302,7 +248,14 @@ static inline int text_is_ascii(const unsigned char *s, int64_t n) {
 
 /* The str builder.  Text k is given either as a view (ptr[k], len[k]) or as base[off[k] .. off[k+1]); element i of the walk
  * takes text k = idx[i] (idx absent: k = i) and its str goes to objs[slot[i]] (slot absent: i); na[i] != 0 skips the element
- * (its slot keeps what it holds).  The output slots must be fresh (NULL / None). */
+ * (its slot keeps what it holds).  The output slots must be fresh (NULL / None).
+ * PyUnicode_New needs the GIL, so allocating N str objects is one thread's work (55-60 ns each: for the 14 M records of a
+ * 1 M-row table it IS the step) — everything else runs beside it: the calling thread allocates element after element, in walk
+ * order, into a sequential array and publishes how far it got; the workers, chunk by chunk behind it, copy the text in and put
+ * the object at its (scattered) place.  Non-ASCII texts are decoded by the calling thread.
+ * (Tried and dropped: letting the workers allocate from malloc — CPython's free() accepts such blocks — creates 14 M small
+ * strings in 0.6 s instead of 0.9 but frees them in 3.5 s instead of 1.0, and for 2 KB strings sixteen threads growing sixteen
+ * malloc arenas at once were four times SLOWER than the one thread, on the GPU box's host.) */
 #define VCHUNK 16384
 typedef struct {
     const char *const *ptr;
@@ -311,14 +264,14 @@ typedef struct {
     const int64_t *off;
     const int64_t *idx, *slot;
     const uint8_t *na;
-    PyObject **objs;
+    PyObject **objs;             /* the output array */
+    PyObject **seq;              /* element i's object, in walk order (== objs when there is no slot) */
     uint8_t *ascii;              /* per i: 1 = ASCII text (NULL: all are) */
     int64_t n;
     int64_t next_chunk;          /* atomic: next chunk a worker takes */
-    int64_t ready;               /* atomic: elements [0, ready) are allocated (python mode) */
-    int mode;                    /* 0 classify, 1 create / fill */
-    int raw;                     /* large strings are allocated by the workers */
-    int abort_fill, oom;
+    int64_t ready;               /* atomic: elements [0, ready) are allocated */
+    int mode;                    /* 0 classify, 1 fill + place */
+    int abort_fill;
 } vshared_t;
 
 static inline const unsigned char *vtext(const vshared_t *w, int64_t i, int64_t *n) {
@@ -335,7 +288,12 @@ static void *vworker(void *arg) {
         const int64_t c = __atomic_fetch_add(&w->next_chunk, 1, __ATOMIC_RELAXED);
         if (c >= n_chunks) break;
         const int64_t lo = c * VCHUNK, hi = (lo + VCHUNK < w->n) ? lo + VCHUNK : w->n;
-        int waited = 0;
+        if (w->mode == 1) {
+            while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {
+                if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;
+                sched_yield();
+            }
+        }
         for (int64_t i = lo; i < hi; ++i) {
             if (w->na && w->na[i]) continue;
             int64_t n;
@@ -344,21 +302,9 @@ static void *vworker(void *arg) {
                 w->ascii[i] = (uint8_t)text_is_ascii(s, n);
                 continue;
             }
-            if (w->ascii && !w->ascii[i]) continue;            /* decoded by the calling thread */
-            if (w->raw && n >= RAW_MIN_TEXT) {                 /* a large string: this thread's own */
-                PyObject *o = raw_ascii_str((const char *)s, (Py_ssize_t)n);
-                if (!o) { __atomic_store_n(&w->oom, 1, __ATOMIC_RELAXED); return NULL; }
-                w->objs[w->slot ? w->slot[i] : i] = o;
-                continue;
-            }
-            if (!waited) {                                     /* a small one: filled behind the allocating thread */
-                while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {
-                    if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;
-                    sched_yield();
-                }
-                waited = 1;
-            }
-            memcpy(PyUnicode_1BYTE_DATA(w->objs[w->slot ? w->slot[i] : i]), s, (size_t)n);
+            PyObject *o = w->seq[i];
+            if (!w->ascii || w->ascii[i]) memcpy(PyUnicode_1BYTE_DATA(o), s, (size_t)n);
+            if (w->slot) w->objs[w->slot[i]] = o;
         }
     }
     return NULL;
@@ -375,8 +321,8 @@ static void vrun_all(vshared_t *w, int n_threads, int mode) {   /* without the G
     for (int t = 0; t < k; ++t) pthread_join(th[t], NULL);
 }
 
-/* w: the texts, idx / slot / na, objs and n filled in.  Returns 0, or -1 with an exception set (what was created stays in the
- * array, which owns it; ASCII objects not yet filled hold garbage text). */
+/* w: the texts, idx / slot / na, objs and n filled in.  Returns 0, or -1 with an exception set (nothing is left in the array
+ * then). */
 static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     const int64_t n = w->n;
     if (n == 0) return 0;
@@ -389,16 +335,19 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
         *q = NULL;
         Py_DECREF(Py_None);
     }
+    w->seq = w->objs;
+    if (w->slot) {
+        w->seq = (PyObject **)PyMem_RawMalloc((size_t)n * sizeof(PyObject *));
+        if (!w->seq) { PyErr_NoMemory(); return -1; }
+    }
     if (!all_ascii) {
         w->ascii = (uint8_t *)PyMem_RawMalloc((size_t)n);
-        if (!w->ascii) { PyErr_NoMemory(); return -1; }
+        if (!w->ascii) { if (w->slot) PyMem_RawFree(w->seq); PyErr_NoMemory(); return -1; }
         Py_BEGIN_ALLOW_THREADS
         vrun_all(w, n_threads, 0);
         Py_END_ALLOW_THREADS
     }
-    /* this thread allocates the small strings (and decodes the non-ASCII ones) with the GIL and publishes how far it got; the
-     * workers fill them behind it and create the large ones on their own */
-    w->raw = raw_alloc_allowed();
+    int64_t made = 0;
     int failed = 0;
     pthread_t th[MAXT];
     int fillers = 0;
@@ -410,14 +359,13 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
         if (!(w->na && w->na[i])) {
             int64_t k;
             const unsigned char *s = vtext(w, i, &k);
-            const int is_ascii = !w->ascii || w->ascii[i];
-            if (!(is_ascii && w->raw && k >= RAW_MIN_TEXT)) {
-                PyObject *o = is_ascii ? PyUnicode_New((Py_ssize_t)k, 127) : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
-                if (!o) { failed = 2; break; }
-                w->objs[w->slot ? w->slot[i] : i] = o;
-            }
+            PyObject *o = (!w->ascii || w->ascii[i]) ? PyUnicode_New((Py_ssize_t)k, 127)
+                                                     : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
+            if (!o) { failed = 1; break; }
+            w->seq[i] = o;
         }
-        if (((i + 1) & (VCHUNK - 1)) == 0) __atomic_store_n(&w->ready, i + 1, __ATOMIC_RELEASE);
+        made = i + 1;
+        if ((made & (VCHUNK - 1)) == 0) __atomic_store_n(&w->ready, made, __ATOMIC_RELEASE);
     }
     if (failed) __atomic_store_n(&w->abort_fill, 1, __ATOMIC_RELAXED);
     else __atomic_store_n(&w->ready, n, __ATOMIC_RELEASE);
@@ -425,9 +373,15 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     if (!failed) vworker(w);                       /* help with what is left */
     for (int t = 0; t < fillers; ++t) pthread_join(th[t], NULL);
     Py_END_ALLOW_THREADS
-    if (w->oom) failed = 1;
+    if (failed) {                                  /* hand everything back: the array is as fresh as it came */
+        for (int64_t i = 0; i < made; ++i) {
+            if (w->na && w->na[i]) continue;
+            w->objs[w->slot ? w->slot[i] : i] = NULL;
+            Py_DECREF(w->seq[i]);
+        }
+    }
+    if (w->slot) PyMem_RawFree(w->seq);
     if (w->ascii) { PyMem_RawFree(w->ascii); w->ascii = NULL; }
-    if (failed == 1) PyErr_NoMemory();
     return failed ? -1 : 0;
 }
 
@@ -717,10 +671,6 @@ static PyObject *map_text(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
-static PyObject *str_alloc_mode(PyObject *self, PyObject *args) {
-    return PyUnicode_FromString(raw_alloc_allowed() ? "raw" : "python");
-}
-
 static PyMethodDef methods[] = {
     {"all_exact_str", all_exact_str, METH_VARARGS, "is every element of an object array an exact str"},
     {"gather_utf8", gather_utf8, METH_VARARGS, "copy (pointer, length) views into one flat buffer at given offsets"},
@@ -733,7 +683,6 @@ static PyMethodDef methods[] = {
     {"map_text", map_text, METH_VARARGS, "texts given as views -> one contiguous buffer at given offsets"},
     {"category_slots", category_slots, METH_VARARGS, "out[e] = cat_off[cat[e]] + pos[e]"},
     {"set_min_parallel", set_min_parallel, METH_VARARGS, "tests: element count from which the builders use their threads (-1 = defaults)"},
-    {"str_alloc_mode", str_alloc_mode, METH_NOARGS, "'raw' when large str objects are allocated by worker threads, else 'python'"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_dydpy", "pandas object column <-> flat UTF-8 buffers", -1, methods};

@@ -103,13 +103,6 @@ def _addr(a) -> int:
 # says the index arrays were made by this package and need no range check.
 
 
-def str_alloc_mode() -> str:
-    """"raw": LARGE str objects (beyond pymalloc's 512-byte threshold) are allocated by the worker threads themselves
-    (csrc/pyhelpers.c, "large str objects allocated by worker threads"); "python": every str by the calling thread through
-    PyUnicode_New (debug / traced / custom allocators, DYD_STR_ALLOC=python, or no extension)"""
-    return _dydpy.str_alloc_mode() if available() else "python"
-
-
 def strings_from_views(ptr: np.ndarray, length: np.ndarray, idx=None, n_threads: int = 0, all_ascii: bool = False, slot=None,
                        checked: bool = False) -> np.ndarray:
     """object array of str from one (address, length) view per text: out[slot[i]] = text idx[i] — the split step's records,

@@ -112,3 +112,92 @@ def random_boxes(rng, n_rows, max_boxes=32, special=True, fixed=None):
         k = rng.integers(0, B, size=max(1, B // 150))
         box[k] = box[k][:, [0, 1, 0, 1]]                                 # zero-area boxes
     return box, off
+
+
+def split_expected_tablewise(df, label_to_category, json_columns=None, train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, random_seed=42):
+    """What oracle.steps.split_frames returns, assembled table-wise: the same per-row walk over the oracle's own primitives
+    (parse_objects, split_object_labels: processor.py:712-792) collects INDICES instead of ``row.copy()`` per record — the
+    copies are what make the port walk 150 rows a second — and the frames come from one ``take`` per table; the shuffle is
+    pandas' own ``sample(frac=1, random_state=seed)`` (:800).  tests/test_split_cpu.py pins this against split_frames itself."""
+    import copy
+    import json
+
+    from oracle import steps as osteps
+
+    s = train_ratio + val_ratio + test_ratio
+    train_ratio, val_ratio = train_ratio / s, val_ratio / s
+    if json_columns is None:
+        json_columns = [c for c in (osteps.NEW_COL, osteps.ANN_COL) if c in df.columns]
+    present = [c for c in json_columns if c in df.columns]
+    cols = {c: df[c].tolist() for c in present}
+    sources = df["source"].tolist() if "source" in df.columns else [None] * len(df)
+    rec = {"src": [], "label": [], "cat": [], "text": [], "combo": []}
+    unc = {"src": [], "why": [], "label": []}
+    counts = []
+    for ri in range(len(df)):
+        cell = None
+        for c in present:
+            v = cols[c][ri]
+            if isinstance(v, str) and v:
+                cell = v
+                break
+        doc, objs, err = osteps.parse_objects(cell)
+        if err or not objs:
+            why = err or "标注字段objects为空"
+            unc["src"].append(ri); unc["why"].append(why); unc["label"].append(None)
+            counts.append((sources[ri], "", 0, "否", why))
+            continue
+        seen = set()
+        for o in objs:
+            if isinstance(o, dict) and o.get("name"):
+                seen.update(osteps.split_object_labels(o.get("name")))
+        combo = "，".join(sorted(seen)) if seen else ""
+        n_out, reasons = 0, set()
+        for o in objs:
+            if not isinstance(o, dict):
+                continue
+            labs = osteps.split_object_labels(o.get("name"))
+            if not labs:
+                unc["src"].append(ri); unc["why"].append("标注框缺少name字段"); unc["label"].append(None)
+                continue
+            for lab in labs:
+                if lab not in label_to_category:
+                    unc["src"].append(ri); unc["why"].append(f"标签{lab}未在规则中定义"); unc["label"].append(lab)
+                    reasons.add(f"标签{lab}未在规则中定义")
+                    continue
+                one = copy.deepcopy(o)
+                one["name"] = lab
+                slim = {k: v for k, v in doc.items() if k != "objects"}
+                slim["objects"] = [one]
+                rec["src"].append(ri); rec["label"].append(lab); rec["cat"].append(label_to_category[lab])
+                rec["text"].append(json.dumps(slim, ensure_ascii=False)); rec["combo"].append(combo)
+                n_out += 1
+        if not n_out:
+            unc["src"].append(ri); unc["label"].append(None)
+            unc["why"].append("；".join(sorted(reasons)) if reasons else "标签无法匹配规则")
+        counts.append((sources[ri], combo, n_out, "否" if not n_out else ("部分可分类" if reasons else "是"), "；".join(sorted(reasons))))
+    src = np.asarray(rec["src"], np.int64)
+    cat = np.asarray(rec["cat"], object)
+    out, cat_counts = {}, {}
+    for name in pd.unique(cat) if len(cat) else []:
+        m = np.flatnonzero(cat == name)
+        f = df.iloc[src[m]].copy()
+        text = pd.Series([rec["text"][k] for k in m.tolist()], index=f.index, dtype=object)
+        for c in present:
+            f[c] = text
+        f["分类标签"] = [rec["label"][k] for k in m.tolist()]
+        f["分类类别"] = name
+        f["原始标签组合"] = [rec["combo"][k] for k in m.tolist()]
+        f = f.sample(frac=1, random_state=random_seed).reset_index(drop=True)
+        a, b = int(len(f) * train_ratio), int(len(f) * val_ratio)
+        out[name] = (f.iloc[:a], f.iloc[a:a + b], f.iloc[a + b:])
+        cat_counts[name] = len(f)
+    if unc["src"]:
+        u = df.iloc[np.asarray(unc["src"], np.int64)].copy()
+        u["无法分类原因"] = unc["why"]
+        if any(v is not None for v in unc["label"]):
+            u["无法分类标签"] = [np.nan if v is None else v for v in unc["label"]]
+    else:
+        u = pd.DataFrame()
+    c = pd.DataFrame(counts, columns=["source", "原始标签组合", "拆分条数", "是否可分类", "无法分类原因"]) if counts else pd.DataFrame()
+    return {"categories": out, "unclassified": u, "split_counts": c, "category_counts": cat_counts}

@@ -1,0 +1,61 @@
+"""configs[2] through the product's own API at 100 k rows: the five step functions in sequence on one table, as the processing
+page runs them (reference ui/pages/processing.py:545-630), every frame of every step against the CPU port."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from deal_yolo_daya_amd import synth
+from deal_yolo_daya_amd.core import processor as P
+from helpers import split_expected_tablewise
+from oracle import steps as osteps
+
+pytestmark = pytest.mark.gpu
+ROWS = 100_000
+
+
+@pytest.fixture(scope="module")
+def table():
+    t = synth.generate(ROWS, seed=31)
+    df = synth.to_frame(t)
+    ids = np.random.default_rng(8).integers(0, int(0.9 * ROWS) + 1, ROWS)
+    df["source"] = [f"http://img.example/{k}.jpg" for k in ids.tolist()]
+    return df, pd.DataFrame({"source": synth.reference_urls(ROWS)})
+
+
+def test_the_five_steps_in_sequence_match_the_cpu_port_at_100k_rows(native, table):
+    df, ref = table
+    dd = P.dedup_frame(df)
+    pd.testing.assert_frame_equal(dd, osteps.dedup_frame(df))
+    ff = P.ref_filter_frame(dd, ref)
+    pd.testing.assert_frame_equal(ff, osteps.ref_filter_frame(dd, ref))
+    assert 0.5 * ROWS < len(ff) < len(dd) < ROWS
+    kept, excluded, high, other = P.replace_and_filter_frame(ff, 2, 0.98, stats=(rs := {}))
+    assert rs["python_cells"] == 0 and rs["fused_launches"] >= 1
+    okept, oproj, oexc = osteps.replace_frame(ff)
+    ohigh, oother = osteps.iou_filter_frame(oproj, 2, 0.98)
+    pd.testing.assert_frame_equal(kept, oproj)
+    assert len(excluded) == len(oexc) == 0 and len(high) > 500
+    pd.testing.assert_frame_equal(high, ohigh.astype(high.dtypes.to_dict()))
+    pd.testing.assert_frame_equal(other, oother.astype(other.dtypes.to_dict()))
+    rules = synth.rules()
+    got = P.split_frames(other, rules, stats=(ss := {}))
+    assert ss["records"] > 600_000 and ss["fast_cells"] == len(other)
+    exp = split_expected_tablewise(other, rules)
+    assert list(got["categories"]) == list(exp["categories"]) and set(exp["categories"]) == {"catA", "catB"}
+    for cat in exp["categories"]:
+        for a, b in zip(got["categories"][cat], exp["categories"][cat]):
+            assert a.equals(b)
+    assert got["unclassified"].equals(exp["unclassified"]) and got["split_counts"].equals(exp["split_counts"])
+    assert got["category_counts"] == exp["category_counts"]
+    # the Arrow-backed text columns carry the same text
+    arrow = P.split_frames(other, rules, text_dtype="arrow")
+    for cat in exp["categories"]:
+        for a, b in zip(arrow["categories"][cat], exp["categories"][cat]):
+            assert a[P.BBOX_COL].tolist() == b[P.BBOX_COL].tolist() and a["source"].tolist() == b["source"].tolist()
+    # the first 3000 rows through the port itself (row.copy() per record: 150 rows a second)
+    head = other.iloc[:3000]
+    got_h, exp_h = P.split_frames(head, rules, random_seed=7), osteps.split_frames(head, rules, random_seed=7)
+    for cat in exp_h["categories"]:
+        for a, b in zip(got_h["categories"][cat], exp_h["categories"][cat]):
+            assert a.equals(b)
+    assert got_h["unclassified"].equals(exp_h["unclassified"]) and got_h["split_counts"].equals(exp_h["split_counts"])

@@ -102,3 +102,17 @@ def test_split_frames_keeps_other_columns_dtypes_and_row_labels(oracle_backend):
     assert frame["score"].dtype == np.float64 and frame["flag"].dtype == bool and list(frame.columns) == list(exp["categories"]["catA"][0].columns)
     first = json.loads(frame[P.BBOX_COL].iloc[0])
     assert len(first["objects"]) == 1 and first["objects"][0]["name"] == frame["分类标签"].iloc[0]
+
+
+def test_the_tablewise_checker_is_the_cpu_port(oracle_backend):
+    """tests/helpers.split_expected_tablewise (used by the GPU suite at 100 k rows, where the port itself would run for minutes)
+    gives exactly what oracle.steps.split_frames gives"""
+    from helpers import split_expected_tablewise
+    table = _table(400, 15, oracle_backend).reset_index(drop=True)
+    cells = table[P.BBOX_COL].tolist()
+    for k, odd in zip(range(0, 400, 23), ['{"objects": [{"name": 7}]}', "", None, '{"objects": []}', '[1]', '{"objects": [{"nam": 1}, {"name": "c1，c99"}]}'] * 3):
+        cells[k] = odd
+    table[P.BBOX_COL] = pd.Series(cells, dtype=object)
+    rules = synth.rules()
+    _same_frames(split_expected_tablewise(table, rules), osteps.split_frames(table, rules))
+    _same_frames(split_expected_tablewise(table, rules, None, 6, 3, 1, 7), osteps.split_frames(table, rules, None, 6, 3, 1, random_seed=7))
