@@ -62,6 +62,11 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p]),
     "dyd_bbox_iou_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "dyd_host_pool_trim": (None, []),
+    "dyd_stage_acquire": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "dyd_stage_release": (None, [C.c_void_p]),
+    "dyd_bbox_iou_fused_staged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_bbox_iou_fused_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dyd_hash128": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -40,6 +40,28 @@ struct Context {
     int bigq_turn = 0;
 };
 
+// A staging slot: everything one host-pointer pass needs to reach the device and come back without creating or destroying
+// anything — its own stream and two timing events, a device arena and a pinned host arena, all kept by the context between
+// calls (round 2's host entries made a stream, two events and six hipMalloc'ed buffers per call and hipFree'd them on return:
+// hipFree waits for the whole device, so thirty-two threads staging "side by side" took turns).  Slots are handed out under
+// their own mutex, never under api_mutex.
+struct StageSlot {
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void *dev = nullptr;
+    size_t dev_cap = 0;
+    void *pin = nullptr;
+    size_t pin_cap = 0;
+    bool busy = false;
+};
+// a free slot (a new one while fewer than 64 exist, else the call waits), its pinned arena grown to `pin_bytes` if the
+// context's pinned budget allows (pin_cap tells); the calling thread is bound to the context's device
+int stage_acquire(size_t pin_bytes, StageSlot **out);
+// the slot's device arena grown to at least `bytes` (contents are not kept)
+int stage_device(StageSlot *slot, size_t bytes);
+void stage_release(StageSlot *slot);
+void stage_free_all();          // dyd_shutdown / rebinding; the caller holds api_mutex
+
 Context &ctx();
 std::recursive_mutex &api_mutex();
 void set_error(const char *fmt, ...);

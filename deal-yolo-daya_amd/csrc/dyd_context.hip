@@ -1,6 +1,11 @@
 // dyd_context.hip — context, error state, device memory and the host-side MT19937
 // permutation of libdyd_gfx950.so (C ABI: include/dyd.h).
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <vector>
 
 #include "dyd_common.h"
 
@@ -25,6 +30,144 @@ void set_error(const char *fmt, ...) {
 }
 void set_last_kernel_ms(double ms) { g_last_ms = ms; }
 
+// ---- staging slots ------------------------------------------------------------------------------------------------------
+namespace {
+struct StagePool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<StageSlot>> slots;
+    size_t pinned_total = 0;
+};
+StagePool &stage_pool() {
+    static StagePool p;
+    return p;
+}
+size_t pinned_budget() {          // bytes of pinned host memory all slots together may hold (DYD_PINNED_POOL_MB, default 1024)
+    static size_t cached = 0;
+    if (!cached) {
+        size_t mb = 1024;
+        if (const char *e = getenv("DYD_PINNED_POOL_MB")) { const long v = atol(e); if (v >= 0) mb = (size_t)v; }
+        cached = (mb << 20) + 1;
+    }
+    return cached - 1;
+}
+constexpr size_t kMaxSlots = 64;
+}  // namespace
+
+int stage_acquire(size_t pin_bytes, StageSlot **out) {
+    {
+        std::lock_guard<std::recursive_mutex> lock(api_mutex());
+        const int rc = ensure_init();
+        if (rc != DYD_OK) return rc;
+    }
+    StagePool &P = stage_pool();
+    StageSlot *slot = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(P.m);
+        for (;;) {
+            // the free slot whose pinned arena fits best (smallest sufficient, else the largest there is)
+            StageSlot *best = nullptr;
+            for (auto &q : P.slots) {
+                if (q->busy) continue;
+                if (!best) { best = q.get(); continue; }
+                const bool qf = q->pin_cap >= pin_bytes, bf = best->pin_cap >= pin_bytes;
+                if ((qf && !bf) || (qf && bf && q->pin_cap < best->pin_cap) || (!qf && !bf && q->pin_cap > best->pin_cap)) best = q.get();
+            }
+            if (best) { slot = best; break; }
+            if (P.slots.size() < kMaxSlots) {
+                P.slots.emplace_back(new StageSlot());
+                slot = P.slots.back().get();
+                break;
+            }
+            P.cv.wait(lk);
+        }
+        slot->busy = true;
+    }
+    auto fail = [&](int rc) {
+        stage_release(slot);
+        return rc;
+    };
+    if (!slot->s) {
+        if (hipStreamCreateWithFlags(&slot->s, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&slot->e0) != hipSuccess ||
+            hipEventCreate(&slot->e1) != hipSuccess) {
+            set_error("staging slot: stream / event creation failed");
+            return fail(DYD_ERR_HIP);
+        }
+    }
+    if (pin_bytes > slot->pin_cap) {
+        const size_t want = pin_bytes + (pin_bytes >> 3);
+        bool allowed;
+        {
+            std::lock_guard<std::mutex> lk(P.m);
+            allowed = P.pinned_total - slot->pin_cap + want <= pinned_budget();
+            if (allowed) P.pinned_total += want - slot->pin_cap;
+        }
+        if (allowed) {
+            if (slot->pin) (void)hipHostFree(slot->pin);
+            slot->pin = nullptr;
+            const size_t old_cap = slot->pin_cap;
+            slot->pin_cap = 0;
+            if (hipHostMalloc(&slot->pin, want, hipHostMallocDefault) == hipSuccess) {
+                slot->pin_cap = want;
+            } else {                                   // no pinned memory to be had: the caller stages from pageable memory
+                slot->pin = nullptr;
+                (void)hipGetLastError();
+                std::lock_guard<std::mutex> lk(P.m);
+                P.pinned_total -= want;
+                (void)old_cap;
+            }
+        }
+    }
+    *out = slot;
+    return DYD_OK;
+}
+
+int stage_device(StageSlot *slot, size_t bytes) {
+    if (bytes <= slot->dev_cap) return DYD_OK;
+    if (slot->dev) {
+        (void)hipStreamSynchronize(slot->s);
+        (void)hipFree(slot->dev);
+        slot->dev = nullptr;
+        slot->dev_cap = 0;
+    }
+    const size_t want = bytes + (bytes >> 2);
+    const hipError_t e = hipMalloc(&slot->dev, want);
+    if (e != hipSuccess) {
+        slot->dev = nullptr;
+        set_error("staging slot: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return DYD_ERR_OOM;
+    }
+    slot->dev_cap = want;
+    return DYD_OK;
+}
+
+void stage_release(StageSlot *slot) {
+    if (!slot) return;
+    StagePool &P = stage_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        slot->busy = false;
+    }
+    P.cv.notify_one();
+}
+
+void stage_free_all() {
+    StagePool &P = stage_pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    for (auto &q : P.slots) {
+        if (q->busy) continue;                         // a pass in flight keeps its slot; it is dropped with the next call
+        if (q->s) (void)hipStreamSynchronize(q->s);
+        if (q->dev) (void)hipFree(q->dev);
+        if (q->pin) (void)hipHostFree(q->pin);
+        if (q->e0) (void)hipEventDestroy(q->e0);
+        if (q->e1) (void)hipEventDestroy(q->e1);
+        if (q->s) (void)hipStreamDestroy(q->s);
+        P.pinned_total -= q->pin_cap;
+        *q = StageSlot();
+    }
+    P.slots.erase(std::remove_if(P.slots.begin(), P.slots.end(), [](const std::unique_ptr<StageSlot> &q) { return !q->busy; }), P.slots.end());
+}
+
 static int init_locked(int device) {
     Context &c = ctx();
     if (c.ready && (device < 0 || device == c.device)) return DYD_OK;
@@ -45,6 +188,7 @@ static int init_locked(int device) {
     }
     if (c.ready) {  // rebinding to another device: drop the old context first
         (void)hipSetDevice(c.device);
+        stage_free_all();
         if (c.scratch) (void)hipFree(c.scratch);
         if (c.dev_status) (void)hipFree(c.dev_status);
         if (c.bigq) (void)hipFree(c.bigq);
@@ -152,6 +296,7 @@ void dyd_shutdown(void) {
     if (!c.ready) return;
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
+    stage_free_all();
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.dev_status) (void)hipFree(c.dev_status);
     if (c.bigq) (void)hipFree(c.bigq);

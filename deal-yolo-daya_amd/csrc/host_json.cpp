@@ -28,6 +28,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1012,6 +1013,7 @@ struct dyd_scan {
     std::vector<uint8_t> high;
     int64_t tot_boxes = 0, tot_points = 0;
     double t_scan = 0, t_device = 0, t_emit = 0;
+    ~dyd_scan();                        // parks the parts' text blocks in the host pool
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -1043,6 +1045,65 @@ inline bool use_fast_lane() {
     return !(env && env[0] == '0');
 }
 
+// Blocks of emitted text outlive the pass that wrote them (the caller builds str objects from them) and are then 2 GB of
+// page tables to tear down (0.17 s per million rows, "release") and as many first-touch faults for the next pass to take again:
+// a freed handle parks them here instead, up to DYD_HOST_POOL_MB (default 3072) in total, and the next pass writes into warm
+// memory.  dyd_host_pool_trim() gives everything back.
+struct HostPool {
+    std::mutex m;
+    std::vector<std::pair<char *, size_t>> blocks;
+    size_t total = 0;
+    static size_t limit() {
+        static size_t cached = 0;
+        if (!cached) {
+            size_t mb = 3072;
+            if (const char *e = getenv("DYD_HOST_POOL_MB")) { const long v = atol(e); if (v >= 0) mb = (size_t)v; }
+            cached = (mb << 20) + 1;
+        }
+        return cached - 1;
+    }
+    // the smallest parked block of at least `need` bytes, else the largest one (the caller grows it), else nothing
+    char *take(size_t need, size_t *cap) {
+        std::lock_guard<std::mutex> lk(m);
+        int best = -1;
+        for (int i = 0; i < (int)blocks.size(); ++i) {
+            if (best < 0) { best = i; continue; }
+            const bool fi = blocks[(size_t)i].second >= need, fb = blocks[(size_t)best].second >= need;
+            if ((fi && !fb) || (fi && fb && blocks[(size_t)i].second < blocks[(size_t)best].second) ||
+                (!fi && !fb && blocks[(size_t)i].second > blocks[(size_t)best].second))
+                best = i;
+        }
+        if (best < 0) { *cap = 0; return nullptr; }
+        char *p = blocks[(size_t)best].first;
+        *cap = blocks[(size_t)best].second;
+        total -= *cap;
+        blocks.erase(blocks.begin() + best);
+        return p;
+    }
+    void give(char *p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (cap >= ((size_t)1 << 20) && total + cap <= limit() && blocks.size() < 256) {
+                blocks.emplace_back(p, cap);
+                total += cap;
+                return;
+            }
+        }
+        free(p);
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto &b : blocks) free(b.first);
+        blocks.clear();
+        total = 0;
+    }
+};
+HostPool &host_pool() {
+    static HostPool p;
+    return p;
+}
+
 // pass 1 over the part's cell range: fills A and the per-cell arrays of h
 void scan_part(dyd_scan *h, const CellSrc &src, const uint8_t *missing, FastPart &A, bool use_fast) {
     std::string tmp;
@@ -1050,6 +1111,7 @@ void scan_part(dyd_scan *h, const CellSrc &src, const uint8_t *missing, FastPart
     std::vector<int32_t> snp;
     const int64_t lo = A.lo, hi = A.hi;
     const size_t bytes = src.bytes(lo, hi);
+    A.seg_off.n = A.lane.n = A.cell_boxes.n = A.seg.n = A.xy.n = A.isint.n = A.npts.n = A.hole.n = 0;   // a part object serves chunk after chunk
     A.seg_off.need((size_t)(hi - lo) + 1);
     A.lane.need((size_t)(hi - lo));
     A.cell_boxes.need((size_t)(hi - lo));
@@ -1099,31 +1161,30 @@ void scan_part(dyd_scan *h, const CellSrc &src, const uint8_t *missing, FastPart
 }
 
 // pass 2 over the part: arg4 = K1's arg indices of the PART's boxes (local order); xy / pt_off as the part's views say
-// (A.xyv: the part's first point; A.ptv[b] - A.ptv_bias: first point of local box b).  false: arg4 does not fit the scan.
-bool emit_part(const dyd_scan *h, const CellSrc &src, FastPart &A, const int32_t *arg4) {
+// (A.xyv: the part's first point; A.ptv[b] - A.ptv_bias: first point of local box b).  The text is APPENDED to `out`, one length
+// per cell to `out_len`.  false: arg4 does not fit the scan.
+bool emit_part(const dyd_scan *h, const CellSrc &src, FastPart &A, const int32_t *arg4, Raw<char> &out, Raw<int64_t> &out_len) {
     std::string tmp, slow;
     bool good = true;
-    A.out.n = 0;
-    A.out_len.n = 0;
-    A.out_len.need((size_t)(A.hi - A.lo));
-    A.out.need(A.seg.n + A.seg.n / 2 + 64);
+    out_len.need((size_t)(A.hi - A.lo));
+    out.need(A.seg.n + A.seg.n / 2 + 64);
     size_t lb = 0;   // local box index
     for (int64_t i = A.lo; i < A.hi; ++i) {
-        const size_t mark = A.out.n;
+        const size_t mark = out.n;
         const size_t nb = (size_t)A.cell_boxes.p[i - A.lo];
-        if (h->status[(size_t)i] != CELL_OK) { A.out_len.push(0); lb += nb; continue; }
+        if (h->status[(size_t)i] != CELL_OK) { out_len.push(0); lb += nb; continue; }
         if (A.lane.p[i - A.lo]) {
             const char *sg = A.seg.p + A.seg_off.p[i - A.lo];
             const size_t sg_len = (size_t)(A.seg_off.p[i - A.lo + 1] - A.seg_off.p[i - A.lo]);
             size_t prev = 0;
             for (size_t b = lb; b < lb + nb; ++b) {
                 const size_t hb = A.hole.p[b];
-                A.out.put(sg + prev, hb - prev);
+                out.put(sg + prev, hb - prev);
                 prev = hb;
                 const size_t p0 = (size_t)(A.ptv[b] - A.ptv_bias), p1 = (size_t)(A.ptv[b + 1] - A.ptv_bias);
-                if (!fj_put_corners(A.out, A.xyv + 2 * p0, A.isint.p + p0, (int32_t)(p1 - p0), arg4 + 4 * b, tmp)) good = false;
+                if (!fj_put_corners(out, A.xyv + 2 * p0, A.isint.p + p0, (int32_t)(p1 - p0), arg4 + 4 * b, tmp)) good = false;
             }
-            A.out.put(sg + prev, sg_len - prev);
+            out.put(sg + prev, sg_len - prev);
         } else {
             slow.clear();
             CellSink sk;
@@ -1131,14 +1192,14 @@ bool emit_part(const dyd_scan *h, const CellSrc &src, FastPart &A, const int32_t
             sk.arg4 = arg4 + 4 * lb;
             try {
                 walk_cell(src.get(i), sk);
-                A.out.put(slow.data(), slow.size());
+                out.put(slow.data(), slow.size());
             } catch (Fail) {
-                A.out.n = mark;
+                out.n = mark;
                 good = false;
             }
         }
         lb += nb;
-        A.out_len.push((int64_t)(A.out.n - mark));
+        out_len.push((int64_t)(out.n - mark));
     }
     return good;
 }
@@ -1183,7 +1244,18 @@ void init_polygon_handle(dyd_scan *h, int64_t n_cells, int n_threads, const Cell
 
 }  // namespace
 
+dyd_scan::~dyd_scan() {
+    for (auto &pp : parts) {
+        if (!pp) continue;
+        size_t cap = 0;
+        char *blk = pp->out.disown(&cap);
+        host_pool().give(blk, cap);
+    }
+}
+
 extern "C" {
+
+void dyd_host_pool_trim(void) { host_pool().trim(); }
 
 // Scan annotation cells for the replace step (processor.py:262-281).  text/cell_off: concatenated UTF-8
 // cells; missing[i] != 0 marks a NaN cell.  The handle owns every output array.
@@ -1270,58 +1342,114 @@ int dyd_json_replace_iou(const uint8_t *text, const int64_t *cell_off, const uin
     const bool use_fast = use_fast_lane();
     int first_rc = DYD_OK;
     try {
-        // twice the CPU share's worth of parts: a part's thread sleeps through its copies and its launch (a fifth of its time), and under a
-        // cgroup quota idle time is not charged — tools/threads_ab.sh, 1 M rows on a 16-CPU slice: 12 / 16 / 24 / 32 threads 1.57 / 1.46 /
+        // twice the CPU share's worth of parts: a part's thread sleeps through its copies and its launches, and under a cgroup quota
+        // idle time is not charged — tools/threads_ab.sh, 1 M rows on a 16-CPU slice: 12 / 16 / 24 / 32 threads 1.57 / 1.46 /
         // 1.40 / 1.36 s for the whole DataFrame route.  An explicit count (argument or DYD_HOST_THREADS) is taken as given.
         if (n_threads <= 0 && !getenv("DYD_HOST_THREADS") && n_cells >= 65536) n_threads = std::min(64, 2 * default_threads());
         init_polygon_handle(h, n_cells, n_threads, src);
         h->pipelined = true;
         h->high.assign((size_t)n_cells, 0);
+        // A part's thread takes its cells through scan -> launch -> emit CHUNK by chunk (DYD_PIPE_CHUNK_KB of cell text, default 8192):
+        // the point / segment buffers of a chunk are reused by the next one and stay small, and the points are scanned straight into
+        // the pinned arena of the staging slot the thread holds for the whole pass (dyd_stage_acquire: stream, events, device arena
+        // kept by the context), so a chunk's way to the device is three DMA copies from memory that is already pinned, one fused
+        // launch and two copies back — nothing is created, allocated or freed per launch.
+        size_t chunk_bytes = (size_t)8 << 20;
+        if (const char *e = getenv("DYD_PIPE_CHUNK_KB")) { const long v = atol(e); if (v > 0) chunk_bytes = (size_t)v << 10; }
         std::vector<double> ts((size_t)h->parts.size() * 3, 0.0);
+        auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
         if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
                 FastPart &A = *h->parts[(size_t)k];
-                auto t0 = std::chrono::steady_clock::now();
-                scan_part(h, src, missing, A, use_fast);
-                const size_t nb = A.npts.n, ncell = (size_t)(A.hi - A.lo);
-                Raw<int32_t> pt_off, box_off, arg4;
-                pt_off.need(nb + 1);
-                box_off.need(ncell + 1);
-                int64_t run = 0;
-                pt_off.p[0] = 0;
-                for (size_t b = 0; b < nb; ++b) { run += A.npts.p[b]; pt_off.p[b + 1] = (int32_t)run; }
-                int64_t runb = 0;
-                box_off.p[0] = 0;
-                for (size_t c = 0; c < ncell; ++c) { runb += A.cell_boxes.p[c]; box_off.p[c + 1] = (int32_t)runb; }
-                arg4.need(4 * nb + 4);
-                auto t1 = std::chrono::steady_clock::now();
-                int rc = (run >= ((int64_t)1 << 31)) ? DYD_ERR_RANGE : DYD_OK;
-                if (!rc && ncell)
-                    rc = dyd_bbox_iou_fused(A.xy.p, pt_off.p, box_off.p, (int64_t)ncell, min_boxes, thr, nullptr, arg4.p,
-                                            h->high.data() + A.lo);
-                auto t2 = std::chrono::steady_clock::now();
-                if (rc) {
+                const size_t part_cells = (size_t)(A.hi - A.lo);
+                if (!part_cells) return;
+                auto fail = [&](int rc) {
                     int expected = DYD_OK;
                     __atomic_compare_exchange_n(&first_rc, &expected, rc, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
-                    return;
+                };
+                const size_t part_bytes = src.bytes(A.lo, A.hi);
+                {   // the part's output text: a warm block of an earlier pass if one is parked
+                    size_t cap = 0;
+                    if (char *blk = host_pool().take(part_bytes / 2 + 64, &cap)) A.out.own(blk, cap);
+                    A.out.need(part_bytes / 2 + 64);
+                    A.out_len.need(part_cells);
                 }
-                A.xyv = A.xy.p;
-                A.ptv = pt_off.p;
-                A.ptv_bias = 0;
-                if (!emit_part(h, src, A, arg4.p)) {
-                    int expected = DYD_OK;
-                    __atomic_compare_exchange_n(&first_rc, &expected, DYD_ERR_INVALID, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+                const size_t chunk_cap = std::min(chunk_bytes, part_bytes) + 4096;
+                dyd_stage *stage = nullptr;
+                void *pin = nullptr;
+                size_t pin_cap = 0;
+                {   // pinned: the points (scan_part reserves 2/3 of the text bytes) and, behind them, offsets / arg indices / flags
+                    const int rc = dyd_stage_acquire(chunk_cap - chunk_cap / 8, &stage, &pin, &pin_cap);
+                    if (rc) { fail(rc); return; }
                 }
-                A.box_base = nb;                 // totals are summed below
-                A.pt_base = (size_t)run;
-                A.xyv = nullptr; A.ptv = nullptr;
-                A.xy.clear_free(); A.isint.clear_free(); A.npts.clear_free(); A.hole.clear_free(); A.seg.clear_free();
-                A.seg_off.clear_free(); A.lane_count = 0;
-                for (size_t c = 0; c < A.lane.n; ++c) A.lane_count += A.lane.p[c];
-                A.lane.clear_free();
-                auto t3 = std::chrono::steady_clock::now();
-                ts[(size_t)k * 3 + 0] = std::chrono::duration<double>(t1 - t0).count();
-                ts[(size_t)k * 3 + 1] = std::chrono::duration<double>(t2 - t1).count();
-                ts[(size_t)k * 3 + 2] = std::chrono::duration<double>(t3 - t2).count();
+                FastPart C;                               // the chunk in work; its buffers serve chunk after chunk
+                Raw<int32_t> v_pt_off, v_box_off, v_arg4; // used when a chunk does not fit the pinned arena
+                Raw<uint8_t> v_high;
+                size_t tot_boxes = 0, tot_pts = 0;
+                int64_t lane_cells = 0;
+                double t_scan = 0, t_dev = 0, t_emit = 0;
+                int64_t c0 = A.lo;
+                while (c0 < A.hi && !__atomic_load_n(&first_rc, __ATOMIC_RELAXED)) {
+                    int64_t c1 = c0;
+                    size_t bytes = 0;
+                    while (c1 < A.hi && (c1 == c0 || bytes + src.bytes(c1, c1 + 1) <= chunk_bytes)) { bytes += src.bytes(c1, c1 + 1); ++c1; }
+                    C.lo = c0; C.hi = c1;
+                    const size_t ncell = (size_t)(c1 - c0);
+                    const size_t xy_room = bytes / 12 + 64 + 64;     // doubles scan_part asks for up front
+                    if (pin && 8 * xy_room + 4096 <= pin_cap) C.xy.adopt(static_cast<double *>(pin), (pin_cap - 4096) / 8);
+                    else C.xy.clear_free();
+                    auto t0 = std::chrono::steady_clock::now();
+                    scan_part(h, src, missing, C, use_fast);
+                    const size_t nb = C.npts.n;
+                    // where the small arrays live: behind the points in the pinned arena when they fit
+                    int32_t *pt_off, *box_off, *arg4;
+                    uint8_t *high;
+                    const size_t o_po = up256(8 * C.xy.n), o_bo = o_po + up256(4 * (nb + 1)), o_arg = o_bo + up256(4 * (ncell + 1)),
+                                 o_high = o_arg + up256(16 * nb + 16), o_end = o_high + up256(ncell);
+                    if (C.xy.lent && o_end <= pin_cap) {
+                        char *base = static_cast<char *>(pin);
+                        pt_off = reinterpret_cast<int32_t *>(base + o_po);
+                        box_off = reinterpret_cast<int32_t *>(base + o_bo);
+                        arg4 = reinterpret_cast<int32_t *>(base + o_arg);
+                        high = reinterpret_cast<uint8_t *>(base + o_high);
+                    } else {
+                        v_pt_off.n = v_box_off.n = v_arg4.n = v_high.n = 0;
+                        v_pt_off.need(nb + 1); v_box_off.need(ncell + 1); v_arg4.need(4 * nb + 4); v_high.need(ncell);
+                        pt_off = v_pt_off.p; box_off = v_box_off.p; arg4 = v_arg4.p; high = v_high.p;
+                    }
+                    int64_t run = 0;
+                    pt_off[0] = 0;
+                    for (size_t b = 0; b < nb; ++b) { run += C.npts.p[b]; pt_off[b + 1] = (int32_t)run; }
+                    int64_t runb = 0;
+                    box_off[0] = 0;
+                    for (size_t c = 0; c < ncell; ++c) { runb += C.cell_boxes.p[c]; box_off[c + 1] = (int32_t)runb; }
+                    auto t1 = std::chrono::steady_clock::now();
+                    int rc = (run >= ((int64_t)1 << 31)) ? DYD_ERR_RANGE : DYD_OK;
+                    if (!rc) rc = dyd_bbox_iou_fused_staged(stage, C.xy.p, pt_off, box_off, (int64_t)ncell, min_boxes, thr, nullptr, arg4, high);
+                    auto t2 = std::chrono::steady_clock::now();
+                    if (rc) { fail(rc); break; }
+                    memcpy(h->high.data() + c0, high, ncell);
+                    C.xyv = C.xy.p;
+                    C.ptv = pt_off;
+                    C.ptv_bias = 0;
+                    if (!emit_part(h, src, C, arg4, A.out, A.out_len)) { fail(DYD_ERR_INVALID); break; }
+                    C.xyv = nullptr; C.ptv = nullptr;
+                    tot_boxes += nb;
+                    tot_pts += (size_t)run;
+                    for (size_t c = 0; c < C.lane.n; ++c) lane_cells += C.lane.p[c];
+                    auto t3 = std::chrono::steady_clock::now();
+                    t_scan += std::chrono::duration<double>(t1 - t0).count();
+                    t_dev += std::chrono::duration<double>(t2 - t1).count();
+                    t_emit += std::chrono::duration<double>(t3 - t2).count();
+                    c0 = c1;
+                }
+                C.xy.clear_free();                        // lent memory is only forgotten
+                dyd_stage_release(stage);
+                A.box_base = tot_boxes;                   // totals are summed below
+                A.pt_base = tot_pts;
+                A.lane_count = lane_cells;
+                ts[(size_t)k * 3 + 0] = t_scan;
+                ts[(size_t)k * 3 + 1] = t_dev;
+                ts[(size_t)k * 3 + 2] = t_emit;
             }))
             throw std::bad_alloc();
         if (first_rc) { delete h; return first_rc; }
@@ -1417,7 +1545,9 @@ int dyd_json_emit_polygons(dyd_scan *h, const uint8_t *text, const int64_t *cell
     try {
         if (!parallel_index_safe((int)h->parts.size(), [&](int k) {
                 FastPart &A = *h->parts[(size_t)k];
-                if (!emit_part(h, src, A, arg4 + 4 * A.box_base)) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
+                A.out.n = 0;
+                A.out_len.n = 0;
+                if (!emit_part(h, src, A, arg4 + 4 * A.box_base, A.out, A.out_len)) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
             }))
             return DYD_ERR_OOM;
         if (bad) return DYD_ERR_INVALID;  // arg4 inconsistent with the scan

@@ -17,21 +17,31 @@
 // the cell as before — so classification (regular / undecodable / irregular) and every edge case remain the exact walker's.
 #pragma once
 
-// growable raw array: no zero fill, realloc growth (mremap for the multi-GB arrays of a 1M-row batch)
+// growable raw array: no zero fill, realloc growth (mremap for the multi-GB arrays of a 1M-row batch).  adopt() lends it memory
+// it does not own (a staging slot's pinned arena): it fills that in place and moves to memory of its own only if it outgrows it.
 template <class T>
 struct Raw {
     T *p = nullptr;
     size_t n = 0, cap = 0;
+    bool lent = false;               // p is somebody else's memory: never freed or realloc'ed here
     Raw() = default;
     Raw(const Raw &) = delete;
     Raw &operator=(const Raw &) = delete;
-    ~Raw() { free(p); }
+    ~Raw() { if (!lent) free(p); }
     void grow(size_t need) {
         size_t c = cap * 2;
         if (c < need) c = need;
         if (c < 1024) c = 1024;
-        T *q = static_cast<T *>(realloc(p, c * sizeof(T)));
-        if (!q) throw std::bad_alloc();
+        T *q;
+        if (lent) {
+            q = static_cast<T *>(malloc(c * sizeof(T)));
+            if (!q) throw std::bad_alloc();
+            if (n) memcpy(q, p, n * sizeof(T));
+            lent = false;
+        } else {
+            q = static_cast<T *>(realloc(p, c * sizeof(T)));
+            if (!q) throw std::bad_alloc();
+        }
         p = q;
         cap = c;
         huge_hint(q, c * sizeof(T));
@@ -52,7 +62,10 @@ struct Raw {
     inline void need(size_t k) { if (n + k > cap) grow(n + k); }
     inline void push(T v) { if (n == cap) grow(n + 1); p[n++] = v; }
     inline void put(const T *s, size_t k) { if (!k) return; need(k); memcpy(p + n, s, k * sizeof(T)); n += k; }
-    void clear_free() { free(p); p = nullptr; n = cap = 0; }
+    void clear_free() { if (!lent) free(p); p = nullptr; n = cap = 0; lent = false; }
+    void adopt(T *mem, size_t elems) { clear_free(); p = mem; cap = elems; lent = elems > 0; if (!lent) p = nullptr; }   // borrowed
+    void own(T *mem, size_t elems) { clear_free(); p = mem; cap = elems; }                                                // a malloc'ed block
+    T *disown(size_t *elems) { T *q = lent ? nullptr : p; *elems = q ? cap : 0; if (!lent) { p = nullptr; n = cap = 0; } return q; }
 };
 
 struct FastPart {

@@ -346,11 +346,33 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
 // needs), the flags and — only when asked for — the boxes.  It works on a stream of its own and holds the library's lock only
 // while the kernels are queued, so the worker threads of the native replace -> IoU pipeline (host_json.cpp: one call per
 // thread's share of the cells) stage and copy side by side.
-int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows, int32_t min_boxes,
-                       double thr, double *out_box4_or_null, int32_t *out_arg4, uint8_t *out_high) {
-    {
-        DYD_API_ENTER();   // context + device binding for this thread; released before the copies
-    }
+// ---- host-pointer passes through a staging slot (dyd_common.h) ------------------------------------------------------------
+struct dyd_stage {
+    StageSlot *slot;
+};
+
+int dyd_stage_acquire(size_t pinned_bytes, dyd_stage **out, void **pinned, size_t *pinned_cap) {
+    if (!out) return DYD_ERR_INVALID;
+    StageSlot *slot = nullptr;
+    const int rc = stage_acquire(pinned_bytes, &slot);
+    if (rc) return rc;
+    dyd_stage *h = new (std::nothrow) dyd_stage{slot};
+    if (!h) { stage_release(slot); return DYD_ERR_OOM; }
+    *out = h;
+    if (pinned) *pinned = slot->pin;
+    if (pinned_cap) *pinned_cap = slot->pin_cap;
+    return DYD_OK;
+}
+
+void dyd_stage_release(dyd_stage *h) {
+    if (!h) return;
+    stage_release(h->slot);
+    delete h;
+}
+
+int dyd_bbox_iou_fused_staged(dyd_stage *h, const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
+                              int32_t min_boxes, double thr, double *out_box4_or_null, int32_t *out_arg4, uint8_t *out_high) {
+    DYD_REQUIRE(h && h->slot, "no staging slot");
     if (n_rows < 0) { set_error("invalid argument: n_rows < 0"); return DYD_ERR_INVALID; }
     if (n_rows == 0) return DYD_OK;
     DYD_REQUIRE(pt_off && box_off && out_high, "null pointer");
@@ -361,40 +383,44 @@ int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *b
     const int64_t n_pts = pt_off[n_boxes];
     DYD_REQUIRE(n_pts == 0 || xy, "xy is null");
     DYD_REQUIRE(n_boxes == 0 || out_arg4, "out_arg4 is null");
-    struct OwnStream {
-        hipStream_t s = nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ~OwnStream() {
-            if (e0) (void)hipEventDestroy(e0);
-            if (e1) (void)hipEventDestroy(e1);
-            if (s) (void)hipStreamDestroy(s);
-        }
-    } own;
-    DYD_HIP(hipStreamCreateWithFlags(&own.s, hipStreamNonBlocking));
-    DYD_HIP(hipEventCreate(&own.e0));
-    DYD_HIP(hipEventCreate(&own.e1));
-    hipStream_t st = own.s;
-    DevBuf d_xy, d_po, d_bo, d_box, d_arg, d_high;
-    int rc;
-    if ((rc = d_xy.alloc(16 * (size_t)n_pts)) || (rc = d_po.alloc(4 * (size_t)(n_boxes + 1))) ||
-        (rc = d_bo.alloc(4 * (size_t)(n_rows + 1))) || (rc = d_box.alloc(32 * (size_t)n_boxes)) ||
-        (rc = d_arg.alloc(16 * (size_t)n_boxes)) || (rc = d_high.alloc((size_t)n_rows)))
-        return rc;
-    if (n_pts) DYD_HIP(hipMemcpyAsync(d_xy.p, xy, 16 * (size_t)n_pts, hipMemcpyHostToDevice, st));
-    DYD_HIP(hipMemcpyAsync(d_po.p, pt_off, 4 * (size_t)(n_boxes + 1), hipMemcpyHostToDevice, st));
-    DYD_HIP(hipMemcpyAsync(d_bo.p, box_off, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice, st));
-    DYD_HIP(hipEventRecord(own.e0, st));
-    rc = dyd_bbox_iou_fused_dev(d_xy.as<double>(), d_po.as<int32_t>(), d_bo.as<int32_t>(), n_rows, n_boxes, n_pts, min_boxes, thr,
-                                d_box.as<double>(), d_arg.as<int32_t>(), d_high.as<uint8_t>(), st);   // takes the lock while it queues
+    StageSlot *slot = h->slot;
+    // one device arena: xy | pt_off | box_off | box4 | arg4 | high, every piece on a 256-byte boundary
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_xy = 0, o_po = o_xy + up(16 * (size_t)n_pts), o_bo = o_po + up(4 * (size_t)(n_boxes + 1)),
+                 o_box = o_bo + up(4 * (size_t)(n_rows + 1)), o_arg = o_box + up(32 * (size_t)n_boxes),
+                 o_high = o_arg + up(16 * (size_t)n_boxes), total = o_high + up((size_t)n_rows);
+    const int rcd = stage_device(slot, total);
+    if (rcd) return rcd;
+    char *d = static_cast<char *>(slot->dev);
+    hipStream_t st = slot->s;
+    if (n_pts) DYD_HIP(hipMemcpyAsync(d + o_xy, xy, 16 * (size_t)n_pts, hipMemcpyHostToDevice, st));
+    DYD_HIP(hipMemcpyAsync(d + o_po, pt_off, 4 * (size_t)(n_boxes + 1), hipMemcpyHostToDevice, st));
+    DYD_HIP(hipMemcpyAsync(d + o_bo, box_off, 4 * (size_t)(n_rows + 1), hipMemcpyHostToDevice, st));
+    DYD_HIP(hipEventRecord(slot->e0, st));
+    int rc = dyd_bbox_iou_fused_dev(reinterpret_cast<const double *>(d + o_xy), reinterpret_cast<const int32_t *>(d + o_po),
+                                    reinterpret_cast<const int32_t *>(d + o_bo), n_rows, n_boxes, n_pts, min_boxes, thr,
+                                    reinterpret_cast<double *>(d + o_box), reinterpret_cast<int32_t *>(d + o_arg),
+                                    reinterpret_cast<uint8_t *>(d + o_high), st);   // takes the lock while it queues
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
-    DYD_HIP(hipEventRecord(own.e1, st));
-    if (n_boxes) DYD_HIP(hipMemcpyAsync(out_arg4, d_arg.p, 16 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
-    if (n_boxes && out_box4_or_null) DYD_HIP(hipMemcpyAsync(out_box4_or_null, d_box.p, 32 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
-    DYD_HIP(hipMemcpyAsync(out_high, d_high.p, (size_t)n_rows, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipEventRecord(slot->e1, st));
+    if (n_boxes) DYD_HIP(hipMemcpyAsync(out_arg4, d + o_arg, 16 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
+    if (n_boxes && out_box4_or_null) DYD_HIP(hipMemcpyAsync(out_box4_or_null, d + o_box, 32 * (size_t)n_boxes, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(out_high, d + o_high, (size_t)n_rows, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, own.e0, own.e1) == hipSuccess) set_last_kernel_ms(ms);
+    if (hipEventElapsedTime(&ms, slot->e0, slot->e1) == hipSuccess) set_last_kernel_ms(ms);
     return DYD_OK;
+}
+
+int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows, int32_t min_boxes,
+                       double thr, double *out_box4_or_null, int32_t *out_arg4, uint8_t *out_high) {
+    if (n_rows < 0) { set_error("invalid argument: n_rows < 0"); return DYD_ERR_INVALID; }
+    dyd_stage *h = nullptr;
+    int rc = dyd_stage_acquire(0, &h, nullptr, nullptr);
+    if (rc) return rc;
+    rc = dyd_bbox_iou_fused_staged(h, xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4_or_null, out_arg4, out_high);
+    dyd_stage_release(h);
+    return rc;
 }
 
 }  // extern "C"

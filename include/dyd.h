@@ -120,6 +120,18 @@ int dyd_iou_any_ge_dev(const double *box4, const int32_t *row_off, int64_t n_row
 int dyd_bbox_iou_fused(const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
                        int32_t min_boxes, double thr, double *out_box4_or_null, int32_t *out_arg4,
                        uint8_t *out_high);
+/* The same pass through a STAGING SLOT the caller holds across many calls: a stream, two timing events, a device arena and a
+ * pinned host arena, all owned by the context and kept between calls (nothing is created, allocated or freed per pass once the
+ * arenas have grown to the working size).  dyd_stage_acquire hands out a free slot — a new one while fewer than 64 exist, else it
+ * waits — with its pinned arena grown to pinned_bytes if the budget (DYD_PINNED_POOL_MB, default 1024 for all slots together)
+ * allows: *pinned / *pinned_cap tell what the caller got (possibly less, possibly nothing).  Host arrays of the _staged call may
+ * lie inside that arena (then every copy is an asynchronous DMA) or anywhere else.  dyd_bbox_iou_fused is acquire(0) + staged +
+ * release.  The native replace -> IoU pass (dyd_json_replace_iou) scans straight into the pinned arena. */
+typedef struct dyd_stage dyd_stage;
+int dyd_stage_acquire(size_t pinned_bytes, dyd_stage **out, void **pinned, size_t *pinned_cap);
+void dyd_stage_release(dyd_stage *stage);
+int dyd_bbox_iou_fused_staged(dyd_stage *stage, const double *xy, const int32_t *pt_off, const int32_t *box_off, int64_t n_rows,
+                              int32_t min_boxes, double thr, double *out_box4_or_null, int32_t *out_arg4, uint8_t *out_high);
 int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_t *box_off,
                            int64_t n_rows, int64_t n_boxes, int64_t n_points, int32_t min_boxes, double thr,
                            double *out_box4, int32_t *out_arg4, uint8_t *out_high, void *stream);
@@ -285,6 +297,9 @@ const uint8_t *dyd_scan_sel(const dyd_scan *scan);             /* [n_boxes] (lab
  * (dyd_scan_text).  Needs the device (no CPU fallback). */
 int dyd_json_replace_iou(const uint8_t *text, const int64_t *cell_off, const uint8_t *const *cell_ptr, const int64_t *cell_len,
                          const uint8_t *missing, int64_t n_cells, int32_t min_boxes, double thr, int n_threads, dyd_scan **out);
+/* Emitted text outlives the pass that wrote it; a freed handle parks those blocks (up to DYD_HOST_POOL_MB, default 3072) so that the
+ * next pass writes into warm memory instead of tearing 2 GB of page tables down and faulting them in again.  This gives them back. */
+void dyd_host_pool_trim(void);
 const uint8_t *dyd_scan_high(const dyd_scan *scan);            /* [n_cells] */
 int32_t dyd_scan_parts(const dyd_scan *scan);
 int dyd_scan_part(const dyd_scan *scan, int32_t k, int64_t *lo, int64_t *hi, const uint8_t **text, const int64_t **off);

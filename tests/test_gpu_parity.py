@@ -495,6 +495,43 @@ def test_native_pipeline_equals_the_stepwise_route(native, monkeypatch):
         ohi, _ = osteps.iou_filter_frame(oproj, mb, thr)
         assert a[0][P.BBOX_COL].tolist() == okept[osteps.NEW_COL].tolist()
         assert a[2]["source"].tolist() == ohi["source"].tolist()
+    # the pass works chunk by chunk through a staging slot: chunks of one cell, of a few cells, and of everything give the same frames
+    base = P.replace_and_filter_frame(df, 2, 0.98)
+    for kb in ("1", "64", "1000000"):
+        monkeypatch.setenv("DYD_PIPE_CHUNK_KB", kb)
+        stats = {}
+        c = P.replace_and_filter_frame(df, 2, 0.98, stats=stats)
+        assert stats.get("native_pipeline", 0) >= 1
+        for x, y in zip(c, base):
+            pd.testing.assert_frame_equal(x, y)
+    monkeypatch.delenv("DYD_PIPE_CHUNK_KB")
+
+
+def test_staged_fused_entry_with_and_without_pinned_memory(native):
+    """dyd_bbox_iou_fused_staged through one slot, call after call (arenas grow and are kept), from pageable arrays and from the
+    slot's own pinned arena: the flags and arg indices of the plain host entry"""
+    import ctypes as C
+    from deal_yolo_daya_amd import synth
+    L = native.lib()
+    t = synth.generate(4000, seed=21)
+    want_arg, want_high = native.bbox_iou_fused(t.xy, t.pt_off, t.box_off, 2, 0.98)
+    stage, pin, cap = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    native.check(L.dyd_stage_acquire(t.xy.nbytes + 4096, C.byref(stage), C.byref(pin), C.byref(cap)), "dyd_stage_acquire")
+    try:
+        assert cap.value == 0 or cap.value >= t.xy.nbytes
+        for rows in (4000, 700, 4000, 1):
+            nb = int(t.box_off[rows]); npts = int(t.pt_off[nb])
+            arg = np.full((nb, 4), -9, np.int32); high = np.full(rows, 9, np.uint8)
+            xy = t.xy[:npts]
+            if pin.value and rows != 700:                      # the points inside the slot's pinned arena
+                xy = np.ctypeslib.as_array(C.cast(pin.value, C.POINTER(C.c_double)), shape=(npts, 2))
+                xy[:] = t.xy[:npts]
+            po = np.ascontiguousarray(t.pt_off[:nb + 1]); bo = np.ascontiguousarray(t.box_off[:rows + 1])
+            native.check(L.dyd_bbox_iou_fused_staged(stage, xy.ctypes.data, po.ctypes.data, bo.ctypes.data, rows, 2, 0.98, None,
+                                                     arg.ctypes.data, high.ctypes.data), "dyd_bbox_iou_fused_staged")
+            assert np.array_equal(arg, want_arg[:nb]) and np.array_equal(high, want_high[:rows])
+    finally:
+        L.dyd_stage_release(stage)
 
 
 def test_arrow_backed_bbox_column_holds_the_same_values(native):
