@@ -17,6 +17,7 @@
 #include <Python.h>
 #include <pthread.h>
 #include <sched.h>
+#include <time.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -256,7 +257,7 @@ static inline int text_is_ascii(const unsigned char *s, int64_t n) {
  * (Tried and dropped: letting the workers allocate from malloc — CPython's free() accepts such blocks — creates 14 M small
  * strings in 0.6 s instead of 0.9 but frees them in 3.5 s instead of 1.0, and for 2 KB strings sixteen threads growing sixteen
  * malloc arenas at once were four times SLOWER than the one thread, on the GPU box's host.) */
-#define VCHUNK 16384
+#define VCHUNK_MAX 16384
 typedef struct {
     const char *const *ptr;
     const int64_t *len;
@@ -268,6 +269,7 @@ typedef struct {
     PyObject **seq;              /* element i's object, in walk order (== objs when there is no slot) */
     uint8_t *ascii;              /* per i: 1 = ASCII text (NULL: all are) */
     int64_t n;
+    int64_t chunk;               /* elements per chunk: a power of two, small enough for every thread to get several */
     int64_t next_chunk;          /* atomic: next chunk a worker takes */
     int64_t ready;               /* atomic: elements [0, ready) are allocated */
     int mode;                    /* 0 classify, 1 fill + place */
@@ -283,15 +285,16 @@ static inline const unsigned char *vtext(const vshared_t *w, int64_t i, int64_t 
 
 static void *vworker(void *arg) {
     vshared_t *w = (vshared_t *)arg;
-    const int64_t n_chunks = (w->n + VCHUNK - 1) / VCHUNK;
+    const int64_t n_chunks = (w->n + w->chunk - 1) / w->chunk;
     for (;;) {
         const int64_t c = __atomic_fetch_add(&w->next_chunk, 1, __ATOMIC_RELAXED);
         if (c >= n_chunks) break;
-        const int64_t lo = c * VCHUNK, hi = (lo + VCHUNK < w->n) ? lo + VCHUNK : w->n;
+        const int64_t lo = c * w->chunk, hi = (lo + w->chunk < w->n) ? lo + w->chunk : w->n;
         if (w->mode == 1) {
-            while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {
-                if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;
-                sched_yield();
+            while (__atomic_load_n(&w->ready, __ATOMIC_ACQUIRE) < hi) {      /* asleep, not spinning: under a CPU quota a spinning */
+                if (__atomic_load_n(&w->abort_fill, __ATOMIC_RELAXED)) return NULL;   /* waiter is charged like a working thread */
+                const struct timespec nap = {0, 40000};
+                nanosleep(&nap, NULL);
             }
         }
         for (int64_t i = lo; i < hi; ++i) {
@@ -327,6 +330,8 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     const int64_t n = w->n;
     if (n == 0) return 0;
     n_threads = clamp_threads(n_threads, n, 4096);
+    w->chunk = VCHUNK_MAX;
+    while (w->chunk > 256 && w->chunk * 4 * n_threads > n) w->chunk >>= 1;
     for (int64_t i = 0; i < n; ++i) {             /* fresh slots only; the None references they hold are released here */
         if (w->na && w->na[i]) continue;
         PyObject **q = &w->objs[w->slot ? w->slot[i] : i];
@@ -353,7 +358,21 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     int fillers = 0;
     w->mode = 1;
     w->next_chunk = 0;
-    for (int t = 1; t < n_threads; ++t)
+    /* Small strings (the split step's 160-byte records): a few fillers keep up with the allocating thread — a copy is cheaper
+     * than an allocation; more would only nap in turns.  Large ones (the 2 KB bbox text of a row: malloc'ed, not pymalloc'ed):
+     * copying beside the allocating thread slowed it down more than the overlap gained (GPU box's host, 1 M x 2 KB: 0.27 s
+     * against 0.19 s for allocate-all-then-fill-with-every-thread), so those are done in two phases. */
+    int64_t sample_bytes = 0, sample_n = 0;
+    for (int64_t i = 0; i < n; i += (n / 1024) + 1) {
+        if (w->na && w->na[i]) continue;
+        int64_t k;
+        (void)vtext(w, i, &k);
+        sample_bytes += k;
+        ++sample_n;
+    }
+    const int two_phases = sample_n > 0 && sample_bytes / sample_n >= 464;
+    const int want_fillers = two_phases ? 0 : (n_threads - 1 < 6 ? n_threads - 1 : 6);
+    for (int t = 0; t < want_fillers; ++t)
         if (pthread_create(&th[fillers], NULL, vworker, w) == 0) ++fillers;
     for (int64_t i = 0; i < n; ++i) {
         if (!(w->na && w->na[i])) {
@@ -365,12 +384,13 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
             w->seq[i] = o;
         }
         made = i + 1;
-        if ((made & (VCHUNK - 1)) == 0) __atomic_store_n(&w->ready, made, __ATOMIC_RELEASE);
+        if ((made & (w->chunk - 1)) == 0) __atomic_store_n(&w->ready, made, __ATOMIC_RELEASE);
     }
     if (failed) __atomic_store_n(&w->abort_fill, 1, __ATOMIC_RELAXED);
     else __atomic_store_n(&w->ready, n, __ATOMIC_RELEASE);
     Py_BEGIN_ALLOW_THREADS
-    if (!failed) vworker(w);                       /* help with what is left */
+    if (!failed && two_phases) vrun_all(w, n_threads, 1);
+    else if (!failed) vworker(w);                  /* help with what is left */
     for (int t = 0; t < fillers; ++t) pthread_join(th[t], NULL);
     Py_END_ALLOW_THREADS
     if (failed) {                                  /* hand everything back: the array is as fresh as it came */
@@ -385,19 +405,20 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     return failed ? -1 : 0;
 }
 
-/* map_strs(ptr, len, idx, slot, n, out, n_threads[, all_ascii]): out[slot[i]] = str(the len[k] bytes at ptr[k]), k = idx[i];
- * all_ascii != 0: the caller vouches that every text is ASCII */
+/* map_strs(ptr, len, idx, slot, n, out, n_threads[, all_ascii[, na]]): out[slot[i]] = str(the len[k] bytes at ptr[k]), k = idx[i];
+ * all_ascii != 0: the caller vouches that every text is ASCII; na[i] != 0 skips element i */
 static PyObject *map_strs(PyObject *self, PyObject *args) {
-    unsigned long long a_ptr, a_len, a_idx, a_slot, a_objs;
+    unsigned long long a_ptr, a_len, a_idx, a_slot, a_objs, a_na = 0;
     Py_ssize_t n;
     int n_threads, all_ascii = 0;
-    if (!PyArg_ParseTuple(args, "KKKKnKi|i", &a_ptr, &a_len, &a_idx, &a_slot, &n, &a_objs, &n_threads, &all_ascii)) return NULL;
+    if (!PyArg_ParseTuple(args, "KKKKnKi|iK", &a_ptr, &a_len, &a_idx, &a_slot, &n, &a_objs, &n_threads, &all_ascii, &a_na)) return NULL;
     vshared_t w;
     memset(&w, 0, sizeof(w));
     w.ptr = (const char *const *)(uintptr_t)a_ptr;
     w.len = (const int64_t *)(uintptr_t)a_len;
     w.idx = (const int64_t *)(uintptr_t)a_idx;
     w.slot = (const int64_t *)(uintptr_t)a_slot;
+    w.na = (const uint8_t *)(uintptr_t)a_na;
     w.objs = (PyObject **)(uintptr_t)a_objs;
     w.n = (int64_t)n;
     if (build_strs(&w, n_threads, all_ascii) < 0) return NULL;

@@ -188,13 +188,16 @@ class ReplaceIou:
     width_height = PolygonScan.width_height
 
     def texts_array(self) -> np.ndarray:
-        """object array: bbox text (str) for regular cells, None elsewhere — str objects made part by part, straight from the
-        parts' buffers (no gathered copy of the text)"""
+        """object array: bbox text (str) for regular cells, None elsewhere — str objects made straight from the parts' buffers
+        (no gathered copy of the text), all parts in ONE pass of the str builder"""
         from . import pycells
 
         L = _native.load_library()
-        out = np.empty(self.n_cells, object)
         na = (self.status != OK).astype(np.uint8)
+        if not pycells.available():
+            out = np.empty(self.n_cells, object)
+        ptr = np.zeros(self.n_cells, np.uint64)
+        length = np.zeros(self.n_cells, np.int64)
         for k in range(int(L.dyd_scan_parts(self._h))):
             lo, hi, text, off = C.c_int64(), C.c_int64(), C.c_void_p(), C.c_void_p()
             _native.check(L.dyd_scan_part(self._h, k, C.byref(lo), C.byref(hi), C.byref(text), C.byref(off)), "dyd_scan_part")
@@ -203,10 +206,12 @@ class ReplaceIou:
                 continue
             offs = _view(off.value, np.int64, n + 1)
             if pycells.available():
-                pycells._dydpy.strs_from_utf8(text.value or 0, offs.ctypes.data, n, na[lo.value:hi.value].ctypes.data,
-                                              out.ctypes.data + 8 * lo.value, host_threads())
+                np.add(offs[:-1], text.value or 0, out=ptr[lo.value:hi.value], casting="unsafe")
+                np.subtract(offs[1:], offs[:-1], out=length[lo.value:hi.value])
             else:
                 out[lo.value:hi.value] = strings_from_buffers(_view(text.value, np.uint8, int(offs[-1])), offs, na[lo.value:hi.value])
+        if pycells.available():
+            return pycells.strings_from_views(ptr, length, na=na)
         return out
 
     def texts_arrow(self):

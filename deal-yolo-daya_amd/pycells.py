@@ -104,10 +104,10 @@ def _addr(a) -> int:
 
 
 def strings_from_views(ptr: np.ndarray, length: np.ndarray, idx=None, n_threads: int = 0, all_ascii: bool = False, slot=None,
-                       checked: bool = False) -> np.ndarray:
+                       checked: bool = False, na=None) -> np.ndarray:
     """object array of str from one (address, length) view per text: out[slot[i]] = text idx[i] — the split step's records,
     straight from the native handle's buffers (no flat copy of the text in either order).
-    ``all_ascii``: the caller vouches that every text is ASCII (saves the classifying pass)."""
+    ``all_ascii``: the caller vouches that every text is ASCII (saves the classifying pass); ``na[i] != 0`` leaves out[slot[i]] None."""
     ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
     length = np.ascontiguousarray(length, dtype=np.int64)
     n = len(ptr) if idx is None else len(idx)
@@ -117,10 +117,14 @@ def strings_from_views(ptr: np.ndarray, length: np.ndarray, idx=None, n_threads:
         slot = np.ascontiguousarray(slot, dtype=np.int64) if checked else _checked_index(slot, n)
         if len(slot) != n:
             raise ValueError("slot and idx differ in length")
+    if na is not None:
+        na = np.ascontiguousarray(na, dtype=np.uint8)
+        if len(na) != n:
+            raise ValueError("na and the walk differ in length")
     out = np.empty(n, object)
     if n:
         _dydpy.map_strs(ptr.ctypes.data, length.ctypes.data, _addr(idx), _addr(slot), n, out.ctypes.data, _threads(n_threads),
-                        1 if all_ascii else 0)
+                        1 if all_ascii else 0, _addr(na))
     return out
 
 
