@@ -102,18 +102,23 @@ inline hipStream_t pick_stream(void *s) { return reinterpret_cast<hipStream_t>(s
         if (rc__ != DYD_OK) return rc__;                             \
     } while (0)
 
-// RAII device buffer for the host-pointer entry points
+// RAII device buffer for the host-pointer entry points: stream-ordered allocation from the device's default memory pool, whose
+// release threshold the context raises at start (dyd_context.hip), so a buffer freed on return is handed to the next call instead
+// of going back to the driver — hipFree waits for the whole device, hipFreeAsync only takes its place in the stream.
 struct DevBuf {
     void *p = nullptr;
+    hipStream_t st = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFreeAsync(p, st);
     }
-    int alloc(size_t bytes) {
+    int alloc(size_t bytes, hipStream_t stream = nullptr) {
         if (bytes == 0) bytes = 16;
-        hipError_t e = hipMalloc(&p, bytes);
+        st = stream ? stream : ctx().stream;
+        hipError_t e = hipMallocAsync(&p, bytes, st);
         if (e != hipSuccess) {
             p = nullptr;
-            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            (void)hipGetLastError();
+            set_error("hipMallocAsync(%zu) failed: %s", bytes, hipGetErrorString(e));
             return DYD_ERR_OOM;
         }
         return DYD_OK;

@@ -214,6 +214,14 @@ static int init_locked(int device) {
     DYD_HIP(hipEventCreate(&c.ev0));
     DYD_HIP(hipEventCreate(&c.ev1));
     DYD_HIP(hipEventCreateWithFlags(&c.scratch_ev, hipEventDisableTiming));
+    {   // freed DevBuf memory stays in the pool for the next call (dyd_shutdown trims it)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+            uint64_t keep = ~(uint64_t)0;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     DYD_HIP(hipMalloc(reinterpret_cast<void **>(&c.dev_status), 16));
     DYD_HIP(hipMemset(c.dev_status, 0, 16));
     c.ready = true;
@@ -297,6 +305,11 @@ void dyd_shutdown(void) {
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     stage_free_all();
+    {
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, c.device) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+        (void)hipGetLastError();
+    }
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.dev_status) (void)hipFree(c.dev_status);
     if (c.bigq) (void)hipFree(c.bigq);

@@ -302,7 +302,7 @@ static int split_seeded(const int32_t *cat, int64_t n, uint32_t seed, const int6
     if (total >= (1LL << 32)) { set_error("invalid argument: more than 2^32 records"); return DYD_ERR_INVALID; }
     DevBuf d_inv, d_small;
     int rc;
-    if ((rc = d_inv.alloc(4 * (size_t)(total > 0 ? total : 1))) || (rc = d_small.alloc(8 * (size_t)(4 * n_cat + 1)))) return rc;
+    if ((rc = d_inv.alloc(4 * (size_t)(total > 0 ? total : 1), st)) || (rc = d_small.alloc(8 * (size_t)(4 * n_cat + 1), st))) return rc;
     uint32_t *inv = d_inv.as<uint32_t>();
     int64_t *d_off = d_small.as<int64_t>(), *d_tr = d_off + n_cat + 1, *d_va = d_tr + n_cat, *d_rb = d_va + n_cat;
     DYD_HIP(hipMemcpyAsync(d_off, off.data(), 8 * (size_t)(n_cat + 1), hipMemcpyHostToDevice, st));

@@ -310,23 +310,102 @@ struct K8BandOut {
     __host__ __device__ K8BandOut operator+(difference_type i) const { return K8BandOut{dst + i, c0 + i, d + i, key, violated, n, base + (uint32_t)i}; }
     __host__ __device__ K8BandOut &operator+=(difference_type i) { dst += i; c0 += i; d += i; base += (uint32_t)i; return *this; }
 };
-// per uncertain draw: its base count and the first guess of "accepted uncertain draws before it"
-__global__ __launch_bounds__(256) void k8_small_init(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ base,
-                                                     const uint32_t *__restrict__ c0, uint32_t n_u, uint32_t *__restrict__ bu,
-                                                     uint32_t *__restrict__ cntA, uint32_t *__restrict__ cntB) {
+// ---- the recurrence on the list of uncertain draws, in ONE launch ------------------------------------------------------------
+// Round 2 iterated c <- scan(flags(c)) over the whole list (~1.2 M draws for 82 M steps) with rocPRIM, one 8-byte read-back per
+// round to learn how far the exact prefix had grown: 45-47 rounds of ~90 us each per category, a fifth of K8.  The recurrence
+// is sequential only from tile to tile: a single workgroup walks the list once, tile after tile of 4096 draws, carrying the EXACT
+// count into each tile and iterating inside the tile until no flag changes — the counts inside a tile are off by at most the
+// tile's own length at the start, far inside the band the draws were selected with, so three to five local rounds settle it
+// (each one a ballot, a 16-entry LDS scan and two barriers).  No host round trip, no second workgroup to wait for.
+constexpr int K8L_THREADS = 1024, K8L_EPT = 4, K8L_TILE = K8L_THREADS * K8L_EPT;
+
+// dvu[u] = the draw's word, bu[u] = certain acceptances before it
+__global__ __launch_bounds__(256) void k8_list_init(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ d,
+                                                    const uint32_t *__restrict__ base, uint32_t n_u, uint32_t *__restrict__ dvu,
+                                                    uint32_t *__restrict__ bu) {
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
     if (u >= n_u) return;
-    const uint32_t t = pos[u], b = base[t], g = c0[t];
-    const uint32_t c = g > b ? g - b : 0u;
-    bu[u] = b;
-    cntA[u] = c;
-    cntB[u] = c;
+    const uint32_t t = pos[u];
+    dvu[u] = d[t];
+    bu[u] = base[t];
 }
-// the outcome of every uncertain draw under the exact counts, as a byte at the draw's place
-__global__ __launch_bounds__(256) void k8_small_mark(K8FlagU f, uint32_t n_u, uint8_t *__restrict__ mark) {
+
+__device__ __forceinline__ uint32_t k8_accept(uint32_t dv, uint32_t c, uint32_t n) {
+    if (c >= n - 1u) return 0u;
+    const uint32_t i = n - 1u - c;
+    return ((dv & k8_mask(i)) <= i) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(K8L_THREADS) void k8_list_resolve(const uint32_t *__restrict__ dvu, const uint32_t *__restrict__ bu,
+                                                               uint32_t n_u, uint32_t n, uint8_t *__restrict__ fu,
+                                                               uint32_t *__restrict__ rounds_out) {
+    __shared__ uint32_t wsum[K8L_THREADS / 64];
+    __shared__ int changed_any;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t c_in = 0;                      // accepted uncertain draws before the tile: exact
+    uint32_t rounds = 0;
+    for (uint32_t tile = 0; tile < n_u; tile += K8L_TILE) {
+        const uint32_t u0 = tile + (uint32_t)tid * K8L_EPT;
+        uint32_t dv[K8L_EPT], b[K8L_EPT], f[K8L_EPT];
+#pragma unroll
+        for (int k = 0; k < K8L_EPT; ++k) {
+            const bool in = u0 + k < n_u;
+            dv[k] = in ? dvu[u0 + k] : 0u;
+            b[k] = in ? bu[u0 + k] : 0xffffffffu;             // beyond the list: never accepted (count >= n - 1)
+            f[k] = in ? k8_accept(dv[k], b[k] + c_in, n) : 0u; // first guess: nothing inside the tile counted yet
+        }
+        uint32_t total = 0;
+        for (;;) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int k = 0; k < K8L_EPT; ++k) s += f[k];
+            uint32_t incl = s;                                  // inclusive scan of the threads' sums inside the wave
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, dlt);
+                if (lane >= dlt) incl += o;
+            }
+            if (tid == 0) changed_any = 0;
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < K8L_THREADS / 64; ++w) {
+                const uint32_t v = wsum[w];
+                before += w < wave ? v : 0u;
+                all += v;
+            }
+            uint32_t c = c_in + before + incl - s;              // accepted uncertain draws before this thread's first element
+            bool changed = false;
+#pragma unroll
+            for (int k = 0; k < K8L_EPT; ++k) {
+                const uint32_t nf = (b[k] != 0xffffffffu) ? k8_accept(dv[k], b[k] + c, n) : 0u;
+                changed |= nf != f[k];
+                c += f[k];                                      // the counts of this round are those of the OLD flags (Picard)
+                f[k] = nf;
+            }
+            if (changed) changed_any = 1;
+            ++rounds;
+            __syncthreads();
+            const int again = changed_any;
+            total = all;
+            __syncthreads();                                    // changed_any is reset by thread 0 at the top of the next round
+            if (!again) break;                                  // the flags reproduced themselves: `all` is their sum
+        }
+#pragma unroll
+        for (int k = 0; k < K8L_EPT; ++k)
+            if (u0 + k < n_u) fu[u0 + k] = (uint8_t)f[k];
+        c_in += total;
+    }
+    if (tid == 0 && rounds_out) *rounds_out = rounds;
+}
+
+// the outcome of every uncertain draw, as a byte at the draw's place
+__global__ __launch_bounds__(256) void k8_list_mark(const uint32_t *__restrict__ pos, const uint8_t *__restrict__ fu, uint32_t n_u,
+                                                    uint8_t *__restrict__ mark) {
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
     if (u >= n_u) return;
-    mark[f.pos[u]] = (uint8_t)f(u);
+    mark[pos[u]] = fu[u];
 }
 
 // first guess of c(t): inside an octave of mask+1 = M the step index decays like i+1 ~ (i_s+1) exp(-(t-t_s)/M)
@@ -378,40 +457,41 @@ __global__ __launch_bounds__(256) void k8_partners(const uint32_t *__restrict__ 
     if (v <= i) key[i] = v;
 }
 
-// last[x] = the largest step that targets slot x (0xffffffff: none); pos[i] = where step i sits in the sorted order
-__global__ __launch_bounds__(256) void k8_last(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ is, uint32_t n,
-                                               uint32_t *__restrict__ last, uint32_t *__restrict__ pos) {
+// From the sorted (slot, step) pairs to what the chase needs, indexed by STEP: prev[i] = the next smaller step that targets the
+// same slot as step i (0xffffffff: none).  And the values that need no chase at all: the last pair of a slot's run is the largest
+// step i that targets slot x — if i > x, value x is fetched by that step before its own step runs and stays at position i
+// (inv[x] = i; inv must come in filled with 0xffffffff).
+__global__ __launch_bounds__(256) void k8_links(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ is, uint32_t n,
+                                                uint32_t *__restrict__ prev, uint32_t *__restrict__ inv) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const uint32_t h = hs[k], i = is[k];
-    pos[i] = (uint32_t)k;
-    if (k + 1 == n || hs[k + 1] != h) last[h] = i;
+    prev[i] = (k > 0 && hs[k - 1] == h) ? is[k - 1] : 0xffffffffu;
+    if ((k + 1 == n || hs[k + 1] != h) && i > h) inv[h] = i;
 }
 
-// inv[v] = final position of value v (see the header); optionally perm[inv[v]] = v as int64
-__global__ __launch_bounds__(256) void k8_inverse(const uint32_t *__restrict__ hs, const uint32_t *__restrict__ is,
-                                                  const uint32_t *__restrict__ last, const uint32_t *__restrict__ pos, uint32_t n,
+// inv[v] = final position of value v (see the header) for the values k8_links left open; optionally inv64 / perm64[inv[v]] = v.
+// Value v rides its own step T = v to slot key[T], where the next smaller step targeting that slot (prev[T]) fetches it for good —
+// or, if there is none, that slot's own step carries it one hop further.  One thread per VALUE: the first hop reads prev[v] and
+// key[v] in order, only the later hops (half as many each time) are random accesses.
+__global__ __launch_bounds__(256) void k8_inverse(const uint32_t *__restrict__ key, const uint32_t *__restrict__ prev, uint32_t n,
                                                   uint32_t *__restrict__ inv32, int64_t *__restrict__ inv64,
                                                   int64_t *__restrict__ perm64) {
-    // one thread per VALUE (not per sorted position): last[v] and the result are then read and written in order, and the values
-    // that a later step fetches (most of them) finish without a single random access
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const uint32_t v = (uint32_t)t;
-    const uint32_t lv = last[v];
-    uint32_t where;
-    if (lv != 0xffffffffu && lv > v) {
-        where = lv;                                   // fetched by the first step that targets slot v
-    } else {
-        uint32_t kk = pos[v];                         // v rides its own step T = is[kk] = v to slot hs[kk]
+    uint32_t where = inv32[v];
+    if (where == 0xffffffffu) {
+        uint32_t T = v;
         while (true) {
-            const uint32_t slot = hs[kk];
-            if (kk > 0 && hs[kk - 1] == slot) { where = is[kk - 1]; break; }   // the next smaller step targeting that slot
-            if (is[kk] == slot) { where = slot; break; }                      // H[T] == T: it never left
-            kk = pos[slot];                                                   // the slot's own step carries it on
+            const uint32_t q = prev[T];
+            if (q != 0xffffffffu) { where = q; break; }     // the next smaller step targeting the slot it sits in
+            const uint32_t slot = key[T];
+            if (slot == T) { where = T; break; }            // H[T] == T: it never left
+            T = slot;                                       // the slot's own step carries it on
         }
+        inv32[v] = where;
     }
-    if (inv32) inv32[v] = where;
     if (inv64) inv64[v] = (int64_t)where;
     if (perm64) perm64[where] = (int64_t)v;
 }
@@ -519,29 +599,14 @@ static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t
     DYD_HIP(hipMemsetAsync(mark, 0, (size_t)draws, st));
     int rounds = 0;
     if (n_u) {
-        hipLaunchKernelGGL(k8_small_init, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, pos_u, cB, cA, n_u, bu, cntA0, cntB0);
+        // list arrays: dvu in cntA0's place, the flag bytes in cntB0's (a quarter of it)
+        uint32_t *dvu = cntA0;
+        uint8_t *fu = reinterpret_cast<uint8_t *>(cntB0);
+        hipLaunchKernelGGL(k8_list_init, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, pos_u, d, cB, n_u, dvu, bu);
         DYD_HIP(hipGetLastError());
-        uint32_t *a = cntA0, *bq = cntB0;
-        uint32_t lo = 0, c_lo = 0;
-        while (lo < n_u) {
-            K8FlagU f{d, pos_u, bu, a, n};
-            auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(lo), f);
-            tb = tmp_bytes;
-            DYD_HIP(hipMemsetAsync(res, 0xff, 4, st));
-            DYD_HIP(rocprim::exclusive_scan(tmp, tb, in, K8DiffOut{bq + lo, a + lo, res, lo}, c_lo, (size_t)(n_u - lo), rocprim::plus<uint32_t>(), st));
-            hipLaunchKernelGGL(k8_pick, dim3(1), dim3(64), 0, st, bq, res);
-            DYD_HIP(hipGetLastError());
-            uint32_t host[2] = {0, 0};
-            DYD_HIP(hipMemcpyAsync(host, res, 8, hipMemcpyDeviceToHost, st));
-            DYD_HIP(hipStreamSynchronize(st));
-            ++rounds;
-            uint32_t *t2 = a; a = bq; bq = t2;   // a = the newest counts: exact up to the first difference
-            if (host[0] == 0xffffffffu) break;
-            lo = host[0];
-            c_lo = host[1];
-            if (rounds > 100000) { set_error("K8: the banded resolve did not settle"); return DYD_ERR_HIP; }
-        }
-        hipLaunchKernelGGL(k8_small_mark, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, K8FlagU{d, pos_u, bu, a, n}, n_u, mark);
+        hipLaunchKernelGGL(k8_list_resolve, dim3(1), dim3(K8L_THREADS), 0, st, dvu, bu, n_u, n, fu, res + 5);
+        DYD_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k8_list_mark, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, pos_u, fu, n_u, mark);
         DYD_HIP(hipGetLastError());
     }
     // exact counts (into cB, over the base counts that are no longer needed), checked against the band
@@ -549,9 +614,11 @@ static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t
     tb = tmp_bytes;
     DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8FlagFinal{d, cA, mark, n}), K8BandOut{cB, cA, d, key, res + 2, n, 0u}, 0u,
                                     (size_t)draws, rocprim::plus<uint32_t>(), st));
-    uint32_t violated = 1;
+    uint32_t violated = 1, list_rounds = 0;
     DYD_HIP(hipMemcpyAsync(&violated, res + 2, 4, hipMemcpyDeviceToHost, st));
+    if (n_u) DYD_HIP(hipMemcpyAsync(&list_rounds, res + 5, 4, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
+    rounds = (int)list_rounds;              // local rounds of the list walk, all tiles together
     if (rounds_out) *rounds_out = rounds;
     if (violated) return DYD_OK;   // a count left its band somewhere: nothing above is trusted (the full-length rounds rewrite every partner)
     *resolved = true;
@@ -633,10 +700,11 @@ static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n
     while (bits < 32 && (1ull << bits) < (unsigned long long)n) ++bits;
     size_t tb = tmp_bytes;
     DYD_HIP(rocprim::radix_sort_pairs<K8SortConfig>(tmp, tb, key, hs, rocprim::make_counting_iterator<uint32_t>(0u), is, (size_t)n, 0u, bits, st));
-    DYD_HIP(hipMemsetAsync(last, 0xff, (size_t)n * 4, st));
-    hipLaunchKernelGGL(k8_last, dim3(gn), dim3(256), 0, st, hs, is, n, last, pos);
+    uint32_t *invw = inv32 ? inv32 : last;               // the caller's 32-bit inverse, else scratch (the list arrays are done with)
+    DYD_HIP(hipMemsetAsync(invw, 0xff, (size_t)n * 4, st));
+    hipLaunchKernelGGL(k8_links, dim3(gn), dim3(256), 0, st, hs, is, n, pos, invw);
     DYD_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k8_inverse, dim3(gn), dim3(256), 0, st, hs, is, last, pos, n, inv32, inv64, perm64);
+    hipLaunchKernelGGL(k8_inverse, dim3(gn), dim3(256), 0, st, key, pos, n, invw, inv64, perm64);
     DYD_HIP(hipGetLastError());
     return DYD_OK;
 }
