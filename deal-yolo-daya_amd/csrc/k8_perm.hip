@@ -528,9 +528,20 @@ static double expected_draws(uint32_t n, K8Octaves *oc) {
 #ifndef K8_SORT_BITS
 #define K8_SORT_BITS 9
 #endif
+#ifndef K8_SORT_BLOCK
+#define K8_SORT_BLOCK 1024
+#endif
+#ifndef K8_SORT_ITEMS
+#define K8_SORT_ITEMS 8
+#endif
+#ifdef K8_SORT_DEFAULT
+using K8SortConfig = rocprim::default_config;
+#else
 using K8SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<K8_SORT_BLOCK, K8_SORT_ITEMS>,
+                                                                                    rocprim::kernel_config<K8_SORT_BLOCK, K8_SORT_ITEMS>,
                                                                                     K8_SORT_BITS, rocprim::block_radix_rank_algorithm::match>>;
+#endif
 
 struct PermScratch {
     uint32_t *d = nullptr;          // tempered stream
