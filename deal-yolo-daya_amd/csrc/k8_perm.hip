@@ -524,24 +524,15 @@ static double expected_draws(uint32_t n, K8Octaves *oc) {
 }
 
 // The (partner, step) sort: keys of at most 30 bits.  rocprim's gfx950 default takes 8 bits per pass — four passes for the 27 bits of
-// 82.5 M records, the last one for 3 bits; 9 bits per pass make it three.
+// 82.5 M records, the last one for 3 bits; 9 bits per pass make it three.  Block size and items per thread do not matter (round 3
+// sweep of <1024,8> / <1024,12> / <1024,16> / <512,8> / <512,16> at 9 bits, <1024,8> at 8 bits and rocprim's default: K8 + K6
+// 16.4-18.3 ms, the kept <1024,8> 16.7): the three scatter passes run at ~1 TB/s of pair traffic whatever the tile.
 #ifndef K8_SORT_BITS
 #define K8_SORT_BITS 9
 #endif
-#ifndef K8_SORT_BLOCK
-#define K8_SORT_BLOCK 1024
-#endif
-#ifndef K8_SORT_ITEMS
-#define K8_SORT_ITEMS 8
-#endif
-#ifdef K8_SORT_DEFAULT
-using K8SortConfig = rocprim::default_config;
-#else
 using K8SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<K8_SORT_BLOCK, K8_SORT_ITEMS>,
-                                                                                    rocprim::kernel_config<K8_SORT_BLOCK, K8_SORT_ITEMS>,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>,
                                                                                     K8_SORT_BITS, rocprim::block_radix_rank_algorithm::match>>;
-#endif
 
 struct PermScratch {
     uint32_t *d = nullptr;          // tempered stream
