@@ -47,6 +47,50 @@ ANNOTATION_COL = "结果字段-目标检测标签配置"          # reference pr
 BBOX_COL = "新_" + ANNOTATION_COL                    # reference processor.py:283, :384
 _CHUNK_CELLS = 1 << 18                               # cells flattened per device batch (Python path)
 LAST_IO_PATH = {}                                    # step -> "native" | "pandas": which CSV path the last call took
+
+# ---- the replace step hands its table to the IoU step ---------------------------------------------------------------------
+# The processing page presses two buttons: process_csv_replace_ptlist writes the processed CSV, filter_by_box_count_and_iou reads it
+# back (reference ui/pages/processing.py:580-598).  The replace step's native pass already knows everything the IoU step is about to
+# recompute — the boxes are its own output (:260 -> :354-362) — so it runs the fused K1+K2 launch with the thresholds the IoU step
+# was last called with (the page's defaults, app.py:33-34, until then) and parks the table with its HIGH flags here, keyed by the
+# file it wrote: absolute path, size, mtime_ns and a digest of the file's first and last megabyte.  filter_by_box_count_and_iou on
+# exactly that file with exactly those thresholds writes its two CSVs from the parked table (LAST_IO_PATH["iou"] == "cached": no
+# read, no scan, no launch); anything else — another file, a file touched since, other thresholds, a table above
+# DYD_STEP_CACHE_MB (default 16384) — takes the normal route.  One table at most is parked; clear_step_cache() drops it.
+import threading as _threading
+
+_STEP_CACHE = {"lock": _threading.Lock(), "entry": None, "params": (2, 0.98)}
+
+
+def clear_step_cache() -> None:
+    with _STEP_CACHE["lock"]:
+        entry, _STEP_CACHE["entry"] = _STEP_CACHE["entry"], None
+    if entry is not None:
+        entry["core"]["scan"].close()
+
+
+def _file_key(path):
+    """(absolute path, size, mtime_ns, digest of the first and last MiB) of a file, or None"""
+    import hashlib
+    try:
+        path = os.path.abspath(str(path))
+        st = os.stat(path)
+        h = hashlib.blake2b(digest_size=16)
+        with open(path, "rb") as f:
+            h.update(f.read(1 << 20))
+            if st.st_size > (2 << 20):
+                f.seek(st.st_size - (1 << 20))
+                h.update(f.read(1 << 20))
+        return (path, st.st_size, st.st_mtime_ns, h.hexdigest())
+    except OSError:
+        return None
+
+
+def _step_cache_limit() -> int:
+    try:
+        return int(os.environ.get("DYD_STEP_CACHE_MB", "16384")) << 20
+    except ValueError:
+        return 16384 << 20
 VERIFY_EVENTS = []                                   # (step, column, detail): verify=True found a 128-bit hash collision
 _NATIVE_CHUNK_CELLS = 1 << 21                        # cells per native scan (2M rows ~ 0.26 G points at 124 pts/row)
 
@@ -590,12 +634,61 @@ def _replace_csv_write(core, output_csv_path, excluded_output_file):
 
 def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, backend):
     """CSV -> CSV replace step without pandas touching the annotation column (fastcsv + native JSON).
-    Returns NotImplemented whenever the fast path does not apply; nothing has been written then."""
-    core = _replace_csv_core(input_csv_path, backend)
+    Returns NotImplemented whenever the fast path does not apply; nothing has been written then.
+    The pass also computes the IoU step's flag and parks the table for it (see _STEP_CACHE)."""
+    clear_step_cache()
+    core, fuse = NotImplemented, None
+    if _step_cache_limit() > 0:
+        fuse = _STEP_CACHE["params"]
+        try:
+            import contextlib
+            with contextlib.redirect_stdout(io.StringIO()) as quiet:
+                core = _replace_csv_core(input_csv_path, backend, fuse=fuse)
+            if core is not NotImplemented:
+                print(quiet.getvalue(), end="")
+        except Exception:  # noqa: BLE001  the IoU step's own failure (string coordinates ...) must not surface one step early
+            core, fuse = NotImplemented, None
+    if core is NotImplemented:
+        fuse = None
+        core = _replace_csv_core(input_csv_path, backend)
     if core is NotImplemented:
         return NotImplemented
+    parked = False
     try:
-        return _replace_csv_write(core, output_csv_path, excluded_output_file)
+        res = _replace_csv_write(core, output_csv_path, excluded_output_file)
+        if res is not _LATE_FALLBACK and fuse is not None:
+            heavy = [c for c in core["columns"] if isinstance(c, _fc.Utf8Column)]
+            heavy_ok = all((c.na != 0).sum() < len(c) or len(c) == 0 for c in heavy)     # an all-NaN text column is re-read as float
+            size = sum(int(c.off[-1]) for c in heavy)
+            key = _file_key(output_csv_path) if heavy_ok and size <= _step_cache_limit() else None
+            if key is not None:
+                with _STEP_CACHE["lock"]:
+                    _STEP_CACHE["entry"] = {"key": key, "params": fuse, "core": core}
+                parked = True
+        return res
+    finally:
+        if not parked:
+            core["scan"].close()
+
+
+def _iou_csv_cached(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold) -> bool:
+    """the IoU step from the table the replace step parked (see _STEP_CACHE); False: not applicable, nothing written"""
+    with _STEP_CACHE["lock"]:
+        entry = _STEP_CACHE["entry"]
+        if entry is None:
+            return False
+        if entry["params"] != (min_boxes, iou_threshold) or entry["key"][0] != os.path.abspath(str(input_csv_path)):
+            return False
+        _STEP_CACHE["entry"] = None                       # one use: the caller owns it now
+    core = entry["core"]
+    try:
+        if _file_key(input_csv_path) != entry["key"]:     # the file was touched since: what is parked is not what is on disk
+            return False
+        kept_rows, high = core["kept_rows"], core["high"]
+        cols = _as_reread(core, core["names"])
+        n = core["table"].n_rows
+        return bool(_fc.write_table(str(high_iou_csv), core["names"], cols, n, rows=kept_rows[high[kept_rows]])
+                    and _fc.write_table(str(other_csv), core["names"], cols, n, rows=kept_rows[~high[kept_rows]]))
     finally:
         core["scan"].close()
 
@@ -735,7 +828,11 @@ def filter_by_box_count_and_iou(
         iou_threshold: float = 0.98,
         backend=None,
 ):
+    _STEP_CACHE["params"] = (min_boxes, iou_threshold)              # what the next replace step computes ahead
     if _fc.enabled() and _nj.enabled() and os.path.isfile(str(input_csv_path)):
+        if _iou_csv_cached(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold):
+            LAST_IO_PATH["iou"] = "cached"
+            return
         if _iou_csv_fast(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_threshold, backend) is None:
             LAST_IO_PATH["iou"] = "native"
             return

@@ -122,9 +122,13 @@ def test_golden_files_take_the_native_csv_path(oracle_backend, tmp_path):
     P.process_csv_replace_ptlist(Q("filtered.csv"), Q("processed.csv"), Q("excluded.csv"), backend=oracle_backend)
     assert P.LAST_IO_PATH["replace"] == "native"
     P.filter_by_box_count_and_iou(Q("processed.csv"), Q("high.csv"), Q("other.csv"), 2, 0.98, backend=oracle_backend)
-    assert P.LAST_IO_PATH["iou"] == "native"
+    assert P.LAST_IO_PATH["iou"] == "cached"              # from the table the replace step parked (processor._STEP_CACHE)
     for n in ("processed", "excluded", "high", "other"):
         assert read_text(Q(n + ".csv")) == golden_csv_text(f"e2e_{n}.csv.gz"), n
+    P.filter_by_box_count_and_iou(Q("processed.csv"), Q("high2.csv"), Q("other2.csv"), 2, 0.98, backend=oracle_backend)
+    assert P.LAST_IO_PATH["iou"] == "native"              # the parked table is used once; now the file is read back
+    for n in ("high", "other"):
+        assert read_text(Q(n + "2.csv")) == golden_csv_text(f"e2e_{n}.csv.gz"), n
     g = load_golden("replace_cases.json")
     write_csv_text(Q("cases.csv"), g["input_csv"])
     P.process_csv_replace_ptlist(Q("cases.csv"), Q("cases_out.csv"), Q("cases_exc.csv"), backend=oracle_backend)

@@ -59,3 +59,34 @@ def test_the_five_steps_in_sequence_match_the_cpu_port_at_100k_rows(native, tabl
         for a, b in zip(got_h["categories"][cat], exp_h["categories"][cat]):
             assert a.equals(b)
     assert got_h["unclassified"].equals(exp_h["unclassified"]) and got_h["split_counts"].equals(exp_h["split_counts"])
+
+
+def test_two_buttons_as_the_page_presses_them(native, tmp_path):
+    """replace step, then IoU step on the file it wrote (reference ui/pages/processing.py:580-598, import swap only): the second step
+    comes from the table the first one parked, and the five files are those of the fused twin and of the CPU port"""
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    df = synth.to_frame(synth.generate(20_000, seed=33))
+    df.loc[[5, 4000], P.ANNOTATION_COL] = None
+    df.to_csv(Q("in.csv"), index=False, encoding="utf-8-sig")
+    P.clear_step_cache()
+    P._STEP_CACHE["params"] = (2, 0.98)
+    res = P.process_csv_replace_ptlist(Q("in.csv"), Q("p.csv"), Q("e.csv"))
+    assert P.LAST_IO_PATH["replace"] == "native"
+    P.filter_by_box_count_and_iou(Q("p.csv"), Q("h.csv"), Q("o.csv"), 2, 0.98)
+    assert P.LAST_IO_PATH["iou"] == "cached"
+    res2 = P.process_csv_replace_and_filter(Q("in.csv"), Q("p2.csv"), Q("e2.csv"), Q("h2.csv"), Q("o2.csv"), 2, 0.98)
+    assert P.LAST_IO_PATH["replace_iou"] == "fused-native" and res2 == {**res, "excluded_output": Q("e2.csv")}
+    osteps.replace_csv(Q("in.csv"), Q("p3.csv"), Q("e3.csv"))
+    osteps.iou_filter_csv(Q("p3.csv"), Q("h3.csv"), Q("o3.csv"), 2, 0.98)
+    for k in "peho":
+        a = open(Q(f"{k}.csv"), "rb").read()
+        assert a == open(Q(f"{k}2.csv"), "rb").read() == open(Q(f"{k}3.csv"), "rb").read(), k
+    # the parked table is used once and only for the file it was written to
+    P.filter_by_box_count_and_iou(Q("p.csv"), Q("h4.csv"), Q("o4.csv"), 2, 0.98)
+    assert P.LAST_IO_PATH["iou"] == "native" and open(Q("h4.csv"), "rb").read() == open(Q("h.csv"), "rb").read()
+    P.process_csv_replace_ptlist(Q("in.csv"), Q("p5.csv"), Q("e5.csv"))
+    with open(Q("p5.csv"), "ab") as f:
+        f.write(b"\n")
+    P.filter_by_box_count_and_iou(Q("p5.csv"), Q("h5.csv"), Q("o5.csv"), 2, 0.98)
+    assert P.LAST_IO_PATH["iou"] != "cached"
+    P.clear_step_cache()

@@ -401,3 +401,46 @@ def test_verify_mode_catches_a_hash_collision(oracle_backend):
 
     assert P.ref_hit_mask(main, ref, CollidingRef()).tolist() == [True, True, False, True]
     assert P.ref_hit_mask(main, ref, CollidingRef(), verify=True).tolist() == [True, False, False, True]
+
+
+def test_the_iou_step_takes_the_table_the_replace_step_parked(oracle_backend, tmp_path, monkeypatch):
+    """the processing page's two buttons (reference ui/pages/processing.py:580-598): replace, then IoU filter on the file it wrote.
+    The second step writes its CSVs from the parked table — the same bytes as the route that reads the file back — and only
+    when file and thresholds are the ones the table was parked for."""
+    from deal_yolo_daya_amd import synth
+    Q = lambda n: str(tmp_path / n)  # noqa: E731
+    df = synth.to_frame(synth.generate(1500, seed=41))
+    df.loc[[3, 77], P.ANNOTATION_COL] = None
+    df.to_csv(Q("in.csv"), index=False, encoding="utf-8-sig")
+    P.clear_step_cache()
+    P._STEP_CACHE["params"] = (2, 0.98)
+
+    def two_steps(tag, mb=2, thr=0.98, touch=False):
+        res = P.process_csv_replace_ptlist(Q("in.csv"), Q(f"p_{tag}.csv"), Q(f"e_{tag}.csv"), backend=oracle_backend)
+        if touch:
+            with open(Q(f"p_{tag}.csv"), "ab") as f:
+                f.write(b"")
+            os.utime(Q(f"p_{tag}.csv"), ns=(1, 1))
+        P.filter_by_box_count_and_iou(Q(f"p_{tag}.csv"), Q(f"h_{tag}.csv"), Q(f"o_{tag}.csv"), mb, thr, backend=oracle_backend)
+        return res, P.LAST_IO_PATH["iou"]
+
+    res_c, how_c = two_steps("c")
+    assert how_c == "cached" and res_c["filtered_rows"] == 1498 and res_c["excluded_rows"] == 2
+    monkeypatch.setenv("DYD_STEP_CACHE_MB", "0")
+    res_n, how_n = two_steps("n")
+    monkeypatch.delenv("DYD_STEP_CACHE_MB")
+    assert how_n == "native" and res_n == {**res_c, "excluded_output": Q("e_n.csv")}
+    for kind in "pehos"[:4]:
+        assert read_text(Q(f"{kind}_c.csv")) == read_text(Q(f"{kind}_n.csv")), kind
+    high = pd.read_csv(Q("h_c.csv"), encoding="utf-8-sig")
+    assert 10 < len(high) < 200
+    # a file touched after it was written is read back; other thresholds are computed, and remembered for the next replace step
+    assert two_steps("t", touch=True)[1] == "native" and read_text(Q("h_t.csv")) == read_text(Q("h_n.csv"))
+    assert two_steps("q", 3, 0.5)[1] == "native"
+    assert two_steps("r", 3, 0.5)[1] == "cached" and read_text(Q("h_r.csv")) == read_text(Q("h_q.csv")) and read_text(Q("o_r.csv")) == read_text(Q("o_q.csv"))
+    # another file of the same content is not the parked one
+    P.process_csv_replace_ptlist(Q("in.csv"), Q("p_x.csv"), Q("e_x.csv"), backend=oracle_backend)
+    P.filter_by_box_count_and_iou(Q("p_r.csv"), Q("h_y.csv"), Q("o_y.csv"), 3, 0.5, backend=oracle_backend)
+    assert P.LAST_IO_PATH["iou"] == "native"
+    P.clear_step_cache()
+    P._STEP_CACHE["params"] = (2, 0.98)
