@@ -17,7 +17,9 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  (replace_and_filter_frame: scan + H2D + fused launch + D2H + emit) and its ratio to cpu_baseline;
                  .pipeline = configs[2] through the product API: the five step functions in sequence on that table, per step
                  seconds and the ratio to the same step of the CPU port
+                 .path_io = SURVEY §8d region 3: CSV path in -> CSV paths out, the fused twin and the page's two step functions
   full_pipeline  configs[2]: K3 -> K4 -> K5 -> K1+K2 -> permutation + K6 on the same 10M resident rows, per stage
+  dense          configs[4] scaled (1M rows x 256 boxes, 44 GB): the same launch, its own roofline object
 and, with --workload c4, the sharded dedup of configs[3] with its all-gather timed on its own.
 """
 from __future__ import annotations
@@ -190,6 +192,55 @@ def host_pipeline(df, ref, cpu_rows):
             "rows": len(df), "seconds": round(total, 3), "rows_per_s": round(len(df) / total, 1), "rows_out": rows_out,
             "steps": steps, "cpu_port": cpu,
             "cpu_port_sample": f"first {cpu_rows} rows of the same table (split: the first {max(1, cpu_rows // 10)} of its input), 1 core" if cpu else None}
+
+
+def path_io(df, rows):
+    """SURVEY §8d region (3), path in -> path out: the first `rows` rows of the host table as a CSV, through the fused CSV twin
+    (process_csv_replace_and_filter: five files from one pass) and through the two step functions as the unchanged processing
+    page calls them (process_csv_replace_ptlist, then filter_by_box_count_and_iou on the file it wrote), one run each."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+
+    from deal_yolo_daya_amd import fastcsv as _fc
+    from deal_yolo_daya_amd import synth
+    from deal_yolo_daya_amd.core import processor as P
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (32 << 30) else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="dyd_bench_", dir=base)
+    Q = lambda n: os.path.join(d, n)  # noqa: E731
+    try:
+        sub = df.iloc[:rows].reset_index(drop=True)
+        a = time.perf_counter()
+        if not _fc.write_table(Q("in.csv"), list(sub.columns), [sub[c] for c in sub.columns], len(sub)):
+            sub.to_csv(Q("in.csv"), index=False, encoding="utf-8-sig")
+        write_in = time.perf_counter() - a
+        in_bytes = os.path.getsize(Q("in.csv"))
+        P.clear_step_cache()
+        with contextlib.redirect_stdout(io.StringIO()):
+            a = time.perf_counter()
+            P.process_csv_replace_and_filter(Q("in.csv"), Q("p.csv"), Q("x.csv"), Q("hi.csv"), Q("lo.csv"), MIN_BOXES, THR)
+            t_fused = time.perf_counter() - a
+            how_fused = P.LAST_IO_PATH.get("replace_iou")
+            a = time.perf_counter()
+            P.process_csv_replace_ptlist(Q("in.csv"), Q("p2.csv"), Q("x2.csv"))
+            b = time.perf_counter()
+            P.filter_by_box_count_and_iou(Q("p2.csv"), Q("hi2.csv"), Q("lo2.csv"), MIN_BOXES, THR)
+            c = time.perf_counter()
+        same = all(open(Q(x), "rb").read() == open(Q(y), "rb").read() for x, y in (("p.csv", "p2.csv"), ("hi.csv", "hi2.csv"), ("lo.csv", "lo2.csv")))
+        out_bytes = sum(os.path.getsize(Q(n)) for n in ("p.csv", "hi.csv", "lo.csv"))
+        return {"region": "SURVEY §8d (3): CSV path in -> CSV paths out (processed, excluded, high, other)", "rows": rows, "filesystem": base,
+                "input_csv_bytes": in_bytes, "output_csv_bytes": out_bytes, "input_written_s": round(write_in, 3),
+                "fused_twin": {"function": "process_csv_replace_and_filter", "seconds": round(t_fused, 3), "rows_per_s": round(rows / t_fused), "io_path": how_fused},
+                "two_steps": {"functions": "process_csv_replace_ptlist -> filter_by_box_count_and_iou (import swap only)",
+                              "replace_s": round(b - a, 3), "iou_s": round(c - b, 3), "seconds": round(c - a, 3), "rows_per_s": round(rows / (c - a)),
+                              "io_path": {"replace": P.LAST_IO_PATH.get("replace"), "iou": P.LAST_IO_PATH.get("iou")},
+                              "vs_fused_twin": round((c - a) / t_fused, 3)},
+                "same_files": bool(same)}
+    finally:
+        P.clear_step_cache()
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def full_pipeline(tab, dev, L, ck, sp):
@@ -371,6 +422,9 @@ def main():
     ap.add_argument("--host-rows", type=int, default=1_000_000, help="rows of the host-inclusive DataFrame run (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = also time configs[2]'s full pipeline per stage (c3, N=1)")
     ap.add_argument("--pipeline-cpu-rows", type=int, default=20000, help="rows of the CPU port's run of the five steps beside host_inclusive.pipeline (0 = skip)")
+    ap.add_argument("--dense", type=int, default=1, help="1 = also time configs[4]'s table (1M rows x 256 boxes) with its own roofline object (c3, N=1)")
+    ap.add_argument("--dense-steps", type=int, default=10)
+    ap.add_argument("--path-rows", type=int, default=300000, help="rows of the CSV path-in / path-out legs (SURVEY §8d region 3; 0 = skip)")
     ap.add_argument("--exchange", type=int, default=1,
                     help="1 = at N > 1 also time configs[3]'s sharded dedup / reference filter with its all-gathers (after the K steps)")
     ap.add_argument("--fused-variant", type=int, default=-1, help="A/B only: force a kernel variant of the fused launch (dyd_set_option)")
@@ -410,65 +464,101 @@ def main():
     rows, bpr, desc = WORKLOADS[args.workload]
     if args.rows:
         rows = args.rows
-    # ---- synthetic batch for this rank, drawn on the device in chunks, resident in HBM --------
-    chunk = GEN_CHUNK if bpr is None else 100_000
-    xy_p, npts_p, nbox_p, lab_p = [], [], [], []
-    for ci, start in enumerate(range(0, rows, chunk)):
-        d = synth.generate_device(min(chunk, rows - start), synth.SEED + 1000 * rank + ci, dev, boxes_per_row=bpr)
-        xy_p.append(d["xy"])
-        npts_p.append(torch.diff(d["pt_off"]))
-        nbox_p.append(torch.diff(d["box_off"]))
-        lab_p.append(d["label"])
-        del d
-    xy = torch.cat(xy_p); del xy_p
-    npts = torch.cat(npts_p); nbox = torch.cat(nbox_p); label = torch.cat(lab_p)
-    del npts_p, nbox_p, lab_p
-    P, B, N = int(xy.shape[0]), int(npts.shape[0]), int(nbox.shape[0])
-    if P >= 2 ** 31:
-        raise SystemExit("points per GPU exceed int32 offsets; lower --rows")
-    pt_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    pt_off[1:] = torch.cumsum(npts, 0, dtype=torch.int64).to(torch.int32)
-    box_off = torch.zeros(N + 1, dtype=torch.int32, device=dev)
-    box_off[1:] = torch.cumsum(nbox, 0, dtype=torch.int64).to(torch.int32)
-    del npts, nbox
-    out_box = torch.empty((B, 4), dtype=torch.float64, device=dev)
-    out_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
-    out_high = torch.empty(N, dtype=torch.uint8, device=dev)
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()
-
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
-
-    def fused():
-        ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P, MIN_BOXES, THR,
-                                    out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "dyd_bbox_iou_fused_dev")
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    ramp_launches = 0
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:      # clock ramp, outside the W + K steps
-        for _ in range(4):
+    def resident(rows, bpr, steps, warmup, ramp_ms, seed_base):
+        """the synthetic batch for this rank, drawn on the device in chunks and resident in HBM; W warm-up steps, then EXACTLY
+        `steps` timed steps of the fused launch, HIP events around each on the launch stream"""
+        chunk = GEN_CHUNK if bpr is None else 100_000
+        xy_p, npts_p, nbox_p, lab_p = [], [], [], []
+        for ci, start in enumerate(range(0, rows, chunk)):
+            d = synth.generate_device(min(chunk, rows - start), seed_base + ci, dev, boxes_per_row=bpr)
+            xy_p.append(d["xy"])
+            npts_p.append(torch.diff(d["pt_off"]))
+            nbox_p.append(torch.diff(d["box_off"]))
+            lab_p.append(d["label"])
+            del d
+        xy = torch.cat(xy_p); del xy_p
+        npts = torch.cat(npts_p); nbox = torch.cat(nbox_p); label = torch.cat(lab_p)
+        del npts_p, nbox_p, lab_p
+        P, B, N = int(xy.shape[0]), int(npts.shape[0]), int(nbox.shape[0])
+        if P >= 2 ** 31:
+            raise SystemExit("points per GPU exceed int32 offsets; lower --rows")
+        pt_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        pt_off[1:] = torch.cumsum(npts, 0, dtype=torch.int64).to(torch.int32)
+        box_off = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+        box_off[1:] = torch.cumsum(nbox, 0, dtype=torch.int64).to(torch.int32)
+        del npts, nbox
+        out_box = torch.empty((B, 4), dtype=torch.float64, device=dev)
+        out_arg = torch.empty((B, 4), dtype=torch.int32, device=dev)
+        out_high = torch.empty(N, dtype=torch.uint8, device=dev)
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+
+        def fused():
+            ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P, MIN_BOXES, THR,
+                                        out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "dyd_bbox_iou_fused_dev")
+
+        ramp_launches = 0
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:      # clock ramp, outside the W + K steps
+            for _ in range(4):
+                fused()
+            torch.cuda.synchronize()
+            ramp_launches += 4
+        for _ in range(warmup):
             fused()
         torch.cuda.synchronize()
-        ramp_launches += 4
-    for _ in range(args.warmup):
-        fused()
-    torch.cuda.synchronize()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):          # EXACTLY K timed steps
+            ev[k][0].record(stream); fused(); ev[k][1].record(stream)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        return {"P": P, "B": B, "N": N, "elapsed": elapsed, "kernel_ms": k_ms, "ramp_launches": ramp_launches,
+                "high_rows": int(out_high.sum().item()), "label": label, "fused": fused,
+                "keep": (xy, pt_off, box_off, out_box, out_arg, out_high)}
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):          # EXACTLY K timed steps
-        ev[s][0].record(stream); fused(); ev[s][1].record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def roofline_of(res, workload, rows):
+        """algorithmic bytes of one launch / its HIP-event time, and the PMC traffic of the same launch from the committed passes"""
+        P, B, N = res["P"], res["B"], res["N"]
+        alg_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N     # SURVEY §8d: K1's bytes + K2's offsets and flags; the boxes reach K2 through LDS
+        achieved = alg_bytes / (res["kernel_ms"] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: separate rocprofv3 --pmc passes over this same command (tools/gpu_profile.sh ->
+        # tools/collect_profiles.py), FETCH_SIZE doubled as the microarch guide prescribes for gfx950.  It is NOT measured in
+        # this run: the value is read from the committed summary of those passes and only for the workload they ran.
+        traffic, traffic_src = None, None
+        for tname in (("r03_c5_traffic.json", "r02_c5_traffic.json") if workload == "c5" else ("k12_traffic.json",)):
+            tf = os.path.join(REPO, "profiles", tname)
+            if not os.path.exists(tf):
+                continue
+            with open(tf) as fh:
+                tj = json.load(fh)
+            same = (tj.get("rows_per_gpu") == rows and tj.get("workload") == workload) or \
+                   (workload == "c5" and tj.get("algorithmic_bytes_per_launch") == alg_bytes)
+            if same:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{tname} <- {tj.get('source', 'rocprofv3 --pmc passes of this command')} (not measured in this run)"
+                break
+        return {"bound": "hbm", "kernel": ("k12_wave_kernel (fused K1+K2)" if B <= 32 * N else
+                                           "k12_wave_dense_kernel (fused K1+K2, rows of 40..256 boxes sorted and swept)"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                "frac_of_measured_achievable_6290": achieved / 6290.0}
 
+    main_res = resident(rows, bpr, args.steps, args.warmup, args.ramp_ms, synth.SEED + 1000 * rank)
+    elapsed = main_res["elapsed"]
+    P, B, N = main_res["P"], main_res["B"], main_res["N"]
+    label, fused = main_res["label"], main_res["fused"]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist.get_backend() == "gloo":
@@ -476,34 +566,19 @@ def main():
         else:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    high_rows = int(out_high.sum().item())
+    high_rows = main_res["high_rows"]
     exchange = None
     if (world > 1 and args.exchange) or args.workload == "c4":      # every rank takes part; rank 0 reports
-        if world == 1 and not dist.is_initialized():                  # c4 on one GPU: a group of one, so the same code path runs
+        if world == 1 and not dist.is_initialized():                  # c4 on one GPU: a group of one, over RCCL like the real thing
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("gloo", rank=0, world_size=1)
+            dist.init_process_group(os.environ.get("DYD_BENCH_BACKEND", "nccl"), rank=0, world_size=1,
+                                    **({"device_id": dev} if os.environ.get("DYD_BENCH_BACKEND", "nccl") == "nccl" else {}))
         exchange = sharded_dedup(rows, rank, world, dev)
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
-        k_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        # HBM traffic of the dominant kernel: separate rocprofv3 --pmc passes over this same command (tools/gpu_profile.sh ->
-        # tools/collect_profiles.py), FETCH_SIZE doubled as the microarch guide prescribes for gfx950.  It is NOT measured in
-        # this run: the value is read from the committed summary of those passes and only for the workload they ran.
-        traffic, traffic_src = None, None
-        tname = "r02_c5_traffic.json" if args.workload == "c5" else "k12_traffic.json"
-        tf = os.path.join(REPO, "profiles", tname)
-        if os.path.exists(tf):
-            with open(tf) as fh:
-                tj = json.load(fh)
-            same = (tj.get("rows_per_gpu") == rows and tj.get("workload") == args.workload) or \
-                   (args.workload == "c5" and tj.get("algorithmic_bytes_per_launch") == 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N)
-            if same:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = f"profiles/{tname} <- {tj.get('source', 'rocprofv3 --pmc passes of this command')} (not measured in this run)"
-        alg_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N     # K1's bytes + K2's offsets and flags; the boxes reach K2 through LDS
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        k_ms = main_res["kernel_ms"]
         line = {
             "metric": "annotation rows/sec through poly->bbox + IoU-filter path",
             "value": rows * world * args.steps / elapsed,
@@ -520,23 +595,31 @@ def main():
             "config": {"workload": desc, "rows_per_gpu": rows, "boxes_per_gpu": B, "points_per_gpu": P,
                        "min_boxes": MIN_BOXES, "iou_threshold": THR, "high_rows_rank0": high_rows,
                        "launch": "fused K1+K2 (dyd_bbox_iou_fused_dev)" + (f", forced variant {args.fused_variant}" if args.fused_variant >= 0 else ""), "kernel_ms": k_ms,
-                       "clock_ramp_launches_before_warmup": ramp_launches, "device": _native.device_name()},
-            "roofline": {"bound": "hbm", "kernel": ("k12_wave_kernel (fused K1+K2)" if B <= 32 * N else
-                                                    "k12_wave_dense_kernel (fused K1+K2, rows of 40..256 boxes sorted and swept)"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "frac_of_measured_achievable_6290": achieved / 6290.0},
+                       "clock_ramp_launches_before_warmup": main_res["ramp_launches"], "device": _native.device_name()},
+            "roofline": roofline_of(main_res, args.workload, rows),
         }
         line["cpu_baseline"] = None
         line["host_inclusive"] = None
         line["full_pipeline"] = None
+        line["dense"] = None
         line["sharded_exchange"] = exchange
         if world == 1:
             if args.pipeline and args.workload == "c3":
                 line["full_pipeline"] = full_pipeline({"N": N, "B": B, "P": P, "label": label, "fused": fused}, dev, L, ck, sp)
-            del xy, pt_off, box_off, out_box, out_arg, out_high, label
+            del label, fused
+            main_res.clear()
             torch.cuda.empty_cache()
+            if args.dense and args.workload == "c3":
+                # configs[4] scaled to one launch: 1 M rows x 256 boxes (44 GB), the same fused entry (its DENSE instantiation), timed
+                # like the headline: HIP events around every launch, its own roofline object
+                drows, dbpr, ddesc = WORKLOADS["c5"]
+                dres = resident(drows, dbpr, args.dense_steps, 2, 200.0, synth.SEED + 555)
+                line["dense"] = {"workload": ddesc, "rows": drows, "boxes": dres["B"], "points": dres["P"], "steps": args.dense_steps,
+                                 "ms_per_step": dres["elapsed"] * 1e3 / args.dense_steps, "kernel_ms": dres["kernel_ms"],
+                                 "rows_per_s": drows * args.dense_steps / dres["elapsed"], "boxes_per_s": dres["B"] * args.dense_steps / dres["elapsed"],
+                                 "high_rows": dres["high_rows"], "roofline": roofline_of(dres, "c5", drows)}
+                dres.clear()
+                torch.cuda.empty_cache()
             if args.cpu_sample > 0:
                 sizes = sorted({min(10000, args.cpu_sample), args.cpu_sample})
                 line["cpu_baseline"] = cpu_baseline(sizes)
@@ -547,6 +630,8 @@ def main():
                     hi["vs_cpu_baseline"] = hi["value"] / line["cpu_baseline"]["value"]
                 if args.pipeline:
                     hi["pipeline"] = host_pipeline(df, ref, min(args.pipeline_cpu_rows, args.host_rows))
+                if args.path_rows > 0:
+                    hi["path_io"] = path_io(df, min(args.path_rows, args.host_rows))
                 line["host_inclusive"] = hi
         print(json.dumps(line, ensure_ascii=False))
     if dist.is_initialized():
