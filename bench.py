@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  .path_io = SURVEY §8d region 3: CSV path in -> CSV paths out, the fused twin and the page's two step functions
   full_pipeline  configs[2]: K3 -> K4 -> K5 -> K1+K2 -> permutation + K6 on the same 10M resident rows, per stage
   dense          configs[4] scaled (1M rows x 256 boxes, 44 GB): the same launch, its own roofline object
-and, with --workload c4, the sharded dedup of configs[3] with its all-gather timed on its own.
+and the sharded dedup / reference filter of configs[3] with its collectives timed on their own: sharded_exchange (weak: rows per GPU
+fixed, at N > 1 or --workload c4) and sharded_exchange_strong (a fixed 100 M-row table cut into N shards, at every N incl. 1).
 """
 from __future__ import annotations
 
@@ -333,11 +334,11 @@ def full_pipeline(tab, dev, L, ck, sp):
             "rows": N, "total_ms": round(total, 3), "rows_per_s": N / total * 1e3, "stages": stages}
 
 
-def sharded_dedup(rows, rank, world, dev, reps=3):
-    """configs[3]'s exchange on this rank's `rows` rows of a world*rows table: K3 hash of the URL column, K4 on the shard,
-    ONE all-gather of the locally unique 16-B keys (RCCL over xGMI), K5 probe of the local survivors against the lower ranks'
-    keys; then the reference filter (reference keys sharded, gathered once, K5).  Wall-clock per stage with a device
-    synchronisation on both sides, the collective on its own; median of `reps`."""
+def sharded_dedup(rows, rank, world, dev, reps=3, scaling="weak"):
+    """configs[3]'s exchange on this rank's `rows` rows of a world*rows table: K3 hash of the URL column, K4 on the shard, ONE
+    all-gather of the locally unique 16-B keys (RCCL over xGMI), K4 on this rank's hash slice of the gathered keys and one all-reduce
+    of the verdict bytes; then the reference filter (reference keys sharded, gathered once, K5).  Wall-clock per stage with a
+    device synchronisation on both sides, the collectives on their own; median of `reps`; every rank's numbers are reported."""
     import torch
     import torch.distributed as dist
     from deal_yolo_daya_amd import distributed as D
@@ -361,9 +362,11 @@ def sharded_dedup(rows, rank, world, dev, reps=3):
         return out.reshape(-1), torch.arange(n + 1, device=dev, dtype=torch.int64) * width
 
     data, off = url_bytes(ids)
+    del ids
     ref_all = torch.arange(0, int(0.9 * N) + 1, 10, device=dev, dtype=torch.int64)
     rlo, rhi = D.shard_bounds(int(ref_all.numel()), world, rank)
     rdata, roff = url_bytes(ref_all[rlo:rhi])
+    del ref_all
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -378,8 +381,9 @@ def sharded_dedup(rows, rank, world, dev, reps=3):
         a = time.perf_counter()
         keep = D.dedup_keys_sharded(h, "first", ops, timings=tm)
         sync(); t["dedup_total_ms"] = (time.perf_counter() - a) * 1e3
-        t["dedup_allgather_ms"] = tm["collective_s"] * 1e3
-        t["gathered_keys"], t["local_unique_keys"] = tm["gathered_keys"], tm["local_unique_keys"]
+        t["dedup_collectives_ms"] = tm["collective_s"] * 1e3
+        t["gathered_keys"], t["local_unique_keys"], t["slice_keys"] = tm["gathered_keys"], tm["local_unique_keys"], tm["slice_keys"]
+        t["verdict_bytes"] = tm.get("verdict_bytes", 0)
         a = time.perf_counter()
         hr = ops.hash128(rdata, roff)
         sync(); b = time.perf_counter()
@@ -389,23 +393,32 @@ def sharded_dedup(rows, rank, world, dev, reps=3):
         ops.check_status()
         sync(); d = time.perf_counter()
         t["ref_k3_ms"], t["ref_allgather_ms"], t["ref_k5_ms"] = (b - a) * 1e3, (c - b) * 1e3, (d - c) * 1e3
+        t["ref_table_keys"] = int(all_ref.shape[0])
         t["kept_local"], t["ref_hits_local"] = int(keep.sum().item()), int(hit.sum().item())
         runs.append(t)
     runs = runs[1:]
     med = {k: float(np.median([r[k] for r in runs])) for k in runs[0]}
-    tot = torch.tensor([med["kept_local"], med["ref_hits_local"]], dtype=torch.float64, device=dev)
-    if dist.get_backend() == "gloo":
-        tc = tot.cpu(); dist.all_reduce(tc); tot = tc
-    else:
-        dist.all_reduce(tot)
     step_ms = med["k3_ms"] + med["dedup_total_ms"] + med["ref_k3_ms"] + med["ref_allgather_ms"] + med["ref_k5_ms"]
+    mine = torch.tensor([step_ms, med["dedup_total_ms"], med["dedup_collectives_ms"], med["ref_k5_ms"], med["local_unique_keys"],
+                         med["slice_keys"], med["ref_table_keys"], med["kept_local"], med["ref_hits_local"]], dtype=torch.float64, device=dev)
+    every = torch.empty((world, mine.numel()), dtype=torch.float64, device=dev)
+    if dist.get_backend() == "gloo":
+        hc, ec = mine.cpu(), every.cpu()
+        dist.all_gather_into_tensor(ec, hc); every = ec
+    else:
+        dist.all_gather_into_tensor(every, mine)
+    every = every.cpu().numpy()
+    step_max = float(every[:, 0].max())
     return {"config": "configs[3] exchange: sharded URL dedup + reference filter, rows sharded contiguously, one all-gather of the "
-                      "locally unique keys (dedup) and one of the reference keys",
-            "rows_per_gpu": rows, "rows_total": N, "world": world, "backend": dist.get_backend(),
+                      "locally unique keys + one all-reduce of verdict bytes (dedup) and one all-gather of the reference keys",
+            "scaling": scaling, "rows_per_gpu": rows, "rows_total": N, "world": world, "backend": dist.get_backend(),
             "stages_ms_rank0": {k: round(v, 3) for k, v in med.items() if k.endswith("_ms")},
-            "allgather_bytes_dedup": int(med["gathered_keys"]) * 16, "local_unique_keys_rank0": int(med["local_unique_keys"]),
-            "kept_rows_total": int(tot[0].item()), "ref_hits_total": int(tot[1].item()),
-            "step_ms_rank0": round(step_ms, 3), "rows_per_s": N / step_ms * 1e3}
+            "allgather_bytes_dedup": int(med["gathered_keys"]) * 16, "allreduce_bytes_dedup": int(med["verdict_bytes"]),
+            "per_rank": [{"rank": r, "step_ms": round(float(e[0]), 3), "dedup_total_ms": round(float(e[1]), 3), "dedup_collectives_ms": round(float(e[2]), 3),
+                          "ref_k5_ms": round(float(e[3]), 3), "local_unique_keys": int(e[4]), "dedup_slice_keys": int(e[5]),
+                          "ref_table_keys": int(e[6])} for r, e in enumerate(every)],
+            "kept_rows_total": int(every[:, 7].sum()), "ref_hits_total": int(every[:, 8].sum()),
+            "step_ms_max_over_ranks": round(step_max, 3), "rows_per_s": N / step_max * 1e3}
 
 
 def main():
@@ -426,7 +439,9 @@ def main():
     ap.add_argument("--dense-steps", type=int, default=10)
     ap.add_argument("--path-rows", type=int, default=300000, help="rows of the CSV path-in / path-out legs (SURVEY §8d region 3; 0 = skip)")
     ap.add_argument("--exchange", type=int, default=1,
-                    help="1 = at N > 1 also time configs[3]'s sharded dedup / reference filter with its all-gathers (after the K steps)")
+                    help="1 = also time configs[3]'s sharded dedup / reference filter with its collectives (after the K steps): weak (rows per GPU as "
+                         "the workload says) at N > 1 or with --workload c4, strong (--strong-rows in total) at every N")
+    ap.add_argument("--strong-rows", type=int, default=100_000_000, help="rows of the fixed table of the strong-scaling exchange (0 = skip)")
     ap.add_argument("--fused-variant", type=int, default=-1, help="A/B only: force a kernel variant of the fused launch (dyd_set_option)")
     args = ap.parse_args()
 
@@ -567,14 +582,17 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     high_rows = main_res["high_rows"]
-    exchange = None
-    if (world > 1 and args.exchange) or args.workload == "c4":      # every rank takes part; rank 0 reports
-        if world == 1 and not dist.is_initialized():                  # c4 on one GPU: a group of one, over RCCL like the real thing
+    exchange, exchange_strong = None, None
+    if args.exchange:                                                # every rank takes part; rank 0 reports
+        if world == 1 and not dist.is_initialized():                  # one GPU: a group of one, over RCCL like the real thing
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group(os.environ.get("DYD_BENCH_BACKEND", "nccl"), rank=0, world_size=1,
-                                    **({"device_id": dev} if os.environ.get("DYD_BENCH_BACKEND", "nccl") == "nccl" else {}))
-        exchange = sharded_dedup(rows, rank, world, dev)
+            backend = os.environ.get("DYD_BENCH_BACKEND", "nccl")
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
+        if world > 1 or args.workload == "c4":
+            exchange = sharded_dedup(rows, rank, world, dev, scaling="weak")
+        if args.strong_rows > 0:                                      # configs[3] as a FIXED table of --strong-rows rows cut into `world` shards
+            exchange_strong = sharded_dedup(args.strong_rows // world, rank, world, dev, reps=2, scaling="strong")
 
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
@@ -603,6 +621,7 @@ def main():
         line["full_pipeline"] = None
         line["dense"] = None
         line["sharded_exchange"] = exchange
+        line["sharded_exchange_strong"] = exchange_strong
         if world == 1:
             if args.pipeline and args.workload == "c3":
                 line["full_pipeline"] = full_pipeline({"N": N, "B": B, "P": P, "label": label, "fused": fused}, dev, L, ck, sp)

@@ -5,11 +5,11 @@ lowest (rank, local index).  The poly->bbox (K1) and IoU (K2) stages are indepen
 need no communication.  The two set-valued stages exchange hashes exactly once:
 
     dedup       K3 hash local rows -> K4 on the shard alone (local keep-mask) -> ONE all-gather of the shard's
-                locally-UNIQUE 16-B keys (RCCL over xGMI; an 8-byte count per rank goes ahead of it) -> K5: a row that
-                survived locally is dropped when its key also occurs on a LOWER rank (keep=first), a HIGHER rank
-                (keep=last) or any other rank (keep=False).  Contiguous shards make "first occurrence" = lowest
-                (rank, local index), so no row index travels, and a rank builds a table of the OTHER ranks' unique
-                keys only — never of all N rows
+                locally-UNIQUE 16-B keys (RCCL over xGMI; an 8-byte count per rank goes ahead of it) -> every rank
+                settles the 1/G slice of the gathered keys whose hash falls to it with K4 (the gathered array is in
+                (rank, row) order, so "first occurrence" inside it is the lowest (rank, local index) and no row index
+                travels) -> the verdicts, one byte per gathered key, are merged with one all-reduce.  A rank inserts
+                ~U/G keys, whatever its place in the row order
     ref filter  K3 hash local main rows and local reference rows -> ONE all-gather of the
                 reference keys -> K5 probe of the local main keys
     split       ONE all-gather of per-rank per-category counts (n_cat x 8 B) -> each rank's
@@ -40,15 +40,6 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple:
     lo = (n * rank) // world
     hi = (n * (rank + 1)) // world
     return lo, hi
-
-
-def shard_bounds_weighted(weight_prefix: np.ndarray, world: int, rank: int) -> tuple:
-    """Contiguous row range with ~equal total weight (e.g. boxes per row): weight_prefix is the
-    inclusive prefix sum of the per-row weights (the box offsets without the leading 0)."""
-    n = len(weight_prefix)
-    total = int(weight_prefix[-1]) if n else 0
-    cut = lambda r: int(np.searchsorted(weight_prefix, total * r / world, side="left")) if r < world else n  # noqa: E731
-    return (0 if rank == 0 else cut(rank)), cut(rank + 1)
 
 
 class HipOps:
@@ -184,12 +175,26 @@ def _local_keys(col, ops, for_isin: bool = False, drop_na: bool = False) -> torc
 
 
 def dedup_keys_sharded(h: torch.Tensor, keep, ops, group=None, timings: dict | None = None) -> torch.Tensor:
-    """Global keep-mask (bool tensor on h's device) of this rank's keys h [n, 2]: local K4, one all-gather of the locally
-    unique keys, K5 probe of the local survivors against the other ranks' keys (see the module docstring)."""
+    """Global keep-mask (bool tensor on h's device) of this rank's keys h [n, 2]: local K4, ONE all-gather of the locally unique
+    keys, then every rank settles a 1/G SLICE of the gathered keys (by hash) with K4 and the verdicts travel back as one byte per
+    gathered key (an all-reduce, a sixteenth of the all-gather's bytes).
+
+    Round 2 let rank r probe its survivors against the keys of the ranks below it: rank G-1 built a table of 7/8 of all unique
+    keys while rank 0 built none, so the stage took as long as its last rank and did not shrink with G.  The gathered array is in
+    (rank, row) order, so "first occurrence" inside any subset of it IS the lowest (rank, local index): K4 with the same ``keep``
+    on the keys of one hash slice, in gathered order, says for every key of the slice whether it survives globally.  Each rank
+    therefore inserts ~U/G keys instead of up to U(G-1)/G."""
     import time as _t
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     local_keep = ops.dedup_local(h, keep).bool()
+    if world == 1:
+        if hasattr(ops, "check_status"):
+            ops.check_status()
+        if timings is not None:
+            timings.update({"collective_s": timings.get("collective_s", 0.0), "gathered_keys": 0, "local_unique_keys": int(local_keep.sum()),
+                            "slice_keys": 0, "verdict_bytes": 0})
+        return local_keep
     uniq_mask = local_keep if keep in ("first", "last") else ops.dedup_local(h, "first").bool()
     uniq = h[uniq_mask].contiguous()                      # one key per distinct local value, in row order
     if timings is not None and h.is_cuda:
@@ -204,16 +209,38 @@ def dedup_keys_sharded(h: torch.Tensor, keep, ops, group=None, timings: dict | N
         timings["local_unique_keys"] = int(uniq.shape[0])
     start = int(sum(counts[:rank]))
     end = start + counts[rank]
-    if keep == "first":
-        others = gathered[:start]
-    elif keep == "last":
-        others = gathered[end:]
+    # this rank's slice of the gathered keys (the hash's first word modulo the world size), settled with K4 in gathered order
+    mine = torch.remainder(gathered[:, 0], world) == rank
+    where = torch.nonzero(mine).reshape(-1)
+    dropped = torch.zeros(gathered.shape[0], dtype=torch.uint8, device=gathered.device)
+    if where.numel():
+        kept = ops.dedup_local(gathered[where].contiguous(), keep).bool()
+        dropped[where] = (~kept).to(torch.uint8)
+    if timings is not None:
+        if h.is_cuda:
+            torch.cuda.synchronize(h.device)
+        timings["slice_keys"] = int(where.numel())
+    t1 = _t.perf_counter()
+    if dropped.is_cuda and dist.get_backend(group) == "gloo":   # one-GPU rehearsal of several ranks: gloo moves host memory
+        host = dropped.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        dropped = host.to(dropped.device)
     else:
-        others = torch.cat([gathered[:start], gathered[end:]]) if world > 1 else gathered[:0]
+        dist.all_reduce(dropped, op=dist.ReduceOp.MAX, group=group)   # the slices are disjoint: MAX just merges them
+    if timings is not None:
+        if h.is_cuda:
+            torch.cuda.synchronize(h.device)
+        timings["collective_s"] = timings.get("collective_s", 0.0) + (_t.perf_counter() - t1)
+        timings["verdict_bytes"] = int(dropped.numel())
     out = local_keep.clone()
-    if others.shape[0] and bool(local_keep.any()):
-        hit = ops.isin(h[local_keep].contiguous(), others.contiguous()).bool()
-        out[local_keep] = ~hit
+    own = dropped[start:end].bool()                       # per locally unique key, in row order
+    if keep in ("first", "last"):
+        out[uniq_mask] = ~own                             # the locally kept rows ARE the locally unique ones
+    else:
+        # keep=False: a locally single key survives only if no other rank holds it; its verdict sits at its first local occurrence
+        first_of = torch.full((h.shape[0],), False, dtype=torch.bool, device=h.device)
+        first_of[uniq_mask] = ~own
+        out = local_keep & first_of
     if hasattr(ops, "check_status"):
         ops.check_status()
     return out

@@ -73,15 +73,9 @@ def test_sharded_steps_match_single_process(world, tmp_path):
 
 
 def test_shard_bounds_cover_and_balance():
-    from deal_yolo_daya_amd.distributed import shard_bounds, shard_bounds_weighted
+    from deal_yolo_daya_amd.distributed import shard_bounds
     for n in (0, 1, 7, 8, 1000003):
         for world in (1, 2, 3, 8):
             b = [shard_bounds(n, world, r) for r in range(world)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
-    w = np.random.default_rng(0).integers(1, 33, size=10000)
-    pre = np.cumsum(w)
-    b = [shard_bounds_weighted(pre, 8, r) for r in range(8)]
-    assert b[0][0] == 0 and b[-1][1] == len(w) and all(b[i][1] == b[i + 1][0] for i in range(7))
-    loads = [w[l:h].sum() for l, h in b]
-    assert max(loads) - min(loads) <= 2 * 32
