@@ -401,13 +401,13 @@ def sharded_dedup(rows, rank, world, dev, reps=3, scaling="weak"):
     step_ms = med["k3_ms"] + med["dedup_total_ms"] + med["ref_k3_ms"] + med["ref_allgather_ms"] + med["ref_k5_ms"]
     mine = torch.tensor([step_ms, med["dedup_total_ms"], med["dedup_collectives_ms"], med["ref_k5_ms"], med["local_unique_keys"],
                          med["slice_keys"], med["ref_table_keys"], med["kept_local"], med["ref_hits_local"]], dtype=torch.float64, device=dev)
-    every = torch.empty((world, mine.numel()), dtype=torch.float64, device=dev)
+    every = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
     if dist.get_backend() == "gloo":
         hc, ec = mine.cpu(), every.cpu()
         dist.all_gather_into_tensor(ec, hc); every = ec
     else:
         dist.all_gather_into_tensor(every, mine)
-    every = every.cpu().numpy()
+    every = every.cpu().numpy().reshape(world, -1)
     step_max = float(every[:, 0].max())
     return {"config": "configs[3] exchange: sharded URL dedup + reference filter, rows sharded contiguously, one all-gather of the "
                       "locally unique keys + one all-reduce of verdict bytes (dedup) and one all-gather of the reference keys",
