@@ -39,6 +39,39 @@ __global__ __launch_bounds__(K0_BLOCK) void k0_stream(const uint4 *__restrict__ 
     if ((MODE == 1 || MODE == 4) && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) dst[0] = acc;
 }
 
+// The fused kernel's stream: 72 % of its bytes are read, 28 % written (16 P + 4 B + 4 N in, 48 B + N out).  modes 10-12 move
+// exactly that mix and nothing else: per iteration a lane issues FIVE 16-byte loads from the read stream before it touches any of
+// them (with 8 workgroups of 256 lanes per CU that is 160 KiB in flight per CU) and TWO 16-byte stores to the write stream —
+// 5 : 2 = 71.4 % : 28.6 %.  mode 10 plain loads and stores, 11 plain loads + non-temporal stores (what k12_wave_kernel does),
+// 12 non-temporal both.  `n16` counts the READ stream's 16-byte units; the write stream gets 2/5 as many.
+template <int MODE>
+__global__ __launch_bounds__(K0_BLOCK) void k0_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * K0_BLOCK;
+    const int64_t groups = n16 / 5;
+    for (int64_t g = (int64_t)blockIdx.x * K0_BLOCK + threadIdx.x; g < groups; g += stride) {
+        uint4 v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {          // lane-contiguous inside every one of the five sub-streams: 256 lanes x 16 B per instruction
+            const uint4 *q = src + (int64_t)k * groups + g;
+            if (MODE == 12) v[k] = make_uint4(__builtin_nontemporal_load(&q->x), __builtin_nontemporal_load(&q->y),
+                                              __builtin_nontemporal_load(&q->z), __builtin_nontemporal_load(&q->w));
+            else v[k] = *q;
+        }
+        const uint4 a = make_uint4(v[0].x ^ v[1].x ^ v[4].x, v[0].y ^ v[1].y ^ v[4].y, v[0].z ^ v[1].z, v[0].w ^ v[1].w);
+        const uint4 b = make_uint4(v[2].x ^ v[3].x ^ v[4].z, v[2].y ^ v[3].y ^ v[4].w, v[2].z ^ v[3].z, v[2].w ^ v[3].w);
+        uint4 *o0 = dst + g, *o1 = dst + groups + g;
+        if (MODE == 10) {
+            *o0 = a;
+            *o1 = b;
+        } else {
+            __builtin_nontemporal_store(a.x, &o0->x); __builtin_nontemporal_store(a.y, &o0->y);
+            __builtin_nontemporal_store(a.z, &o0->z); __builtin_nontemporal_store(a.w, &o0->w);
+            __builtin_nontemporal_store(b.x, &o1->x); __builtin_nontemporal_store(b.y, &o1->y);
+            __builtin_nontemporal_store(b.z, &o1->z); __builtin_nontemporal_store(b.w, &o1->w);
+        }
+    }
+}
+
 // Random-access ceilings for the hash-table and permutation kernels (K4/K5/K6): every lane touches one 8-byte word at a
 // pseudo-random place of a table of 2^k words (a bijective xorshift-multiply mix of the lane's index: every word is hit
 // exactly once, like a permutation).  mode 6: scatter (store), 7: gather (load), 8: atomicMin on the word (K4's insert).
@@ -74,7 +107,21 @@ using namespace dyd;
 
 extern "C" int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream) {
     DYD_API_ENTER();
-    DYD_REQUIRE(mode >= 0 && mode <= 9 && bytes >= 0 && dst, "bad membench arguments");
+    DYD_REQUIRE(mode >= 0 && mode <= 12 && bytes >= 0 && dst, "bad membench arguments");
+    if (mode >= 10) {   // the 5 : 2 read / write mix: `bytes` of src are read, 2/5 of that written to dst
+        const int64_t n16 = bytes / 16;
+        if (n16 < 5) return DYD_OK;
+        DYD_REQUIRE(src != nullptr, "bad membench arguments");
+        if (blocks <= 0) blocks = ctx().num_cu * 8;
+        hipStream_t st = pick_stream(stream);
+        const uint4 *s = static_cast<const uint4 *>(src);
+        uint4 *d = static_cast<uint4 *>(dst);
+        if (mode == 10) hipLaunchKernelGGL(k0_mix<10>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+        else if (mode == 11) hipLaunchKernelGGL(k0_mix<11>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+        else hipLaunchKernelGGL(k0_mix<12>, dim3(blocks), dim3(K0_BLOCK), 0, st, s, d, n16);
+        DYD_HIP(hipGetLastError());
+        return DYD_OK;
+    }
     if (mode >= 6) {   // random access over the largest power-of-two number of 8-byte words in `bytes` of dst
         int k = 0;
         const int64_t word = (mode == 9) ? 4 : 8;

@@ -419,7 +419,9 @@ void dyd_host_free(void *p);
 int dyd_set_option(const char *key, int64_t value);
 /* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 3-5 the same non-temporal, 16 B per
  * lane) used to record the box's HBM ceiling next to the kernels' achieved GB/s; modes 6 / 7 / 8: one 8-byte word per lane
- * at a pseudo-random place of `dst` (scatter / gather / atomicMin, every word once) — the ceiling K4/K5/K6 are quoted against. */
+ * at a pseudo-random place of `dst` (scatter / gather / atomicMin, every word once) — the ceiling K4/K5/K6 are quoted against;
+ * modes 10 / 11 / 12: the fused kernel's 72 % read / 28 % write mix (five 16-byte loads in flight per lane, two 16-byte stores;
+ * plain, non-temporal stores, non-temporal both): `bytes` of src are read, 2/5 of that written to dst. */
 int dyd_membench_dev(int mode, const void *src, void *dst, int64_t bytes, int blocks, void *stream);
 
 #ifdef __cplusplus
