@@ -74,6 +74,9 @@ SIGNATURES = {
     "dyd_dedup": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dyd_dedup_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "dyd_isin": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dyd_dedup_partner": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "dyd_isin_partner": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dyd_host_cells_differ": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dyd_isin_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dyd_dedup_global_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "dyd_mt19937_permutation": (C.c_int, [C.c_uint32, C.c_int64, C.c_void_p]),
@@ -333,6 +336,38 @@ def isin(h: np.ndarray, ref_h: np.ndarray) -> np.ndarray:
     ref_h = np.ascontiguousarray(ref_h, dtype=np.uint64).reshape(-1, 2)
     out = np.empty(len(h), np.uint8)
     check(lib().dyd_isin(_ptr(h), len(h), _ptr(ref_h) if len(ref_h) else None, len(ref_h), _ptr(out)), "dyd_isin")
+    return out
+
+
+def dedup_partner(h: np.ndarray) -> np.ndarray:
+    """per row the first row whose hash equals its own (int64; the row itself for a first occurrence)"""
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty(len(h), np.int64)
+    check(lib().dyd_dedup_partner(_ptr(h), len(h), _ptr(out)), "dyd_dedup_partner")
+    return out
+
+
+def isin_partner(h: np.ndarray, ref_h: np.ndarray) -> np.ndarray:
+    """per main row the reference row whose hash it equals (int64, -1: none)"""
+    h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+    ref_h = np.ascontiguousarray(ref_h, dtype=np.uint64).reshape(-1, 2)
+    out = np.empty(len(h), np.int64)
+    check(lib().dyd_isin_partner(_ptr(h), len(h), _ptr(ref_h) if len(ref_h) else None, len(ref_h), _ptr(out)), "dyd_isin_partner")
+    return out
+
+
+def cells_differ(text_a, off_a, idx_a, text_b, off_b, idx_b, n: int) -> np.ndarray:
+    """uint8 per pair: do the cells a[idx_a[i]] and b[idx_b[i]] (flat utf-8 + int64 offsets) differ?  Pairs with a negative index
+    count as equal.  Host code inside the library, multithreaded; needs no GPU."""
+    text_a = np.ascontiguousarray(text_a, dtype=np.uint8); text_b = np.ascontiguousarray(text_b, dtype=np.uint8)
+    off_a = np.ascontiguousarray(off_a, dtype=np.int64); off_b = np.ascontiguousarray(off_b, dtype=np.int64)
+    idx_a = None if idx_a is None else np.ascontiguousarray(idx_a, dtype=np.int64)
+    idx_b = None if idx_b is None else np.ascontiguousarray(idx_b, dtype=np.int64)
+    out = np.zeros(int(n), np.uint8)
+    if n:
+        load_library().dyd_host_cells_differ(_ptr(text_a) if text_a.size else None, _ptr(off_a), None if idx_a is None else _ptr(idx_a),
+                                             _ptr(text_b) if text_b.size else None, _ptr(off_b), None if idx_b is None else _ptr(idx_b),
+                                             int(n), 0, _ptr(out))
     return out
 
 

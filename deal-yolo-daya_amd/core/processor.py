@@ -260,13 +260,15 @@ def merge_all_csv_in_folder(
 
 
 # =============================================================================== a1  dedup
-def dedup_keep_mask(col: pd.Series, keep="first", backend=None, verify: bool = False) -> np.ndarray:
+def dedup_keep_mask(col: pd.Series, keep="first", backend=None, verify: bool = True) -> np.ndarray:
     """Boolean keep-mask of ``drop_duplicates(keep=keep)`` on one key column: K3 hash, K4 mask.
 
-    Equality is equality of 128-bit hashes (MurmurHash3 x64_128 of the cell's canonical bytes; two different values collide
-    with probability ~1e-23 at 1e8 rows).  ``verify=True`` proves that none did: equal values always hash alike, so the hashes
-    are faithful iff there are exactly as many distinct hashes as distinct values (``Series.nunique``); if not, the mask is
-    recomputed by pandas' own value comparison and VERIFY_EVENTS records it."""
+    Equality on the device is equality of 128-bit hashes (MurmurHash3 x64_128 of the cell's canonical bytes); pandas compares
+    values (:140-144).  ``verify`` (default) proves that the two agree: the device also names, for every row, the first row with
+    the same hash (dyd_dedup_partner), and the host compares the BYTES of each such pair (dyd_host_cells_differ, all cores) —
+    equal bytes for every pair means every hash-equal group is a value-equal group, so the mask is pandas' mask.  A pair that
+    differs (a collision, accidental or crafted) is recorded in VERIFY_EVENTS and the mask is recomputed by pandas' own value
+    comparison.  Costs one more gather per row on the device and one pass over the duplicated rows' bytes on the host."""
     if keep not in ("first", "last", False):
         raise ValueError('keep must be either "first", "last" or False')       # pandas' own message
     be = _backend(backend)
@@ -278,9 +280,21 @@ def dedup_keep_mask(col: pd.Series, keep="first", backend=None, verify: bool = F
         h[na] = _fl.NA_KEY                              # all missing cells are one key (NaN == NaN)
     mask = be.dedup(h, keep).astype(bool)
     if verify:
-        distinct_hashes = int(mask.sum()) if keep in ("first", "last") else int(be.dedup(h, "first").sum())
-        if distinct_hashes != int(col.nunique(dropna=False)):
-            VERIFY_EVENTS.append(("dedup", str(col.name), distinct_hashes))
+        if hasattr(be, "dedup_partner"):
+            from .. import _native
+            partner = be.dedup_partner(h)
+            rows = np.flatnonzero(partner != np.arange(len(partner)))
+            wrong = 0
+            if len(rows):
+                mates = partner[rows]
+                both_na = na[rows] & na[mates]
+                differ = _native.cells_differ(data, off, np.where(both_na, -1, rows), data, off, mates, len(rows)).astype(bool)
+                wrong = int((differ | (na[rows] != na[mates])).sum())
+        else:                                           # a backend without the partner query: count distinct values instead
+            distinct_hashes = int(mask.sum()) if keep in ("first", "last") else int(be.dedup(h, "first").sum())
+            wrong = abs(distinct_hashes - int(col.nunique(dropna=False)))
+        if wrong:
+            VERIFY_EVENTS.append(("dedup", str(col.name), wrong))
             mask = ~col.duplicated(keep=keep).to_numpy()
     return mask
 
@@ -347,11 +361,12 @@ def deduplicate_csv_by_source(
 
 
 # =============================================================================== a2  reference filter
-def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None, verify: bool = False) -> np.ndarray:
+def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None, verify: bool = True) -> np.ndarray:
     """``main.astype(str).isin(set(ref.dropna().astype(str)))`` (:194-198): K3 on both, K5.
 
-    ``verify=True``: a value of the reference set always hits (equal strings hash alike), so only a HIT can be wrong; the
-    hit rows are re-checked by value against the reference strings (pandas' isin on that subset)."""
+    ``verify`` (default): a value of the reference set always hits (equal strings hash alike), so only a HIT can be wrong; the
+    device names the reference row every hit matched (dyd_isin_partner) and the host compares the two cells' bytes.  Hits whose
+    bytes differ are re-checked by value against the reference strings (pandas' isin on those rows) and recorded in VERIFY_EVENTS."""
     be = _backend(backend)
     if len(main_col) == 0:
         return np.zeros(0, bool)
@@ -362,10 +377,17 @@ def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None, verify: 
     hit = be.isin(hm, hr).astype(bool)
     if verify and hit.any():
         rows = np.flatnonzero(hit)
-        true_hit = main_col.iloc[rows].astype(str).isin(set(ref_col.dropna().astype(str))).to_numpy()
-        if not true_hit.all():
-            VERIFY_EVENTS.append(("ref_filter", str(main_col.name), int((~true_hit).sum())))
-            hit[rows[~true_hit]] = False
+        if hasattr(be, "isin_partner"):
+            from .. import _native
+            mates = be.isin_partner(hm, hr)[rows]
+            suspect = rows[_native.cells_differ(md, mo, rows, rd, ro, mates, len(rows)).astype(bool) | (mates < 0)]
+        else:
+            suspect = rows
+        if len(suspect):
+            true_hit = main_col.iloc[suspect].astype(str).isin(set(ref_col.dropna().astype(str))).to_numpy()
+            if hasattr(be, "isin_partner") or not true_hit.all():
+                VERIFY_EVENTS.append(("ref_filter", str(main_col.name), int(len(suspect) if hasattr(be, "isin_partner") else (~true_hit).sum())))
+            hit[suspect[~true_hit]] = False
     return hit
 
 

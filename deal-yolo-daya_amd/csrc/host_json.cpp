@@ -2780,3 +2780,36 @@ const uint8_t *dyd_scan_sel(const dyd_scan *h) { return h->sel.data(); }
 
 }  // extern "C"
 
+
+// ===================================================================================================
+// verification of hash equality (dedup / reference filter): the bytes of matched cells
+// ===================================================================================================
+extern "C" {
+
+// cells a[i] = text_a[off_a[ia]..off_a[ia + 1]) with ia = idx_a ? idx_a[i] : i, likewise b; a pair with a negative index is skipped.
+// out_first_mismatch: the smallest i whose cells differ (-1: all pairs are equal); returns the number of differing pairs.
+int64_t dyd_host_cells_differ(const uint8_t *text_a, const int64_t *off_a, const int64_t *idx_a, const uint8_t *text_b, const int64_t *off_b,
+                              const int64_t *idx_b, int64_t n, int n_threads, uint8_t *out_differs_or_null) {
+    if (n <= 0 || !off_a || !off_b) return 0;
+    if (n_threads <= 0) n_threads = default_threads();
+    std::vector<int64_t> bad((size_t)std::max(1, std::min(n_threads, 64)), 0);
+    parallel_cells(n, (int)bad.size(), [&](int t, int64_t lo, int64_t hi) {
+        int64_t count = 0;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t ia = idx_a ? idx_a[i] : i, ib = idx_b ? idx_b[i] : i;
+            uint8_t d = 0;
+            if (ia >= 0 && ib >= 0) {
+                const int64_t la = off_a[ia + 1] - off_a[ia], lb = off_b[ib + 1] - off_b[ib];
+                d = (la != lb || (la > 0 && memcmp(text_a + off_a[ia], text_b + off_b[ib], (size_t)la) != 0)) ? 1 : 0;
+            }
+            if (out_differs_or_null) out_differs_or_null[i] = d;
+            count += d;
+        }
+        bad[(size_t)t] += count;
+    });
+    int64_t total = 0;
+    for (int64_t c : bad) total += c;
+    return total;
+}
+
+}  // extern "C"

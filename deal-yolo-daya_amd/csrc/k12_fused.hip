@@ -234,10 +234,10 @@ void set_k7_trace(void *p);
 int set_k2s_debug(void *p);
 #endif
 
-// -1 = auto (by mean boxes per row), 0 = fused <2048,16,256>, 1 = K1 launch then K2 launch,
-// 2 = fused <1024,8,128>, 3 = fused <1024,16,256>, 4 = wave-autonomous fused (LDS hand-off),
-// 5 / 6 = variants 0 / 2 with the f32 reject filter in K2 (k2_filter.h), 9 = fused <1024,8,256> with the filter (rows of up to
-// 256 boxes fit the K2 tile and are swept in x1 order, k2_sweep.h), 10 = the wave kernel's DENSE instantiation (k12_wave.h)
+// -1 = by the table's shape (below); 1 = K1 launch then K2 launch (polygons of 48 points and more), 4 = wave-autonomous fused
+// kernel (LDS hand-off; up to 32 boxes per image on average), 10 = its DENSE instantiation (rows of 40..256 boxes sorted and swept,
+// k2_sweep.h), 6 / 9 = workgroup-level fusion <1024,8,128> / <1024,8,256> with the f32 reject filter (polygons of 20..48 points).
+// The other tilings of rounds 1-2 (0, 2, 3, 5 and the 1- and 2-wave workgroups 7, 8) were A/B residue and are gone.
 static int g_fused_variant = -1;
 
 }  // namespace dyd
@@ -298,9 +298,8 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
         if (!rcb) release_bigq(st);
         return rcb;
     }
-    if (v == 4 || v == 7 || v == 8) {
-        const int wpb = (v == 4) ? 4 : (v == 7 ? 1 : 2);   // A/B: 1, 2 and 4 waves per workgroup time the same (0.598 ms back to back)
-        int64_t blocks = ceil_div(n_rows, (int64_t)wpb * KW_ROWS);
+    if (v == 4) {
+        int64_t blocks = ceil_div(n_rows, (int64_t)4 * KW_ROWS);   // 4 waves per workgroup (1, 2 and 4 time the same: 0.598 ms back to back at 1 M rows)
 #ifdef K12_XCD_REMAP
         blocks = ceil_div(blocks, 8) * 8;   // the grid is a multiple of 8: workgroups beyond the table leave at once
 #endif
@@ -308,34 +307,23 @@ int dyd_bbox_iou_fused_dev(const double *xy, const int32_t *pt_off, const int32_
             set_error("n_rows=%lld exceeds one launch", (long long)n_rows);
             return DYD_ERR_RANGE;
         }
-        const double2 *xy2 = reinterpret_cast<const double2 *>(xy);
-        if (wpb == 4)
-            hipLaunchKernelGGL(k12_wave_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
-                               thr, out_box4, out_arg4, out_high, bigq);
-        else if (wpb == 2)
-            hipLaunchKernelGGL(k12_wave_kernel<2>, dim3((unsigned)blocks), dim3(128), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
-                               thr, out_box4, out_arg4, out_high, bigq);
-        else
-            hipLaunchKernelGGL(k12_wave_kernel<1>, dim3((unsigned)blocks), dim3(64), 0, st, xy2, pt_off, box_off, n_rows, min_boxes,
-                               thr, out_box4, out_arg4, out_high, bigq);
+        hipLaunchKernelGGL(k12_wave_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const double2 *>(xy), pt_off, box_off,
+                           n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq);
         DYD_HIP(hipGetLastError());
         const int rcb = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
         if (!rcb) release_bigq(st);
         return rcb;
     }
     int rc;
-    if (v == 5)
-        rc = launch_fused<2048, 16, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
+    if (v == 9)
+        rc = launch_fused<1024, 8, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
     else if (v == 6)
         rc = launch_fused<1024, 8, 128, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
-    else if (v == 9)
-        rc = launch_fused<1024, 8, 256, true>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
-    else if (v == 2)
-        rc = launch_fused<1024, 8, 128>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
-    else if (v == 3)
-        rc = launch_fused<1024, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
-    else
-        rc = launch_fused<2048, 16, 256>(xy, pt_off, box_off, n_rows, min_boxes, thr, out_box4, out_arg4, out_high, bigq, st);
+    else {
+        release_bigq(st);
+        set_error("invalid argument: fused_variant %d does not exist (1, 4, 6, 9, 10 or -1)", v);
+        return DYD_ERR_INVALID;
+    }
     if (!rc) rc = launch_k2_big_rows(out_box4, box_off, bigq, min_boxes, thr, out_high, nullptr, st);
     if (rc) return rc;
     release_bigq(st);

@@ -149,6 +149,43 @@ __global__ __launch_bounds__(K4_BLOCK) void k5_probe(const ulonglong2 *__restric
     out_mask[i] = found;
 }
 
+// ---- who stands for whom (verification of hash equality) ------------------------------------------------------------------
+// Equality in K4 / K5 is equality of 128-bit hashes.  To PROVE that it was equality of values the host compares the bytes of
+// every row that was matched with the bytes of the row it was matched to — which needs that row's index, not just the flag:
+// k4_partner walks the (keep=first) table by key and writes the FIRST row holding the same hash (the row itself for a first
+// occurrence), k5_partner the reference row a main row hit (-1: no hit).  One extra gather per row; run only when asked for.
+__global__ __launch_bounds__(K4_BLOCK) void k4_partner(const ulonglong2 *__restrict__ keys, int64_t n, const long long *__restrict__ tab,
+                                                       uint64_t mask, long long *__restrict__ out_partner, int *err) {
+    const int64_t i = (int64_t)blockIdx.x * K4_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong2 k = keys[i];
+    uint64_t slot = k.x & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        const long long cur = tab[slot];
+        if (cur == K4_EMPTY) break;
+        if (key_eq(keys[cur], k)) { out_partner[i] = cur; return; }
+        slot = (slot + 1) & mask;
+    }
+    out_partner[i] = -1;
+    atomicOr(err, 2);  // a key that was inserted must be found
+}
+
+__global__ __launch_bounds__(K4_BLOCK) void k5_partner(const ulonglong2 *__restrict__ keys, int64_t n, const ulonglong2 *__restrict__ ref_keys,
+                                                       const long long *__restrict__ tab, uint64_t mask, long long *__restrict__ out_partner) {
+    const int64_t i = (int64_t)blockIdx.x * K4_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong2 k = keys[i];
+    uint64_t slot = k.x & mask;
+    long long found = -1;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        const long long cur = tab[slot];
+        if (cur == K4_EMPTY) break;
+        if (key_eq(ref_keys[cur], k)) { found = cur; break; }
+        slot = (slot + 1) & mask;
+    }
+    out_partner[i] = found;
+}
+
 // dyd_set_option("k4_capacity_shift", k): the table is made 2^k times SMALLER than it should be — only so that a test can
 // watch the failure path (a full table must surface as an error, never as a wrong mask)
 static int g_k4_capacity_shift = 0;
@@ -207,6 +244,47 @@ static int isin_launch(const uint64_t *h, int64_t n, const uint64_t *ref_h, int6
     DYD_HIP(hipGetLastError());
     hipLaunchKernelGGL(k5_probe, dim3((unsigned)ceil_div(n, K4_BLOCK)), dim3(K4_BLOCK), 0, st,
                        reinterpret_cast<const ulonglong2 *>(h), n, rk, tab, cap - 1, out_mask);
+    DYD_HIP(hipGetLastError());
+    release_scratch(st);
+    return DYD_OK;
+}
+
+static int dedup_partner_launch(const uint64_t *h, int64_t n, long long *out_partner, hipStream_t st) {
+    const uint64_t cap = table_capacity(n);
+    void *scr = nullptr;
+    int rc = get_scratch(cap * 8 + 16, &scr, st);
+    if (rc) return rc;
+    long long *tab = static_cast<long long *>(scr);
+    int *err = ctx().dev_status;
+    DYD_HIP(hipMemsetAsync(tab, 0xFF, cap * 8, st));
+    const ulonglong2 *keys = reinterpret_cast<const ulonglong2 *>(h);
+    hipLaunchKernelGGL(k4_insert, dim3((unsigned)ceil_div(n, K4_BLOCK)), dim3(K4_BLOCK), 0, st, keys, n, tab, (unsigned int *)nullptr, cap - 1,
+                       DYD_KEEP_FIRST, err);
+    DYD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k4_partner, dim3((unsigned)ceil_div(n, K4_BLOCK)), dim3(K4_BLOCK), 0, st, keys, n, tab, cap - 1, out_partner, err);
+    DYD_HIP(hipGetLastError());
+    release_scratch(st);
+    return DYD_OK;
+}
+
+static int isin_partner_launch(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, long long *out_partner, hipStream_t st) {
+    if (r == 0) {
+        DYD_HIP(hipMemsetAsync(out_partner, 0xFF, 8 * (size_t)n, st));
+        return DYD_OK;
+    }
+    const uint64_t cap = table_capacity(2 * r);
+    void *scr = nullptr;
+    int rc = get_scratch(cap * 8 + 16, &scr, st);
+    if (rc) return rc;
+    long long *tab = static_cast<long long *>(scr);
+    int *err = ctx().dev_status;
+    DYD_HIP(hipMemsetAsync(tab, 0xFF, cap * 8, st));
+    const ulonglong2 *rk = reinterpret_cast<const ulonglong2 *>(ref_h);
+    hipLaunchKernelGGL(k4_insert, dim3((unsigned)ceil_div(r, K4_BLOCK)), dim3(K4_BLOCK), 0, st, rk, r, tab, (unsigned int *)nullptr, cap - 1,
+                       DYD_KEEP_FIRST, err);
+    DYD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k5_partner, dim3((unsigned)ceil_div(n, K4_BLOCK)), dim3(K4_BLOCK), 0, st, reinterpret_cast<const ulonglong2 *>(h), n, rk, tab,
+                       cap - 1, out_partner);
     DYD_HIP(hipGetLastError());
     release_scratch(st);
     return DYD_OK;
@@ -294,6 +372,43 @@ int dyd_isin(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, uin
     t.finish();
     DYD_HIP(hipMemcpyAsync(out_mask, d_m.p, (size_t)n, hipMemcpyDeviceToHost, st));
     return take_device_status(st, "dyd_isin");
+}
+
+
+// Host-pointer entries for the verification of hash equality: out_partner[i] = the first row whose hash equals row i's (i itself
+// for a first occurrence) / the reference row main row i hit (-1: none).  The caller compares the bytes of the pairs.
+int dyd_dedup_partner(const uint64_t *h, int64_t n, int64_t *out_partner) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(h && out_partner, "null pointer");
+    DYD_REQUIRE(n < (1LL << 38), "n too large");
+    DevBuf d_h, d_p;
+    int rc;
+    if ((rc = d_h.alloc(16 * (size_t)n)) || (rc = d_p.alloc(8 * (size_t)n))) return rc;
+    hipStream_t st = ctx().stream;
+    DYD_HIP(hipMemcpyAsync(d_h.p, h, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    rc = dedup_partner_launch(d_h.as<uint64_t>(), n, d_p.as<long long>(), st);
+    if (rc) return rc;
+    DYD_HIP(hipMemcpyAsync(out_partner, d_p.p, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    return take_device_status(st, "dyd_dedup_partner");
+}
+
+int dyd_isin_partner(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, int64_t *out_partner) {
+    DYD_API_ENTER();
+    DYD_REQUIRE(n >= 0 && r >= 0, "negative size");
+    if (n == 0) return DYD_OK;
+    DYD_REQUIRE(h && out_partner && (r == 0 || ref_h), "null pointer");
+    DevBuf d_h, d_r, d_p;
+    int rc;
+    if ((rc = d_h.alloc(16 * (size_t)n)) || (rc = d_r.alloc(16 * (size_t)r)) || (rc = d_p.alloc(8 * (size_t)n))) return rc;
+    hipStream_t st = ctx().stream;
+    DYD_HIP(hipMemcpyAsync(d_h.p, h, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (r) DYD_HIP(hipMemcpyAsync(d_r.p, ref_h, 16 * (size_t)r, hipMemcpyHostToDevice, st));
+    rc = isin_partner_launch(d_h.as<uint64_t>(), n, d_r.as<uint64_t>(), r, d_p.as<long long>(), st);
+    if (rc) return rc;
+    DYD_HIP(hipMemcpyAsync(out_partner, d_p.p, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    return take_device_status(st, "dyd_isin_partner");
 }
 
 }  // extern "C"

@@ -155,6 +155,16 @@ int dyd_dedup_dev(const uint64_t *h, int64_t n, int keep_mode, uint8_t *out_keep
  * Replaces Series.isin(ref_values) (processor.py:194-199). out_mask[i] = 1 iff h[i] is
  * one of the r reference keys. */
 int dyd_isin(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, uint8_t *out_mask);
+/* Verification of hash equality.  K4 / K5 call two cells equal when their 128-bit hashes are; pandas compares values
+ * (processor.py:140-144, :198).  out_partner[i] = the first row whose hash equals row i's (i itself for a first occurrence) /
+ * the reference row that main row i hit (-1: no hit); the host then compares the BYTES of every such pair
+ * (dyd_host_cells_differ, multithreaded host code: cells given as flat text + offsets, optionally through index arrays; pairs with
+ * a negative index are skipped; returns the number of pairs that differ, out_differs marks them) — zero means every match was a
+ * match of values.  One extra gather per row on the device; the step functions do this by default (verify=True). */
+int dyd_dedup_partner(const uint64_t *h, int64_t n, int64_t *out_partner);
+int dyd_isin_partner(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r, int64_t *out_partner);
+int64_t dyd_host_cells_differ(const uint8_t *text_a, const int64_t *off_a, const int64_t *idx_a, const uint8_t *text_b, const int64_t *off_b,
+                              const int64_t *idx_b, int64_t n, int n_threads, uint8_t *out_differs_or_null);
 int dyd_isin_dev(const uint64_t *h, int64_t n, const uint64_t *ref_h, int64_t r,
                  uint8_t *out_mask, void *stream);
 
@@ -414,7 +424,7 @@ void dyd_host_free(void *p);
  * e.g. dyd_set_option("k1_variant", 1) = K1 without LDS staging; "k7_variant": -1 by the table's shape (default),
  * 2 / 22 row tiles (one / two per ticket), 30 box tiles (rows of many boxes); "fused_variant": -1 by the table's shape (default:
  * 4 up to 32 boxes per image on average, 10 beyond, 6 / 9 for polygons of 20..48 points), 4 = wave kernel, 10 = its dense
- * instantiation (rows of 40..256 boxes sorted and swept), 0 / 2 / 3 / 5 / 6 / 9 = workgroup tilings, 1 = two launches;
+ * instantiation (rows of 40..256 boxes sorted and swept), 6 / 9 = workgroup tilings, 1 = two launches;
  * "k2_variant": -1 by shape, 4 = the wave kernel's pair stage, 0..3 / 5 = tile kernels (2 / 3 / 5 with the f32 filter and the sweep). */
 int dyd_set_option(const char *key, int64_t value);
 /* measurement aid: plain streaming kernel (mode 0 copy, 1 read-only, 2 write-only, 3-5 the same non-temporal, 16 B per

@@ -34,6 +34,20 @@ class OracleBackend:
     def isin(self, h, ref_h):
         return olib.isin(h, ref_h)
 
+    def dedup_partner(self, h):
+        """first row with the same 128-bit key, per row (numpy; what dyd_dedup_partner computes on the device)"""
+        keys = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2).view([("a", np.uint64), ("b", np.uint64)]).reshape(-1)
+        _, first, inverse = np.unique(keys, return_index=True, return_inverse=True)
+        return first[inverse].astype(np.int64)
+
+    def isin_partner(self, h, ref_h):
+        h = np.ascontiguousarray(h, dtype=np.uint64).reshape(-1, 2)
+        ref_h = np.ascontiguousarray(ref_h, dtype=np.uint64).reshape(-1, 2)
+        table = {}
+        for j, k in enumerate(map(tuple, ref_h.tolist())):
+            table.setdefault(k, j)
+        return np.asarray([table.get(k, -1) for k in map(tuple, h.tolist())], np.int64)
+
     def mt19937_permutation(self, seed, n):
         return olib.mt19937_permutation(seed, n)
 

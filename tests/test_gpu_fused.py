@@ -31,7 +31,7 @@ def _table(rng, n_rows, max_boxes, max_pts, special):
                                                               (65, 32, 12, True), (3000, 32, 12, True),
                                                               (700, 90, 30, False), (50, 300, 6, False),
                                                               (20, 4, 900, True)])
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [-1, 1, 4, 6, 9, 10])
 def test_fused_matches_oracle(native, n_rows, max_boxes, max_pts, special, variant):
     import torch
 
@@ -81,7 +81,7 @@ def _chain_table(rng, n_rows, max_boxes, empty_share):
 
 @pytest.mark.parametrize("n_rows,max_boxes,share", [(400, 6, 0.3), (3000, 32, 0.05), (300, 64, 0.02), (40, 200, 0.01), (6, 700, 0.003),
                                                     (50, 5, 1.0)])
-@pytest.mark.parametrize("variant", [-1, 0, 1, 4, 6, 7, 9, 10])
+@pytest.mark.parametrize("variant", [-1, 1, 4, 6, 9, 10])
 def test_fused_ends_a_row_at_its_first_empty_polygon(native, n_rows, max_boxes, share, variant):
     """[A, null, A] is not HIGH, [A, A, null] is (reference processor.py:254-255 -> :364-365): every fused variant, rows below
     and above the 64 boxes of a wave tile, through the host-pointer entry"""
@@ -103,7 +103,7 @@ def test_fused_ends_a_row_at_its_first_empty_polygon(native, n_rows, max_boxes, 
     assert plain_differs or share == 1.0, "the table must tell the chain from K2-on-K1's-boxes"
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 4, 6, 10])
+@pytest.mark.parametrize("variant", [-1, 4, 6, 9, 10])
 def test_rows_of_thousands_of_boxes_through_the_device_entries(native, variant):
     """a 5000-box row, a 700-box row with an empty polygon in its middle and one of 300 boxes among ordinary rows, device
     resident: the main kernel queues them and k2_big_rows_kernel spreads them over the grid (csrc/k2_wave.h) — same flags as

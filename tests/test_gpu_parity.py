@@ -555,3 +555,43 @@ def test_arrow_backed_bbox_column_holds_the_same_values(native):
     assert ka[P.BBOX_COL].dropna().tolist() == ko[P.BBOX_COL].dropna().tolist()
     assert ha["source"].tolist() == ho["source"].tolist() and len(ha) + len(oa) == len(ka)
     assert ka.to_csv(index=False) == ko.to_csv(index=False)
+
+
+def test_partner_queries_and_the_default_verification(native):
+    """dyd_dedup_partner / dyd_isin_partner (who was matched to whom) against numpy, and the step functions' default verification on
+    the device path: a doctored hash that makes two different URLs collide must not cost a row"""
+    import pandas as pd
+    from helpers import OracleBackend
+    from deal_yolo_daya_amd.core import processor as P
+    rng = np.random.default_rng(77)
+    for n in (1, 5, 4097, 300_000):
+        h = rng.integers(0, 2 ** 63, size=(n, 2)).astype(np.uint64)
+        h[rng.integers(0, n, n // 2)] = h[rng.integers(0, n, n // 2)]                  # many duplicates
+        h[:, 0] &= np.uint64(0xffff) if n > 1000 else np.uint64(0xffffffffffffffff)       # crowded slots
+        assert np.array_equal(native.dedup_partner(h), OracleBackend().dedup_partner(h)), n
+        ref = np.concatenate([h[rng.integers(0, n, max(1, n // 3))], rng.integers(0, 2 ** 63, size=(7, 2)).astype(np.uint64)])
+        got = native.isin_partner(h, ref)
+        hit = native.isin(h, ref).astype(bool)
+        assert np.array_equal(got >= 0, hit) and np.array_equal(ref[got[hit]], h[hit]), n
+    assert native.isin_partner(h, np.zeros((0, 2), np.uint64)).tolist() == [-1] * len(h)
+
+    class Colliding:
+        def __getattr__(self, name):
+            return getattr(native, name)
+
+        def hash128(self, data, off):
+            out = native.hash128(data, off)
+            if len(out) > 1:
+                out[1] = out[0]
+            return out
+
+    urls = pd.Series([f"http://img.example/{k % 5000}.jpg" for k in range(20_000)] + [None], name="source")
+    P.VERIFY_EVENTS.clear()
+    assert np.array_equal(P.dedup_keep_mask(urls, "first"), ~urls.duplicated(keep="first").to_numpy()) and not P.VERIFY_EVENTS
+    assert not P.dedup_keep_mask(urls, "first", Colliding(), verify=False)[1]
+    assert np.array_equal(P.dedup_keep_mask(urls, "first", Colliding()), ~urls.duplicated(keep="first").to_numpy()) and len(P.VERIFY_EVENTS) == 1
+    ref = pd.Series(["http://img.example/0.jpg", "http://img.example/77.jpg"], name="source")
+    want = urls.astype(str).isin(set(ref.astype(str))).to_numpy()
+    assert np.array_equal(P.ref_hit_mask(urls, ref), want) and len(P.VERIFY_EVENTS) == 1
+    assert np.array_equal(P.ref_hit_mask(urls, ref, Colliding()), want) and len(P.VERIFY_EVENTS) == 2
+    P.VERIFY_EVENTS.clear()

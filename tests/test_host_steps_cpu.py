@@ -365,15 +365,15 @@ def test_key_columns_of_any_hashable_match_pandas(oracle_backend):
         col = pd.Series(vals, dtype=object, name="source")
         for keep in ("first", "last", False):
             want = ~col.duplicated(keep=keep).to_numpy()
-            assert np.array_equal(P.dedup_keep_mask(col, keep, oracle_backend), want), (vals, keep)
-            assert np.array_equal(P.dedup_keep_mask(col, keep, oracle_backend, verify=True), want), (vals, keep)
+            assert np.array_equal(P.dedup_keep_mask(col, keep, oracle_backend, verify=False), want), (vals, keep)
+            assert np.array_equal(P.dedup_keep_mask(col, keep, oracle_backend), want), (vals, keep)       # verify is the default
     with pytest.raises(TypeError):
         P.dedup_keep_mask(pd.Series(["a", [1, 2]], dtype=object, name="source"), "first", oracle_backend)
 
 
 def test_verify_mode_catches_a_hash_collision(oracle_backend):
-    """a backend whose hash maps two different URLs to one key: without verify the second row is dropped, with verify the
-    collision is detected (fewer distinct hashes than distinct values) and the exact masks come back"""
+    """a backend whose hash maps two different URLs to one key: without verify the second row is dropped, with verify (the
+    default) the collision is detected — the bytes of a row and of the row it was matched to differ — and the exact masks come back"""
     class Colliding:
         def __getattr__(self, name):
             return getattr(oracle_backend, name)
@@ -385,11 +385,15 @@ def test_verify_mode_catches_a_hash_collision(oracle_backend):
 
     main = pd.Series(["http://a/1.jpg", "http://a/2.jpg", "http://a/3.jpg", "http://a/1.jpg"], name="source")
     be = Colliding()
-    assert P.dedup_keep_mask(main, "first", be).tolist() == [True, False, True, False]           # the collision swallowed row 1
+    assert P.dedup_keep_mask(main, "first", be, verify=False).tolist() == [True, False, True, False]   # the collision swallowed row 1
     P.VERIFY_EVENTS.clear()
-    assert P.dedup_keep_mask(main, "first", be, verify=True).tolist() == [True, True, True, False]
-    assert P.dedup_keep_mask(main, False, be, verify=True).tolist() == [False, True, True, False]
+    assert P.dedup_keep_mask(main, "first", be).tolist() == [True, True, True, False]
+    assert P.dedup_keep_mask(main, False, be).tolist() == [False, True, True, False]
     assert len(P.VERIFY_EVENTS) == 2 and P.VERIFY_EVENTS[0][0] == "dedup"
+    assert P.dedup_frame(pd.DataFrame({"source": main}), "first", be)["source"].tolist() == main.tolist()[:3]
+    P.VERIFY_EVENTS.clear()
+    clean = pd.Series([f"http://a/{k % 700}.jpg" for k in range(3000)] + [None, None], name="source")
+    assert np.array_equal(P.dedup_keep_mask(clean, "last", oracle_backend), ~clean.duplicated(keep="last").to_numpy()) and not P.VERIFY_EVENTS
     ref = pd.Series(["http://a/1.jpg"], name="source")
 
     class CollidingRef(Colliding):
@@ -399,8 +403,13 @@ def test_verify_mode_catches_a_hash_collision(oracle_backend):
                 h[1] = h[0]
             return h
 
-    assert P.ref_hit_mask(main, ref, CollidingRef()).tolist() == [True, True, False, True]
-    assert P.ref_hit_mask(main, ref, CollidingRef(), verify=True).tolist() == [True, False, False, True]
+    assert P.ref_hit_mask(main, ref, CollidingRef(), verify=False).tolist() == [True, True, False, True]
+    assert P.ref_hit_mask(main, ref, CollidingRef()).tolist() == [True, False, False, True]
+    assert P.VERIFY_EVENTS and P.VERIFY_EVENTS[-1][0] == "ref_filter"
+    P.VERIFY_EVENTS.clear()
+    ref2 = pd.Series(["http://a/5.jpg", None, "nan", "None", "http://a/699.jpg"])
+    want = clean.astype(str).isin(set(ref2.dropna().astype(str))).to_numpy()
+    assert np.array_equal(P.ref_hit_mask(clean, ref2, oracle_backend), want) and want.sum() == 11 and not P.VERIFY_EVENTS
 
 
 def test_the_iou_step_takes_the_table_the_replace_step_parked(oracle_backend, tmp_path, monkeypatch):

@@ -136,24 +136,15 @@ def main():
         k12_bytes = 16 * P + 4 * (B + 1) + 48 * B + 4 * (N + 1) + N
         res = {}
         for rnd in range(2):
-            for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+            for variant in (1, 4, 6, 9, 10):
                 ck(L.dyd_set_option(b"fused_variant", variant), "opt")
                 med, mn = timeit(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(),
                                                                       N, B, P, 2, 0.98, out_box.data_ptr(), out_arg.data_ptr(),
                                                                       out_high.data_ptr(), sp), "k12"))
                 res.setdefault(variant, []).append((med, mn))
-        b2b = []
-        names = {4: "4 waves/wg (default)", 8: "2 waves/wg", 7: "1 wave/wg"}
-        for variant in (4, 8, 7, 4):   # interleaved, in one process: box-to-box variance is larger than the differences
-            ck(L.dyd_set_option(b"fused_variant", variant), "opt")
-            ms = timeit_b2b(lambda: ck(L.dyd_bbox_iou_fused_dev(xy.data_ptr(), pt_off.data_ptr(), box_off.data_ptr(), N, B, P, 2, 0.98,
-                                                                out_box.data_ptr(), out_arg.data_ptr(), out_high.data_ptr(), sp), "k12"))
-            b2b.append([names[variant], round(ms, 4)])
-        print(json.dumps({"k12_wave_back_to_back_ms": b2b}), flush=True)
         ck(L.dyd_set_option(b"fused_variant", -1), "opt")
-        for variant, name in ((0, "k12_fused<2048,16,256>"), (2, "k12_fused<1024,8,128>"), (3, "k12_fused<1024,16,256>"),
-                              (4, "k12_wave_kernel"), (8, "k12_wave_kernel, 2 waves per workgroup"), (7, "k12_wave_kernel, 1 wave per workgroup"), (5, "k12_fused<2048,16,256,filter>"), (6, "k12_fused<1024,8,128,filter>"),
-                              (1, "k1_then_k2_two_launches")):
+        for variant, name in ((4, "k12_wave_kernel"), (10, "k12_wave_dense_kernel"), (6, "k12_fused<1024,8,128,filter>"),
+                              (9, "k12_fused<1024,8,256,filter>"), (1, "k1_then_k2_two_launches")):
             med = float(np.median([r[0] for r in res[variant]])); mn = min(r[1] for r in res[variant])
             report(name, k12_bytes, med, mn, rows_per_s=round(N / med * 1e3), high=int(out_high.sum().item()))
 
