@@ -581,7 +581,7 @@ def test_partner_queries_and_the_default_verification(native):
 
         def hash128(self, data, off):
             out = native.hash128(data, off)
-            if len(out) > 1:
+            if len(out) > 2:                      # the main column only: rows 0 and 1 collide
                 out[1] = out[0]
             return out
 
