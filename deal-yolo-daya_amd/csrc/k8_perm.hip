@@ -220,96 +220,6 @@ __device__ __forceinline__ uint32_t k8_classify(uint32_t dt, uint32_t t, uint32_
     const uint32_t v = dt & m;
     return v <= i_lo ? 1u : (v > i_hi ? 0u : 2u);
 }
-// one scan instead of a scan and a compaction: the certain acceptances in the low word, the uncertain draws in the high word; the
-// output side stores the base count of every draw and, for an uncertain draw, its position at its rank in the list
-struct K8Packed {
-    const uint32_t *d, *c0;
-    uint32_t n;
-    __device__ __forceinline__ unsigned long long operator()(uint32_t t) const {
-        const uint32_t k = k8_classify(d[t], t, c0[t], n);
-        return k == 1u ? 1ull : (k == 2u ? (1ull << 32) : 0ull);
-    }
-};
-struct K8SplitOut {
-    uint32_t *base, *pos_u;
-    const uint32_t *d, *c0;
-    uint32_t *total;        // [0] = number of uncertain draws (written by the last draw's store)
-    uint32_t n, cap, last_t, t0;
-    struct Ref {
-        uint32_t *base, *pos_u;
-        const uint32_t *d, *c0;
-        uint32_t *total;
-        uint32_t n, cap, last_t, t;
-        __device__ __forceinline__ Ref &operator=(unsigned long long v) {
-            base[t] = (uint32_t)v;
-            const uint32_t rank = (uint32_t)(v >> 32);
-            const bool unc = k8_classify(d[t], t, c0[t], n) == 2u;
-            if (unc && rank < cap) pos_u[rank] = t;
-            if (t == last_t) *total = rank + (unc ? 1u : 0u);
-            return *this;
-        }
-    };
-    using iterator_category = std::random_access_iterator_tag;
-    using value_type = unsigned long long;
-    using difference_type = std::ptrdiff_t;
-    using pointer = unsigned long long *;
-    using reference = Ref;
-    __host__ __device__ Ref operator[](difference_type i) const { return Ref{base, pos_u, d, c0, total, n, cap, last_t, t0 + (uint32_t)i}; }
-    __host__ __device__ Ref operator*() const { return (*this)[0]; }
-    __host__ __device__ K8SplitOut operator+(difference_type i) const { K8SplitOut r = *this; r.t0 += (uint32_t)i; return r; }
-    __host__ __device__ K8SplitOut &operator+=(difference_type i) { t0 += (uint32_t)i; return *this; }
-};
-struct K8FlagU {           // the recurrence on the list of uncertain draws: count = base + accepted uncertain draws before
-    const uint32_t *d, *pos, *bu, *cnt_prev;
-    uint32_t n;
-    __device__ __forceinline__ uint32_t operator()(uint32_t u) const {
-        const uint32_t c = bu[u] + cnt_prev[u];
-        if (c >= n - 1u) return 0u;
-        const uint32_t i = n - 1u - c;
-        return ((d[pos[u]] & k8_mask(i)) <= i) ? 1u : 0u;
-    }
-};
-struct K8FlagFinal {       // scan input of the last pass: certain outcomes from the band, the others from the byte array
-    const uint32_t *d, *c0;
-    const uint8_t *mark;
-    uint32_t n;
-    __device__ __forceinline__ uint32_t operator()(uint32_t t) const {
-        const uint32_t k = k8_classify(d[t], t, c0[t], n);
-        return k == 2u ? (uint32_t)mark[t] : k;
-    }
-};
-// output of the last pass: the exact count, checked against the band it was derived under — and, since the count says which step the
-// draw belongs to, the partner of that step straight away (what k8_partners does for the full-length rounds)
-struct K8BandOut {
-    uint32_t *dst;
-    const uint32_t *c0, *d;
-    uint32_t *key, *violated;
-    uint32_t n, base;
-    struct Ref {
-        uint32_t *p, *key, *violated;
-        uint32_t c0v, dv, n, t;
-        __device__ __forceinline__ Ref &operator=(uint32_t v) {
-            const uint32_t K = k8_band(t, c0v);
-            if ((v > c0v ? v - c0v : c0v - v) > K) *violated = 1u;
-            *p = v;
-            if (t == 0u) key[0] = 0u;   // step 0 does not exist: a no-op
-            if (v < n - 1u) {
-                const uint32_t i = n - 1u - v, h = dv & k8_mask(i);
-                if (h <= i) key[i] = h;
-            }
-            return *this;
-        }
-    };
-    using iterator_category = std::random_access_iterator_tag;
-    using value_type = uint32_t;
-    using difference_type = std::ptrdiff_t;
-    using pointer = uint32_t *;
-    using reference = Ref;
-    __host__ __device__ Ref operator[](difference_type i) const { return Ref{dst + i, key, violated, c0[i], d[i], n, base + (uint32_t)i}; }
-    __host__ __device__ Ref operator*() const { return (*this)[0]; }
-    __host__ __device__ K8BandOut operator+(difference_type i) const { return K8BandOut{dst + i, c0 + i, d + i, key, violated, n, base + (uint32_t)i}; }
-    __host__ __device__ K8BandOut &operator+=(difference_type i) { dst += i; c0 += i; d += i; base += (uint32_t)i; return *this; }
-};
 // ---- the recurrence on the list of uncertain draws, in ONE launch ------------------------------------------------------------
 // Round 2 iterated c <- scan(flags(c)) over the whole list (~1.2 M draws for 82 M steps) with rocPRIM, one 8-byte read-back per
 // round to learn how far the exact prefix had grown: 45-47 rounds of ~90 us each per category, a fifth of K8.  The recurrence
@@ -318,17 +228,6 @@ struct K8BandOut {
 // tile's own length at the start, far inside the band the draws were selected with, so three to five local rounds settle it
 // (each one a ballot, a 16-entry LDS scan and two barriers).  No host round trip, no second workgroup to wait for.
 constexpr int K8L_THREADS = 1024, K8L_EPT = 4, K8L_TILE = K8L_THREADS * K8L_EPT;
-
-// dvu[u] = the draw's word, bu[u] = certain acceptances before it
-__global__ __launch_bounds__(256) void k8_list_init(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ d,
-                                                    const uint32_t *__restrict__ base, uint32_t n_u, uint32_t *__restrict__ dvu,
-                                                    uint32_t *__restrict__ bu) {
-    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
-    if (u >= n_u) return;
-    const uint32_t t = pos[u];
-    dvu[u] = d[t];
-    bu[u] = base[t];
-}
 
 __device__ __forceinline__ uint32_t k8_accept(uint32_t dv, uint32_t c, uint32_t n) {
     if (c >= n - 1u) return 0u;
@@ -412,7 +311,20 @@ __global__ __launch_bounds__(256) void k8_list_mark(const uint32_t *__restrict__
 struct K8Octaves {
     int count;
     double t_s[34], i_s1[34], m[34];   // octave k starts at draw t_s with i+1 = i_s1
+    double r[34];                      // exp(-1 / m): i+1 one draw later
 };
+__device__ __forceinline__ int k8_octave_of(const K8Octaves &oc, double t) {
+    int k = 0;
+    while (k + 1 < oc.count && t >= oc.t_s[k + 1]) ++k;
+    return k;
+}
+__device__ __forceinline__ uint32_t k8_c0_from(double i1, uint32_t n) {
+    if (i1 < 1.0) i1 = 1.0;
+    double c = (double)n - i1;
+    if (c < 0.0) c = 0.0;
+    if (c > (double)(n - 1u)) c = (double)(n - 1u);
+    return (uint32_t)c;
+}
 __global__ __launch_bounds__(256) void k8_guess(K8Octaves oc, uint32_t n, int64_t n_draws, uint32_t *__restrict__ c0) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_draws) return;
@@ -424,6 +336,215 @@ __global__ __launch_bounds__(256) void k8_guess(K8Octaves oc, uint32_t n, int64_
     if (c < 0.0) c = 0.0;
     if (c > (double)(n - 1u)) c = (double)(n - 1u);
     c0[t] = (uint32_t)c;
+}
+
+// ---- the two full-length passes of the banded resolve, hand-written (round 3) ------------------------------------------------
+// Round 2 ran them as rocPRIM scans over transform iterators with work hidden in the output iterators: a guess kernel (115 M
+// double exps, 0.58 ms), a 64-bit scan that re-read draw and guess in its output side and stored a base count per draw (1.16 ms),
+// a final scan that stored the exact count of every draw (0.91 ms) — 2.65 ms per category for what is one read of the draws each
+// time.  Now: single-pass scans with decoupled look-back (a workgroup takes a tile of 8192 draws by ticket, publishes its
+// aggregate in one 8-byte word, sums the words of the tiles before it), everything else fused in:
+//   pass A  reads d; computes the guess (ONE exp per 8 consecutive draws, the others by the octave's decay ratio), classifies,
+//           scans (certain acceptances | uncertain draws) as one packed word; stores the guess (pass B checks the band with it), the
+//           class as a byte, and — for the uncertain draws only — position, word and base count straight into the list;
+//   pass B  reads d, the byte (by now 0 / 1 everywhere) and the guess; scans the acceptances; the exclusive count says which step
+//           a draw belongs to, so the partner key[i] is written at once; no count is ever stored.
+constexpr int K8S_THREADS = 1024, K8S_EPT = 8, K8S_TILE = K8S_THREADS * K8S_EPT;
+constexpr unsigned long long K8S_AGG = 1ull << 62, K8S_PFX = 2ull << 62, K8S_VALUE = (1ull << 62) - 1;
+constexpr int K8S_SPIN_LIMIT = 1 << 22;
+
+// state[0] = ticket counter, state[1] = error word (a look-back gave up), state[2 + t] = look-back word of tile t.
+// Returns the sum of the aggregates of every tile before `tile` (all threads get it); publishes this tile's words.
+__device__ __forceinline__ unsigned long long k8s_lookback(unsigned long long *state, int64_t tile, unsigned long long mine,
+                                                           unsigned long long *s_bcast) {
+    unsigned long long *words = state + 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0)
+        __hip_atomic_store(&words[tile], (tile == 0 ? K8S_PFX : K8S_AGG) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        unsigned long long base = 0;
+        int64_t look = tile - 1;
+        bool failed = false;
+        while (look >= 0) {
+            const int64_t t = look - lane;
+            unsigned long long wv = K8S_PFX;      // lanes before tile 0 read as an empty prefix
+            if (t >= 0) {
+                int spins = 0;
+                do {
+                    wv = __hip_atomic_load(&words[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((wv >> 62) == 0 && ++spins > K8S_SPIN_LIMIT) { failed = true; break; }
+                    if ((wv >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+                } while ((wv >> 62) == 0);
+            }
+            if (__any(failed)) { failed = true; break; }
+            const unsigned long long has_pfx = __ballot((wv >> 62) == 2);
+            const int first = has_pfx ? __ffsll((long long)has_pfx) - 1 : kWave;
+            unsigned long long part = (lane <= first) ? (wv & K8S_VALUE) : 0ull;
+#pragma unroll
+            for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+                const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)part, dlt), hi = (unsigned int)__shfl_xor((int)(unsigned int)(part >> 32), dlt);
+                part += ((unsigned long long)hi << 32) | lo;
+            }
+            base += part;
+            if (has_pfx) break;
+            look -= kWave;
+        }
+        if (lane == 0) {
+            if (failed) { atomicExch(&state[1], 1ull); base = 0; }
+            if (tile != 0)
+                __hip_atomic_store(&words[tile], K8S_PFX | ((base + mine) & K8S_VALUE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_bcast = base;
+        }
+    }
+    __syncthreads();
+    return *s_bcast;
+}
+
+// exclusive scan of one packed 64-bit value per thread over the workgroup; `total` = the workgroup's sum
+__device__ __forceinline__ unsigned long long k8s_block_scan(unsigned long long v, unsigned long long *s_wave, unsigned long long &total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const unsigned int lo = (unsigned int)__shfl_up((int)(unsigned int)incl, dlt), hi = (unsigned int)__shfl_up((int)(unsigned int)(incl >> 32), dlt);
+        if (lane >= dlt) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < K8S_THREADS / 64; ++w) {
+        const unsigned long long x = s_wave[w];
+        before += w < wave ? x : 0ull;
+        total += x;
+    }
+    __syncthreads();                              // s_wave is reused by the caller's next scan
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(K8S_THREADS) void k8_scan_classify(const uint32_t *__restrict__ d, K8Octaves oc, uint32_t n, int64_t draws, uint32_t cap,
+                                                                uint32_t *__restrict__ c0_out, uint8_t *__restrict__ mark,
+                                                                uint32_t *__restrict__ pos_u, uint32_t *__restrict__ dvu, uint32_t *__restrict__ bu,
+                                                                unsigned long long *__restrict__ state, uint32_t *__restrict__ n_sel) {
+    __shared__ unsigned long long s_wave[K8S_THREADS / 64];
+    __shared__ unsigned long long s_bcast;
+    __shared__ unsigned long long s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    const int64_t t0 = tile * K8S_TILE + (int64_t)tid * K8S_EPT;
+    uint32_t dv[K8S_EPT], c0[K8S_EPT], cls[K8S_EPT];
+    const bool full = t0 + K8S_EPT <= draws;
+    if (full) {
+        const uint4 a = reinterpret_cast<const uint4 *>(d + t0)[0], b = reinterpret_cast<const uint4 *>(d + t0)[1];
+        dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w; dv[4] = b.x; dv[5] = b.y; dv[6] = b.z; dv[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < K8S_EPT; ++k) dv[k] = (t0 + k < draws) ? d[t0 + k] : 0u;
+    }
+    {   // the guess for 8 consecutive draws: one exp, then the octave's decay ratio (a run that crosses into the next octave: one by one)
+        const int k0 = k8_octave_of(oc, (double)t0);
+        if (k0 + 1 >= oc.count || (double)(t0 + K8S_EPT - 1) < oc.t_s[k0 + 1]) {
+            double i1 = oc.i_s1[k0] * exp(-((double)t0 - oc.t_s[k0]) / oc.m[k0]);
+            const double r = oc.r[k0];
+#pragma unroll
+            for (int k = 0; k < K8S_EPT; ++k) { c0[k] = k8_c0_from(i1, n); i1 *= r; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K8S_EPT; ++k) {
+                const double t = (double)(t0 + k);
+                const int kk = k8_octave_of(oc, t);
+                c0[k] = k8_c0_from(oc.i_s1[kk] * exp(-(t - oc.t_s[kk]) / oc.m[kk]), n);
+            }
+        }
+    }
+    unsigned long long mine = 0;                  // certain acceptances | uncertain draws << 32
+#pragma unroll
+    for (int k = 0; k < K8S_EPT; ++k) {
+        cls[k] = (t0 + k < draws) ? k8_classify(dv[k], (uint32_t)(t0 + k), c0[k], n) : 0u;
+        mine += cls[k] == 1u ? 1ull : (cls[k] == 2u ? (1ull << 32) : 0ull);
+    }
+    unsigned long long tile_total;
+    const unsigned long long in_tile = k8s_block_scan(mine, s_wave, tile_total);
+    const unsigned long long before = k8s_lookback(state, tile, tile_total, &s_bcast) + in_tile;
+    uint32_t cert = (uint32_t)before, unc = (uint32_t)(before >> 32);
+#pragma unroll
+    for (int k = 0; k < K8S_EPT; ++k) {
+        if (cls[k] == 2u) {
+            if (unc < cap) { pos_u[unc] = (uint32_t)(t0 + k); dvu[unc] = dv[k]; bu[unc] = cert; }
+            ++unc;
+        } else if (cls[k] == 1u) {
+            ++cert;
+        }
+    }
+    if (t0 <= draws - 1 && draws - 1 < t0 + K8S_EPT) *n_sel = unc;      // the thread holding the last draw: the list's length
+    if (full) {
+        reinterpret_cast<uint4 *>(c0_out + t0)[0] = make_uint4(c0[0], c0[1], c0[2], c0[3]);
+        reinterpret_cast<uint4 *>(c0_out + t0)[1] = make_uint4(c0[4], c0[5], c0[6], c0[7]);
+        const uint32_t lo = cls[0] | (cls[1] << 8) | (cls[2] << 16) | (cls[3] << 24), hi = cls[4] | (cls[5] << 8) | (cls[6] << 16) | (cls[7] << 24);
+        reinterpret_cast<uint2 *>(mark + t0)[0] = make_uint2(lo, hi);
+    } else {
+#pragma unroll
+        for (int k = 0; k < K8S_EPT; ++k)
+            if (t0 + k < draws) { c0_out[t0 + k] = c0[k]; mark[t0 + k] = (uint8_t)cls[k]; }
+    }
+}
+
+// res[2] = 1 when a count left the band it was classified under; res[6] = accepted draws in all
+__global__ __launch_bounds__(K8S_THREADS) void k8_scan_final(const uint32_t *__restrict__ d, const uint8_t *__restrict__ mark,
+                                                             const uint32_t *__restrict__ c0, uint32_t n, int64_t draws,
+                                                             uint32_t *__restrict__ key, unsigned long long *__restrict__ state,
+                                                             uint32_t *__restrict__ res) {
+    __shared__ unsigned long long s_wave[K8S_THREADS / 64];
+    __shared__ unsigned long long s_bcast;
+    __shared__ unsigned long long s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    const int64_t t0 = tile * K8S_TILE + (int64_t)tid * K8S_EPT;
+    uint32_t dv[K8S_EPT], g[K8S_EPT], f[K8S_EPT];
+    if (t0 + K8S_EPT <= draws) {
+        const uint4 a = reinterpret_cast<const uint4 *>(d + t0)[0], b = reinterpret_cast<const uint4 *>(d + t0)[1];
+        dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w; dv[4] = b.x; dv[5] = b.y; dv[6] = b.z; dv[7] = b.w;
+        const uint4 ga = reinterpret_cast<const uint4 *>(c0 + t0)[0], gb = reinterpret_cast<const uint4 *>(c0 + t0)[1];
+        g[0] = ga.x; g[1] = ga.y; g[2] = ga.z; g[3] = ga.w; g[4] = gb.x; g[5] = gb.y; g[6] = gb.z; g[7] = gb.w;
+        const uint2 m = reinterpret_cast<const uint2 *>(mark + t0)[0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[k] = (m.x >> (8 * k)) & 0xffu; f[4 + k] = (m.y >> (8 * k)) & 0xffu; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K8S_EPT; ++k) {
+            const bool in = t0 + k < draws;
+            dv[k] = in ? d[t0 + k] : 0u; g[k] = in ? c0[t0 + k] : 0u; f[k] = in ? (uint32_t)mark[t0 + k] : 0u;
+        }
+    }
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < K8S_EPT; ++k) mine += f[k] ? 1ull : 0ull;
+    unsigned long long tile_total;
+    const unsigned long long in_tile = k8s_block_scan(mine, s_wave, tile_total);
+    const unsigned long long base = k8s_lookback(state, tile, tile_total, &s_bcast);
+    uint32_t v = (uint32_t)(base + in_tile);      // accepted draws before draw t0: the exact count
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < K8S_EPT; ++k) {
+        const int64_t t = t0 + k;
+        if (t < draws) {
+            const uint32_t K = k8_band((uint32_t)t, g[k]);
+            bad |= (v > g[k] ? v - g[k] : g[k] - v) > K;
+            if (t == 0) key[0] = 0u;                // step 0 does not exist: a no-op
+            if (v < n - 1u) {
+                const uint32_t i = n - 1u - v, h = dv[k] & k8_mask(i);
+                if (h <= i) key[i] = h;
+            }
+            v += f[k] ? 1u : 0u;
+        }
+    }
+    if (bad) res[2] = 1u;
+    if (t0 <= draws - 1 && draws - 1 < t0 + K8S_EPT) res[6] = v;
 }
 
 // first index in [lo, n) where the two count arrays differ (0xffffffff: none) — everything before it is final
@@ -514,7 +635,7 @@ static double expected_draws(uint32_t n, K8Octaves *oc) {
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
         const double M = (double)mask + 1.0;
         const uint32_t lo = (mask >> 1) + 1;   // the octave's last step: 2^(k-1)
-        if (oc && cnt < 34) { oc->t_s[cnt] = t; oc->i_s1[cnt] = (double)i + 1.0; oc->m[cnt] = M; ++cnt; }
+        if (oc && cnt < 34) { oc->t_s[cnt] = t; oc->i_s1[cnt] = (double)i + 1.0; oc->m[cnt] = M; oc->r[cnt] = exp(-1.0 / M); ++cnt; }
         t += M * log(((double)i + 1.5) / ((double)lo + 0.5));   // sum_{j=lo}^{i} M/(j+1)
         if (lo <= 1) break;
         i = lo - 1;
@@ -552,17 +673,9 @@ static size_t perm_work_bytes(uint32_t n, int64_t draws, size_t *tmp_bytes_out) 
     (void)rocprim::radix_sort_pairs<K8SortConfig>(nullptr, sort_tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, rocprim::make_counting_iterator<uint32_t>(0u),
                                     (uint32_t *)nullptr, (size_t)n, 0u, 32u);
     size_t tmp = scan_tmp > sort_tmp ? scan_tmp : sort_tmp;
-    {   // the banded resolve: its scans (certain acceptances, final counts, the short recurrence) and the compaction
-        size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-        const auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
-        (void)rocprim::exclusive_scan(nullptr, t1, rocprim::make_transform_iterator(cnt, K8Packed{nullptr, nullptr, n}),
-                                      K8SplitOut{nullptr, nullptr, nullptr, nullptr, nullptr, n, 0u, 0u, 0u}, 0ull, (size_t)draws,
-                                      rocprim::plus<unsigned long long>());
-        (void)rocprim::exclusive_scan(nullptr, t3, rocprim::make_transform_iterator(cnt, K8FlagFinal{nullptr, nullptr, nullptr, n}),
-                                      K8BandOut{nullptr, nullptr, nullptr, nullptr, nullptr, n, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
-        (void)rocprim::exclusive_scan(nullptr, t4, rocprim::make_transform_iterator(cnt, K8FlagU{nullptr, nullptr, nullptr, nullptr, n}),
-                                      K8DiffOut{nullptr, nullptr, nullptr, 0u}, 0u, (size_t)draws, rocprim::plus<uint32_t>());
-        for (size_t t : {t1, t2, t3, t4}) tmp = t > tmp ? t : tmp;
+    {   // the banded resolve's own scans keep one look-back word per tile of 8192 draws (+ ticket and error word) here
+        const size_t words = 8 * ((size_t)ceil_div(draws, (int64_t)K8S_TILE) + 2);
+        tmp = words > tmp ? words : tmp;
     }
     tmp = (tmp + 255) & ~(size_t)255;
     if (tmp_bytes_out) *tmp_bytes_out = tmp;
@@ -576,53 +689,53 @@ void set_k8_band(int v) { g_k8_band = v != 0; }
 
 // The banded resolve (see k8_classify).  On success with *resolved = true the exact counts are in cB and the partners in key.
 // The list arrays live in the regions the sort phase uses later: mark | cntB in hs, pos_u in is, bu in last, cntA in pos.
-static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, uint32_t *cA, uint32_t *cB, uint32_t *hs, uint32_t *is, uint32_t *last,
+static int resolve_banded(const uint32_t *d, int64_t draws, uint32_t n, const K8Octaves &oc, uint32_t *cA, uint32_t *hs, uint32_t *is, uint32_t *last,
                           uint32_t *pos, size_t region_bytes, void *tmp, size_t tmp_bytes, uint32_t *res, uint32_t *key, hipStream_t st,
-                          int *rounds_out, bool *resolved) {
+                          int *rounds_out, bool *resolved, uint32_t *accepted_out) {
     *resolved = false;
     const size_t mark_bytes = (((size_t)draws) + 255) & ~(size_t)255;
-    if (region_bytes < mark_bytes + 1024) return DYD_OK;
-    uint8_t *mark = reinterpret_cast<uint8_t *>(hs);
-    uint32_t *cntB0 = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hs) + mark_bytes);
-    const size_t cap_b = (region_bytes - mark_bytes) / 4, cap = cap_b < (size_t)n ? cap_b : (size_t)n;
-    uint32_t *pos_u = is, *bu = last, *cntA0 = pos;
-    const auto cnt = rocprim::make_counting_iterator<uint32_t>(0u);
-    size_t tb = tmp_bytes;
-    // ONE scan: base[t] = certain acceptances before t (into cB) and the uncertain draws, in order, into the list
-    uint32_t *n_sel = res + 4;
-    DYD_HIP(hipMemsetAsync(n_sel, 0, 4, st));
-    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8Packed{d, cA, n}),
-                                    K8SplitOut{cB, pos_u, d, cA, n_sel, n, (uint32_t)cap, (uint32_t)(draws - 1), 0u}, 0ull, (size_t)draws,
-                                    rocprim::plus<unsigned long long>(), st));
-    uint32_t n_u = 0;
-    DYD_HIP(hipMemcpyAsync(&n_u, n_sel, 4, hipMemcpyDeviceToHost, st));
-    DYD_HIP(hipStreamSynchronize(st));
-    if ((size_t)n_u > cap || (int64_t)n_u >= draws) return DYD_OK;   // not worth it (or no room): the full-length rounds
-    DYD_HIP(hipMemsetAsync(mark, 0, (size_t)draws, st));
-    int rounds = 0;
-    if (n_u) {
-        // list arrays: dvu in cntA0's place, the flag bytes in cntB0's (a quarter of it)
-        uint32_t *dvu = cntA0;
-        uint8_t *fu = reinterpret_cast<uint8_t *>(cntB0);
-        hipLaunchKernelGGL(k8_list_init, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, pos_u, d, cB, n_u, dvu, bu);
+    const int64_t n_tiles = ceil_div(draws, (int64_t)K8S_TILE);
+    const size_t state_bytes = 8 * ((size_t)n_tiles + 2);
+    if (region_bytes < mark_bytes + 1024 || tmp_bytes < state_bytes) {   // no room for the list: the full-length rounds (they want a first guess)
+        hipLaunchKernelGGL(k8_guess, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, oc, n, draws, cA);
         DYD_HIP(hipGetLastError());
+        return DYD_OK;
+    }
+    uint8_t *mark = reinterpret_cast<uint8_t *>(hs);
+    uint8_t *fu = reinterpret_cast<uint8_t *>(hs) + mark_bytes;          // outcome of every uncertain draw, a byte each
+    const size_t cap_b = region_bytes - mark_bytes, cap = cap_b < (size_t)n ? cap_b : (size_t)n;
+    uint32_t *pos_u = is, *bu = last, *dvu = pos;                        // the list, in the regions the sort phase uses afterwards
+    unsigned long long *state = static_cast<unsigned long long *>(tmp);
+    uint32_t *n_sel = res + 4;
+    // pass A: the guess (kept in cA), the class of every draw (a byte in mark) and the list of the uncertain draws
+    DYD_HIP(hipMemsetAsync(state, 0, state_bytes, st));
+    DYD_HIP(hipMemsetAsync(res, 0, 32, st));
+    hipLaunchKernelGGL(k8_scan_classify, dim3((unsigned)n_tiles), dim3(K8S_THREADS), 0, st, d, oc, n, draws, (uint32_t)cap, cA, mark, pos_u, dvu, bu, state, n_sel);
+    DYD_HIP(hipGetLastError());
+    uint32_t n_u = 0;
+    unsigned long long failed_a = 0;
+    DYD_HIP(hipMemcpyAsync(&n_u, n_sel, 4, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(&failed_a, state + 1, 8, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipStreamSynchronize(st));
+    if (failed_a || (size_t)n_u > cap || (int64_t)n_u >= draws) return DYD_OK;   // not worth it (or no room): the full-length rounds, from the guess in cA
+    if (n_u) {
         hipLaunchKernelGGL(k8_list_resolve, dim3(1), dim3(K8L_THREADS), 0, st, dvu, bu, n_u, n, fu, res + 5);
         DYD_HIP(hipGetLastError());
         hipLaunchKernelGGL(k8_list_mark, dim3((unsigned)ceil_div((int64_t)n_u, 256)), dim3(256), 0, st, pos_u, fu, n_u, mark);
         DYD_HIP(hipGetLastError());
     }
-    // exact counts (into cB, over the base counts that are no longer needed), checked against the band
-    DYD_HIP(hipMemsetAsync(res + 2, 0, 4, st));
-    tb = tmp_bytes;
-    DYD_HIP(rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(cnt, K8FlagFinal{d, cA, mark, n}), K8BandOut{cB, cA, d, key, res + 2, n, 0u}, 0u,
-                                    (size_t)draws, rocprim::plus<uint32_t>(), st));
-    uint32_t violated = 1, list_rounds = 0;
-    DYD_HIP(hipMemcpyAsync(&violated, res + 2, 4, hipMemcpyDeviceToHost, st));
-    if (n_u) DYD_HIP(hipMemcpyAsync(&list_rounds, res + 5, 4, hipMemcpyDeviceToHost, st));
+    // pass B: exact counts (never stored) -> partners, checked against the band the classes were derived under
+    DYD_HIP(hipMemsetAsync(state, 0, state_bytes, st));
+    hipLaunchKernelGGL(k8_scan_final, dim3((unsigned)n_tiles), dim3(K8S_THREADS), 0, st, d, mark, cA, n, draws, key, state, res);
+    DYD_HIP(hipGetLastError());
+    uint32_t back[8] = {0, 0, 1, 0, 0, 0, 0, 0};
+    unsigned long long failed_b = 0;
+    DYD_HIP(hipMemcpyAsync(back, res, 32, hipMemcpyDeviceToHost, st));
+    DYD_HIP(hipMemcpyAsync(&failed_b, state + 1, 8, hipMemcpyDeviceToHost, st));
     DYD_HIP(hipStreamSynchronize(st));
-    rounds = (int)list_rounds;              // local rounds of the list walk, all tiles together
-    if (rounds_out) *rounds_out = rounds;
-    if (violated) return DYD_OK;   // a count left its band somewhere: nothing above is trusted (the full-length rounds rewrite every partner)
+    if (rounds_out) *rounds_out = (int)back[5];           // local rounds of the list walk, all tiles together
+    if (back[2] || failed_b) return DYD_OK;   // a count left its band somewhere: nothing above is trusted (the full-length rounds rewrite every partner)
+    *accepted_out = back[6];
     *resolved = true;
     return DYD_OK;
 }
@@ -645,17 +758,19 @@ static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n
     uint32_t *res = reinterpret_cast<uint32_t *>(w + 2 * a + 5 * b + tmp_bytes);
     const unsigned gn = (unsigned)ceil_div((int64_t)n, 256);
 
-    hipLaunchKernelGGL(k8_guess, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, oc, n, draws, cA);
-    DYD_HIP(hipGetLastError());
     int rounds = 0;
     bool resolved = false;
+    uint32_t accepted = 0;
     if (n >= K8_BAND_MIN_N && g_k8_band) {
-        const int rc = resolve_banded(d, draws, n, cA, cB, hs, is, last, pos, b, tmp, tmp_bytes, res, key, st, &rounds, &resolved);
+        const int rc = resolve_banded(d, draws, n, oc, cA, hs, is, last, pos, b, tmp, tmp_bytes, res, key, st, &rounds, &resolved, &accepted);
         if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k8_guess, dim3((unsigned)ceil_div(draws, 256)), dim3(256), 0, st, oc, n, draws, cA);
+        DYD_HIP(hipGetLastError());
     }
     // Picard rounds over the not yet final suffix [lo, draws): cB[t] = c_lo + sum of flags(cA) on [lo, t).  Whatever lies before
     // the first difference is final (its flags were computed from exact counts), so the partners of that stretch are written
-    // at once and the next round starts there.
+    // at once and the next round starts there.  (Short permutations, and the fallback of the banded resolve.)
     int64_t lo = resolved ? draws : 0;
     uint32_t c_lo = 0;
     while (lo < draws) {
@@ -683,12 +798,14 @@ static int perm_from_stream(const uint32_t *d, int64_t n_draws_avail, uint32_t n
         if (rounds > 100000) { set_error("K8: the rejection resolve did not settle"); return DYD_ERR_HIP; }
     }
     if (rounds_out) *rounds_out = rounds;
-    // enough draws?  the last draw's count (+ its own flag) must reach n-1 accepted  (cB holds the final counts of the tail)
-    uint32_t c_last = 0, d_last = 0;
-    DYD_HIP(hipMemcpyAsync(&c_last, cB + (draws - 1), 4, hipMemcpyDeviceToHost, st));
-    DYD_HIP(hipMemcpyAsync(&d_last, d + (draws - 1), 4, hipMemcpyDeviceToHost, st));
-    DYD_HIP(hipStreamSynchronize(st));
-    {
+    // enough draws?  n - 1 of them must have been accepted
+    if (resolved) {
+        if (accepted < n - 1u) return DYD_ERR_RANGE;
+    } else {   // the full-length rounds: the last draw's count (+ its own flag); cB holds the final counts of the tail
+        uint32_t c_last = 0, d_last = 0;
+        DYD_HIP(hipMemcpyAsync(&c_last, cB + (draws - 1), 4, hipMemcpyDeviceToHost, st));
+        DYD_HIP(hipMemcpyAsync(&d_last, d + (draws - 1), 4, hipMemcpyDeviceToHost, st));
+        DYD_HIP(hipStreamSynchronize(st));
         uint32_t acc = c_last;
         if (c_last < n - 1u) {
             const uint32_t i = n - 1u - c_last;
