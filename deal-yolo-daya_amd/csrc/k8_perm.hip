@@ -223,11 +223,11 @@ __device__ __forceinline__ uint32_t k8_classify(uint32_t dt, uint32_t t, uint32_
 // ---- the recurrence on the list of uncertain draws, in ONE launch ------------------------------------------------------------
 // Round 2 iterated c <- scan(flags(c)) over the whole list (~1.2 M draws for 82 M steps) with rocPRIM, one 8-byte read-back per
 // round to learn how far the exact prefix had grown: 45-47 rounds of ~90 us each per category, a fifth of K8.  The recurrence
-// is sequential only from tile to tile: a single workgroup walks the list once, tile after tile of 4096 draws, carrying the EXACT
+// is sequential only from tile to tile: a single workgroup walks the list once, tile after tile of 8192 draws, carrying the EXACT
 // count into each tile and iterating inside the tile until no flag changes — the counts inside a tile are off by at most the
 // tile's own length at the start, far inside the band the draws were selected with, so three to five local rounds settle it
 // (each one a ballot, a 16-entry LDS scan and two barriers).  No host round trip, no second workgroup to wait for.
-constexpr int K8L_THREADS = 1024, K8L_EPT = 4, K8L_TILE = K8L_THREADS * K8L_EPT;
+constexpr int K8L_THREADS = 1024, K8L_EPT = 8, K8L_TILE = K8L_THREADS * K8L_EPT;
 
 __device__ __forceinline__ uint32_t k8_accept(uint32_t dv, uint32_t c, uint32_t n) {
     if (c >= n - 1u) return 0u;
@@ -238,23 +238,49 @@ __device__ __forceinline__ uint32_t k8_accept(uint32_t dv, uint32_t c, uint32_t 
 __global__ __launch_bounds__(K8L_THREADS) void k8_list_resolve(const uint32_t *__restrict__ dvu, const uint32_t *__restrict__ bu,
                                                                uint32_t n_u, uint32_t n, uint8_t *__restrict__ fu,
                                                                uint32_t *__restrict__ rounds_out) {
-    __shared__ uint32_t wsum[K8L_THREADS / 64];
-    __shared__ int changed_any;
+    __shared__ uint32_t wsum[2][K8L_THREADS / 64];
+    __shared__ int changed_any[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t c_in = 0;                      // accepted uncertain draws before the tile: exact
     uint32_t rounds = 0;
+    uint32_t rate = 128;                    // accepted share of the last tile in 1/256: the first guess of the counts inside the next
+    if (tid < 2) changed_any[tid] = 0;
+    // the next tile's words are loaded while the current one is iterated on (a single workgroup has nobody to hide its latency)
+    uint32_t ndv[K8L_EPT], nb[K8L_EPT];
+    auto load = [&](uint32_t tile, uint32_t *dv, uint32_t *b) {
+        const uint32_t u0 = tile + (uint32_t)tid * K8L_EPT;
+        if (u0 + K8L_EPT <= n_u) {
+            const uint4 a0 = reinterpret_cast<const uint4 *>(dvu + u0)[0], a1 = reinterpret_cast<const uint4 *>(dvu + u0)[1];
+            const uint4 b0 = reinterpret_cast<const uint4 *>(bu + u0)[0], b1 = reinterpret_cast<const uint4 *>(bu + u0)[1];
+            dv[0] = a0.x; dv[1] = a0.y; dv[2] = a0.z; dv[3] = a0.w; dv[4] = a1.x; dv[5] = a1.y; dv[6] = a1.z; dv[7] = a1.w;
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < K8L_EPT; ++k) {
+                const bool in = u0 + k < n_u;
+                dv[k] = in ? dvu[u0 + k] : 0u;
+                b[k] = in ? bu[u0 + k] : 0xffffffffu;         // beyond the list: never accepted
+            }
+        }
+    };
+    load(0, ndv, nb);
+    __syncthreads();
     for (uint32_t tile = 0; tile < n_u; tile += K8L_TILE) {
         const uint32_t u0 = tile + (uint32_t)tid * K8L_EPT;
         uint32_t dv[K8L_EPT], b[K8L_EPT], f[K8L_EPT];
 #pragma unroll
-        for (int k = 0; k < K8L_EPT; ++k) {
-            const bool in = u0 + k < n_u;
-            dv[k] = in ? dvu[u0 + k] : 0u;
-            b[k] = in ? bu[u0 + k] : 0xffffffffu;             // beyond the list: never accepted (count >= n - 1)
-            f[k] = in ? k8_accept(dv[k], b[k] + c_in, n) : 0u; // first guess: nothing inside the tile counted yet
+        for (int k = 0; k < K8L_EPT; ++k) { dv[k] = ndv[k]; b[k] = nb[k]; }
+        if (tile + K8L_TILE < n_u) load(tile + K8L_TILE, ndv, nb);
+        {   // first guess of the count before each of this thread's draws: the last tile's acceptance share, spread evenly
+            uint32_t c = c_in + (((uint32_t)tid * K8L_EPT * rate) >> 8);
+#pragma unroll
+            for (int k = 0; k < K8L_EPT; ++k) {
+                f[k] = (b[k] != 0xffffffffu) ? k8_accept(dv[k], b[k] + c, n) : 0u;
+                c += f[k];
+            }
         }
         uint32_t total = 0;
-        for (;;) {
+        for (int par = 0;; par ^= 1) {
             uint32_t s = 0;
 #pragma unroll
             for (int k = 0; k < K8L_EPT; ++k) s += f[k];
@@ -264,13 +290,12 @@ __global__ __launch_bounds__(K8L_THREADS) void k8_list_resolve(const uint32_t *_
                 const uint32_t o = (uint32_t)__shfl_up((int)incl, dlt);
                 if (lane >= dlt) incl += o;
             }
-            if (tid == 0) changed_any = 0;
-            if (lane == 63) wsum[wave] = incl;
+            if (lane == 63) wsum[par][wave] = incl;
             __syncthreads();
             uint32_t before = 0, all = 0;
 #pragma unroll
             for (int w = 0; w < K8L_THREADS / 64; ++w) {
-                const uint32_t v = wsum[w];
+                const uint32_t v = wsum[par][w];
                 before += w < wave ? v : 0u;
                 all += v;
             }
@@ -283,18 +308,28 @@ __global__ __launch_bounds__(K8L_THREADS) void k8_list_resolve(const uint32_t *_
                 c += f[k];                                      // the counts of this round are those of the OLD flags (Picard)
                 f[k] = nf;
             }
-            if (changed) changed_any = 1;
+            if (changed) changed_any[par] = 1;
             ++rounds;
             __syncthreads();
-            const int again = changed_any;
+            const int again = changed_any[par];
+            if (tid == 0) changed_any[par ^ 1] = 0;             // the other parity's flag and sums are free again: two barriers a round
             total = all;
-            __syncthreads();                                    // changed_any is reset by thread 0 at the top of the next round
             if (!again) break;                                  // the flags reproduced themselves: `all` is their sum
         }
+        if (u0 + K8L_EPT <= n_u) {
+            const uint32_t lo = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24), hi = f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24);
+            reinterpret_cast<uint2 *>(fu + u0)[0] = make_uint2(lo, hi);
+        } else {
 #pragma unroll
-        for (int k = 0; k < K8L_EPT; ++k)
-            if (u0 + k < n_u) fu[u0 + k] = (uint8_t)f[k];
+            for (int k = 0; k < K8L_EPT; ++k)
+                if (u0 + k < n_u) fu[u0 + k] = (uint8_t)f[k];
+        }
         c_in += total;
+        const uint32_t len = (n_u - tile < (uint32_t)K8L_TILE) ? n_u - tile : (uint32_t)K8L_TILE;
+        rate = (total << 8) / len;
+        __syncthreads();                                        // changed_any[par] of the last round is read by all before anybody resets it
+        if (tid < 2) changed_any[tid] = 0;
+        __syncthreads();
     }
     if (tid == 0 && rounds_out) *rounds_out = rounds;
 }

@@ -6,11 +6,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python tools/k8_bench.py --reps 7 > $OUT/k8_bench.log 2> $OUT/k8_bench.err; rc=$?
+timeout -k 10 300 python tools/k8_bench.py --reps 7 ${K8ARGS:-} > $OUT/k8_bench.log 2> $OUT/k8_bench.err; rc=$?
 echo "k8_bench rc=$rc"; tail -n 1 $OUT/k8_bench.log
 if [ $rc -ge 124 ]; then exit $rc; fi
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k8 -- python3 $GRAFT_REPO_ROOT/tools/k8_bench.py --reps 7 > $OUT/rocprof_k8.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k8 -- python3 $GRAFT_REPO_ROOT/tools/k8_bench.py --reps 7 ${K8ARGS:-} > $OUT/rocprof_k8.log 2>&1
 echo "rocprof rc=$?"
 find $OUT/prof_k8 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/k8_kernel_stats.csv
 head -30 $OUT/k8_kernel_stats.csv | cut -c1-200

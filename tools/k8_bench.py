@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--records", type=int, default=165_004_682)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=0, help="1 = compare positions with numpy's RandomState.permutation (slow at full size)")
+    ap.add_argument("--single", type=int, default=0, help="1 = one category only (half the records): per-kernel times without a second category's kernels beside them")
     args = ap.parse_args()
     import torch
     from deal_yolo_daya_amd import _native
@@ -30,7 +31,11 @@ def main():
     labels = torch.randint(0, 20, (B,), generator=g, device=dev, dtype=torch.int32)
     cat = torch.where(labels < 10, 0, torch.where(labels < 18, 1, -1)).to(torch.int32).contiguous()
     del labels
-    sizes = np.asarray([int((cat == c).sum().item()) for c in (0, 1)], np.int64)
+    n_cat = 2
+    if args.single:
+        cat = torch.where(cat == 0, 0, -1).to(torch.int32).contiguous()
+        n_cat = 1
+    sizes = np.asarray([int((cat == c).sum().item()) for c in range(n_cat)], np.int64)
     n_train = (sizes * 0.8).astype(np.int64)
     n_val = (sizes * 0.1).astype(np.int64)
     split = torch.empty(B, dtype=torch.uint8, device=dev)
@@ -38,7 +43,7 @@ def main():
     sp = torch.cuda.current_stream().cuda_stream
 
     def run():
-        ck(L.dyd_split_ids_seeded_dev(cat.data_ptr(), B, 42, sizes.ctypes.data, n_train.ctypes.data, n_val.ctypes.data, 2, None,
+        ck(L.dyd_split_ids_seeded_dev(cat.data_ptr(), B, 42, sizes.ctypes.data, n_train.ctypes.data, n_val.ctypes.data, n_cat, None,
                                       split.data_ptr(), pos.data_ptr(), sp), "dyd_split_ids_seeded_dev")
 
     run()
@@ -56,7 +61,7 @@ def main():
     if args.check:
         p = pos.cpu().numpy()
         c = cat.cpu().numpy()
-        for k in (0, 1):
+        for k in range(n_cat):
             inv = np.empty(int(sizes[k]), np.int64)
             inv[np.random.RandomState(42).permutation(int(sizes[k]))] = np.arange(int(sizes[k]))
             assert np.array_equal(p[c == k], inv), f"category {k}: positions differ from numpy"
