@@ -10,7 +10,8 @@ timeout -k 10 300 python tools/k8_bench.py --reps 7 ${K8ARGS:-} > $OUT/k8_bench.
 echo "k8_bench rc=$rc"; tail -n 1 $OUT/k8_bench.log
 if [ $rc -ge 124 ]; then exit $rc; fi
 cd /tmp
+rm -rf $OUT/prof_k8
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_k8 -- python3 $GRAFT_REPO_ROOT/tools/k8_bench.py --reps 7 ${K8ARGS:-} > $OUT/rocprof_k8.log 2>&1
 echo "rocprof rc=$?"
-find $OUT/prof_k8 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/k8_kernel_stats.csv
+rm -rf $OUT/prof_k8_prev; ls -t $(find $OUT/prof_k8 -name "*kernel_stats.csv") | head -1 | xargs -I{} cp {} $OUT/k8_kernel_stats.csv
 head -30 $OUT/k8_kernel_stats.csv | cut -c1-200
