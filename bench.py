@@ -632,7 +632,7 @@ def main():
                 # configs[4] scaled to one launch: 1 M rows x 256 boxes (44 GB), the same fused entry (its DENSE instantiation), timed
                 # like the headline: HIP events around every launch, its own roofline object
                 drows, dbpr, ddesc = WORKLOADS["c5"]
-                dres = resident(drows, dbpr, args.dense_steps, 2, 200.0, synth.SEED + 555)
+                dres = resident(drows, dbpr, args.dense_steps, 2, 200.0, synth.SEED + 1000 * rank)   # the table `--workload c5` draws
                 line["dense"] = {"workload": ddesc, "rows": drows, "boxes": dres["B"], "points": dres["P"], "steps": args.dense_steps,
                                  "ms_per_step": dres["elapsed"] * 1e3 / args.dense_steps, "kernel_ms": dres["kernel_ms"],
                                  "rows_per_s": drows * args.dense_steps / dres["elapsed"], "boxes_per_s": dres["B"] * args.dense_steps / dres["elapsed"],

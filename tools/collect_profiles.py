@@ -67,3 +67,16 @@ if os.path.exists(bj):
                        "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
                                  "bench.py --steps 3 --warmup 1 on the same table)"},
                       fh, indent=1)
+
+    dense = bench.get("dense")
+    dkey = next((k for k in summary if "k12_wave_dense_kernel" in k), None)
+    dt = summary.get(dkey, {}).get("hbm_traffic_bytes_per_launch") if dkey else None
+    if dense and dt:
+        alg = dense["roofline"]["algorithmic_bytes_per_launch"]
+        with open(os.path.join(prof, f"{tag}_c5_traffic.json"), "w") as fh:
+            json.dump({"workload": "c5", "kernel": dkey, "rows_per_gpu": dense["rows"], "traffic_bytes_per_launch": dt["total_corrected"],
+                       "read_bytes_fetch_size_x2": dt["read_corrected_x2"], "write_bytes": dt["write"], "algorithmic_bytes_per_launch": alg,
+                       "traffic_over_algorithmic": dt["total_corrected"] / alg,
+                       "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                 "bench.py --workload c5 --steps 3 --warmup 1: the table the dense object of the default line draws)"},
+                      fh, indent=1)
