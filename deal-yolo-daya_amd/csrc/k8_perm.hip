@@ -10,15 +10,19 @@
 //             terms plus old-state twists (s'[k] = F(k)^s[k+397] | F(k)^F(k-227)^s[k+170] | F(k)^F(k-227)^F(k-454)^s[k-57],
 //             F(k) = twist(s[k], s[k+1])), so one workgroup produces a whole block per barrier: k8_mt_stream;
 //   resolve   c(t) = number of accepted draws before draw t obeys c(t+1) = c(t) + [ (d[t] & mask(i)) <= i ], i = n-1-c(t).
-//             Iterating c <- scan(flags(c)) from an analytic first guess converges to THE sequential solution (the correct
-//             prefix grows every round; in practice the error falls like (t/mask)^r / r!): a handful of device-wide scans;
+//             An analytic guess of c(t) is off by a few standard deviations of the rejection count at most, and for every count
+//             inside that band most draws are decided the same way: two hand-written single-pass scans (decoupled look-back)
+//             settle those, and the 1-3 % whose outcome depends on the exact count are listed and resolved by ONE workgroup
+//             that walks the list tile by tile (k8_scan_classify -> k8_list_resolve -> k8_scan_final; "the banded resolve").
+//             Short permutations, and a band that did not hold, take full-length rounds c <- scan(flags(c)) (rocPRIM);
 //   shuffle   the FINAL position of every value follows from the partners H[] alone.  Slot j is touched by the steps that
 //             target it, L_j = {i : H[i] = j} (all >= j), and by its own step j, which carries its content on to H[j]; after
 //             step j the slot is final.  So value v either is fetched by the first step that targets slot v before step v
 //             runs (max(L_v) > v: final position max(L_v)), or rides its own step to slot H[v], where the next smaller
 //             member of L_{H[v]} fetches it for good — or, if there is none, that slot's own step carries it one hop
 //             further, and so on (a hop survives with probability ~1/2: chains are a few hops long).  One stable radix sort
-//             of (H[i], i) lays every L_j out in order; "next smaller member" is then the neighbour in the sorted array.
+//             of (H[i], i) lays every L_j out in order; k8_links turns "next smaller member" into an array indexed by step,
+//             so the chase (k8_inverse) reads its first hop in order.
 //
 // K6 wants exactly this INVERSE (shuffled position of the record with in-category rank v), so its former permutation
 // inversion — a 165 M-word random scatter, 64 % of K6 — disappears with the host loop.

@@ -301,7 +301,8 @@ int dyd_json_scan_labelled(const uint8_t *text, const int64_t *cell_off, const u
 const uint8_t *dyd_scan_sel(const dyd_scan *scan);             /* [n_boxes] (labelled scan only) */
 /* The replace step and the IoU step in ONE native pass (processor.py:262-281 then :341-376; ui/pages/processing.py:580-598 runs them
  * back to back): cells as flat text + offsets, or as one (pointer, length) pair per cell (text == cell_off == NULL).  Every worker
- * thread takes its share of the cells through scan, ONE dyd_bbox_iou_fused launch on its own arrays and emit.  The handle then
+ * thread holds one staging slot (dyd_stage_acquire) and takes its share of the cells through scan -> dyd_bbox_iou_fused_staged -> emit
+ * chunk by chunk (DYD_PIPE_CHUNK_KB of cell text, default 8192), the points scanned straight into the slot's pinned arena.  The handle then
  * holds per cell: dyd_scan_status, dyd_scan_high (the IoU step's flag, meaningful for status 0 cells; the caller decides cells with
  * dyd_scan_iou_host != 0 and status 2 cells itself), dyd_scan_wh_*; and the emitted text per part (dyd_scan_part) or gathered
  * (dyd_scan_text).  Needs the device (no CPU fallback). */
