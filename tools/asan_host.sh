@@ -18,5 +18,6 @@ rm -f build_exp/asan.log.* build_exp/ubsan.log.*
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:log_path=$PWD/build_exp/asan.log \
   UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1:log_path=$PWD/build_exp/ubsan.log \
   DYD_LIB_PATH=$PWD/build_exp/libdyd_asan.so python -m pytest tests/test_native_json_cpu.py tests/test_fastcsv_cpu.py \
-  tests/test_merge_cpu.py tests/test_host_steps_cpu.py tests/test_yolo_host_cpu.py tests/test_label_replace_cpu.py -x -q \
+  tests/test_merge_cpu.py tests/test_host_steps_cpu.py tests/test_yolo_host_cpu.py tests/test_label_replace_cpu.py tests/test_split_cpu.py \
+  tests/test_pycells_cpu.py -x -q \
   || { head -n 12 build_exp/asan.log.* build_exp/ubsan.log.* 2>/dev/null; exit 1; }
