@@ -116,3 +116,28 @@ def test_the_tablewise_checker_is_the_cpu_port(oracle_backend):
     rules = synth.rules()
     _same_frames(split_expected_tablewise(table, rules), osteps.split_frames(table, rules))
     _same_frames(split_expected_tablewise(table, rules, None, 6, 3, 1, 7), osteps.split_frames(table, rules, None, 6, 3, 1, random_seed=7))
+
+
+def test_split_frames_on_degenerate_tables(oracle_backend):
+    """no rows, only error rows, nothing classified, no JSON column, a single record, no source column, the second JSON column
+    standing in where the first is empty (:713-718): frames, side tables and counts of the CPU port"""
+    rules = synth.rules()
+    cases = {
+        "empty": pd.DataFrame({"source": pd.Series([], dtype=object), P.BBOX_COL: pd.Series([], dtype=object)}),
+        "all errors": pd.DataFrame({"source": ["a", "b", "c"], P.BBOX_COL: [None, "{", '{"objects": 5}']}),
+        "nothing classified": pd.DataFrame({"source": ["a", "b"], P.BBOX_COL: ['{"objects": [{"name": "zz"}]}', '{"objects": [{"nam": 1}]}']}),
+        "no json column": pd.DataFrame({"source": ["a"], "other": [1]}),
+        "one record": pd.DataFrame({"source": ["a"], P.BBOX_COL: ['{"objects": [{"name": "c1"}], "w": 1}'], "n": [7]}),
+        "no source": pd.DataFrame({P.ANNOTATION_COL: ['{"objects": [{"name": "c1;c11"}]}', '{"objects": [{"name": "c12"}]}'] * 3}),
+        "second column": pd.DataFrame({"source": list("abc"), P.BBOX_COL: ["", None, '{"objects": [{"name": "c2"}]}'],
+                                       P.ANNOTATION_COL: ['{"objects": [{"name": "c3"}]}', '{"objects": [{"name": "c13"}]}', '{"objects": [{"name": "c4"}]}']}),
+    }
+    for name, df in cases.items():
+        got, exp = P.split_frames(df, rules, backend=oracle_backend), osteps.split_frames(df, rules)
+        assert list(got["categories"]) == list(exp["categories"]) and got["category_counts"] == exp["category_counts"], name
+        for c in exp["categories"]:
+            for a, b in zip(got["categories"][c], exp["categories"][c]):
+                pd.testing.assert_frame_equal(a, b)
+        for key in ("unclassified", "split_counts"):
+            if len(exp[key]) or len(got[key]):
+                pd.testing.assert_frame_equal(got[key], exp[key])
