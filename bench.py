@@ -21,7 +21,8 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   full_pipeline  configs[2]: K3 -> K4 -> K5 -> K1+K2 -> permutation + K6 on the same 10M resident rows, per stage
   dense          configs[4] scaled (1M rows x 256 boxes, 44 GB): the same launch, its own roofline object
 and the sharded dedup / reference filter of configs[3] with its collectives timed on their own: sharded_exchange (weak: rows per GPU
-fixed, at N > 1 or --workload c4) and sharded_exchange_strong (a fixed 100 M-row table cut into N shards, at every N incl. 1).
+fixed, at N > 1 or --workload c4) and sharded_exchange_strong (a fixed 100 M-row table cut into N shards, at every N incl. 1); at N > 1
+also fused_strong: the fused launch on every rank's shard of that fixed table (configs[3] itself at N = 8).
 """
 from __future__ import annotations
 
@@ -441,7 +442,8 @@ def main():
     ap.add_argument("--exchange", type=int, default=1,
                     help="1 = also time configs[3]'s sharded dedup / reference filter with its collectives (after the K steps): weak (rows per GPU as "
                          "the workload says) at N > 1 or with --workload c4, strong (--strong-rows in total) at every N")
-    ap.add_argument("--strong-rows", type=int, default=100_000_000, help="rows of the fixed table of the strong-scaling exchange (0 = skip)")
+    ap.add_argument("--strong-rows", type=int, default=100_000_000, help="rows of the fixed table of the strong-scaling legs (exchange at every N, fused launch at N > 1; 0 = skip)")
+    ap.add_argument("--strong-steps", type=int, default=20)
     ap.add_argument("--fused-variant", type=int, default=-1, help="A/B only: force a kernel variant of the fused launch (dyd_set_option)")
     args = ap.parse_args()
 
@@ -574,6 +576,7 @@ def main():
     elapsed = main_res["elapsed"]
     P, B, N = main_res["P"], main_res["B"], main_res["N"]
     label, fused = main_res["label"], main_res["fused"]
+    main_info = {k: main_res[k] for k in ("P", "B", "N", "kernel_ms", "ramp_launches")}   # what the line needs once the tensors are gone
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist.get_backend() == "gloo":
@@ -594,9 +597,33 @@ def main():
         if args.strong_rows > 0:                                      # configs[3] as a FIXED table of --strong-rows rows cut into `world` shards
             exchange_strong = sharded_dedup(args.strong_rows // world, rank, world, dev, reps=2, scaling="strong")
 
+    fused_strong = None
+    if world > 1 and args.strong_rows > 0 and args.workload == "c3":
+        # configs[3] as a FIXED table: --strong-rows rows (100 M) cut into `world` contiguous shards, the same fused launch on each rank's
+        # shard (12.5 M rows per GPU at N = 8: configs[3] itself); max over ranks; together with sharded_exchange_strong the strong-scaling
+        # series of the whole configuration.  Skipped where a shard would not fit beside nothing else (2.9 KB per row).
+        srows = args.strong_rows // world
+        if srows * 2900 < 200e9:
+            del label, fused
+            main_res.clear()
+            torch.cuda.empty_cache()
+            sres = resident(srows, None, args.strong_steps, 3, 200.0, synth.SEED + 7000 + 1000 * rank)
+            st = torch.tensor([sres["elapsed"]], dtype=torch.float64, device=dev)
+            if dist.get_backend() == "gloo":
+                tc = st.cpu(); dist.all_reduce(tc, op=dist.ReduceOp.MAX); st = tc
+            else:
+                dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            s_elapsed = float(st.item())
+            fused_strong = {"config": "configs[3] as a fixed table cut into N shards: the fused K1+K2 launch on every rank's shard, max over ranks",
+                            "scaling": "strong", "rows_total": srows * world, "rows_per_gpu": srows, "steps": args.strong_steps,
+                            "ms_per_step": s_elapsed * 1e3 / args.strong_steps, "kernel_ms_rank0": sres["kernel_ms"],
+                            "rows_per_s": srows * world * args.strong_steps / s_elapsed,
+                            "roofline_rank0": roofline_of(sres, "strong", srows)}
+            sres.clear()
+            label = fused = None
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
-        k_ms = main_res["kernel_ms"]
+        k_ms = main_info["kernel_ms"]
         line = {
             "metric": "annotation rows/sec through poly->bbox + IoU-filter path",
             "value": rows * world * args.steps / elapsed,
@@ -613,8 +640,8 @@ def main():
             "config": {"workload": desc, "rows_per_gpu": rows, "boxes_per_gpu": B, "points_per_gpu": P,
                        "min_boxes": MIN_BOXES, "iou_threshold": THR, "high_rows_rank0": high_rows,
                        "launch": "fused K1+K2 (dyd_bbox_iou_fused_dev)" + (f", forced variant {args.fused_variant}" if args.fused_variant >= 0 else ""), "kernel_ms": k_ms,
-                       "clock_ramp_launches_before_warmup": main_res["ramp_launches"], "device": _native.device_name()},
-            "roofline": roofline_of(main_res, args.workload, rows),
+                       "clock_ramp_launches_before_warmup": main_info["ramp_launches"], "device": _native.device_name()},
+            "roofline": roofline_of(main_info, args.workload, rows),
         }
         line["cpu_baseline"] = None
         line["host_inclusive"] = None
@@ -622,6 +649,7 @@ def main():
         line["dense"] = None
         line["sharded_exchange"] = exchange
         line["sharded_exchange_strong"] = exchange_strong
+        line["fused_strong"] = fused_strong
         if world == 1:
             if args.pipeline and args.workload == "c3":
                 line["full_pipeline"] = full_pipeline({"N": N, "B": B, "P": P, "label": label, "fused": fused}, dev, L, ck, sp)

@@ -52,6 +52,8 @@ def test_ranks_on_one_card(world):
     assert max(p["dedup_slice_keys"] for p in per) < 1.2 * ex["allreduce_bytes_dedup"] / world
     st = line["sharded_exchange_strong"]
     assert st["scaling"] == "strong" and st["rows_total"] == 400000 and st["rows_per_gpu"] == 400000 // world and st["world"] == world
+    fs = line["fused_strong"]
+    assert fs["scaling"] == "strong" and fs["rows_total"] == 400000 and fs["rows_per_gpu"] == 400000 // world and fs["rows_per_s"] > 0
     srows = 400000 // world
     ids = torch.cat([torch.randint(0, int(0.9 * 400000) + 1, (srows,), generator=torch.Generator(device=dev).manual_seed(900 + r),
                                    device=dev, dtype=torch.int64) for r in range(world)])
