@@ -90,3 +90,64 @@ def test_two_buttons_as_the_page_presses_them(native, tmp_path):
     P.filter_by_box_count_and_iou(Q("p5.csv"), Q("h5.csv"), Q("o5.csv"), 2, 0.98)
     assert P.LAST_IO_PATH["iou"] != "cached"
     P.clear_step_cache()
+
+
+def test_split_at_a_million_rows_properties_and_samples(native):
+    """the split step at the bench's size (1 M rows in, ~15 M records): size-independent properties of every frame, numpy's own
+    permutation per category, and 3000 sampled rows walked by the CPU port's primitives record by record"""
+    import json
+    import torch
+    rows = 1_000_000
+    dev = torch.device("cuda", 0)
+    parts = []
+    for ci, s in enumerate(range(0, rows, 500_000)):
+        t = synth.table_from_device(synth.generate_device(500_000, synth.SEED + 300 + ci, dev))
+        parts.append(pd.DataFrame({"source": synth.urls(t), synth.ANN_COL: synth.json_cells(t)}))
+        del t
+    df = pd.concat(parts, ignore_index=True)
+    del parts
+    kept, _, high, other = P.replace_and_filter_frame(df, 2, 0.98)
+    assert len(kept) == rows and 20_000 < len(high) < 50_000
+    del df, kept, high
+    rules = synth.rules()
+    res = P.split_frames(other, rules, stats=(st := {}))
+    ex = res["expanded"]
+    n_rec = st["records"]
+    assert n_rec > 13_000_000 and st["fast_cells"] == len(other) and sum(res["category_counts"].values()) == n_rec
+    src_vals = other["source"].to_numpy()
+    for cid, name in enumerate(ex["category_names"]):
+        train, val, test = res["categories"][name]
+        n = res["category_counts"][name]
+        assert (len(train), len(val)) == P.split_cut_sizes(n, 0.8, 0.1, 0.1) and len(train) + len(val) + len(test) == n
+        members = np.flatnonzero(ex["category_id"] == cid)                    # records of the category in row order
+        assert len(members) == n
+        # sample(frac=1, random_state=42) == take(RandomState(42).permutation(n)) (:800): shuffled position k holds record perm[k]
+        perm = np.random.RandomState(42).permutation(n)
+        assert np.array_equal(ex["position"][members[perm]], np.arange(n))
+        frame_src = np.concatenate([f["source"].to_numpy() for f in (train, val, test)])
+        assert np.array_equal(frame_src, src_vals[ex["src_row"][members[perm]]])
+        assert np.array_equal(ex["split"][members[perm]], np.repeat([0, 1, 2], [len(train), len(val), len(test)]).astype(np.uint8))
+        assert train.index[0] == 0 and test.index[-1] == n - 1 and (train["分类类别"] == name).all()
+    # sampled rows, record by record against the port's primitives
+    rng = np.random.default_rng(3)
+    cells = other[P.BBOX_COL].to_numpy()
+    first_rec = np.searchsorted(ex["src_row"], np.arange(len(other)))
+    inv_order = {name: np.concatenate([f[P.BBOX_COL].to_numpy() for f in res["categories"][name]]) for name in ex["category_names"]}
+    labels_of = {name: np.concatenate([f["分类标签"].to_numpy() for f in res["categories"][name]]) for name in ex["category_names"]}
+    for ri in rng.choice(len(other), 3000, replace=False).tolist():
+        doc, objs, err = osteps.parse_objects(cells[ri])
+        assert err is None
+        e = int(first_rec[ri])
+        for o in objs:
+            for lab in osteps.split_object_labels(o.get("name")):
+                if lab not in rules:
+                    continue
+                one = dict(o); one["name"] = lab
+                slim = {k: v for k, v in doc.items() if k != "objects"}
+                slim["objects"] = [one]
+                assert ex["src_row"][e] == ri
+                name = ex["category_names"][ex["category_id"][e]]
+                k = int(ex["position"][e])
+                assert inv_order[name][k] == json.dumps(slim, ensure_ascii=False) and labels_of[name][k] == lab and rules[lab] == name
+                e += 1
+        assert e == (first_rec[ri + 1] if ri + 1 < len(other) else n_rec)
