@@ -601,9 +601,10 @@ def main():
     if world > 1 and args.strong_rows > 0 and args.workload == "c3":
         # configs[3] as a FIXED table: --strong-rows rows (100 M) cut into `world` contiguous shards, the same fused launch on each rank's
         # shard (12.5 M rows per GPU at N = 8: configs[3] itself); max over ranks; together with sharded_exchange_strong the strong-scaling
-        # series of the whole configuration.  Skipped where a shard would not fit beside nothing else (2.9 KB per row).
+        # series of the whole configuration.  Skipped where a shard would not fit: 2.9 KB per row resident, and about twice that while
+        # the generator's chunks are concatenated (so 100 M rows run from N = 4 on; at N = 2 a shard is 145 GB before the doubling).
         srows = args.strong_rows // world
-        if srows * 2900 < 200e9:
+        if srows * 2900 * 2.2 < 250e9:
             del label, fused
             main_res.clear()
             torch.cuda.empty_cache()
