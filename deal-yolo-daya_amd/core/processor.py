@@ -1261,16 +1261,23 @@ class _Expansion:
             self.native.close()
 
 
-def _expand_table(n: int, cell_of, label_to_category: dict, cells=None, views=None) -> _Expansion:
+SPLIT_BATCH_ROWS = 150_000      # tables of at least two such batches are expanded batch by batch (native_json.SplitExpansionBatches)
+
+
+def _expand_table(n: int, cell_of, label_to_category: dict, cells=None, views=None, strings: bool = False) -> _Expansion:
     """Expansion of all rows: native for the regular cells (csrc/host_json.cpp + host_split_fast.h), ``_expand_cell_python`` for
     the rest, merged back into row order.  ``views`` = (ptr, len, missing) of the picked cells (the DataFrame's own str objects),
-    else ``cells`` is the list of picked cells; ``cell_of(i)`` returns row i's picked cell for the Python path."""
+    else ``cells`` is the list of picked cells; ``cell_of(i)`` returns row i's picked cell for the Python path.  ``strings``: the
+    caller will ask for the records as str objects, so a large table's are allocated while later batches are still parsed."""
     labels = list(label_to_category)
     label_ix = {lab: i for i, lab in enumerate(labels)}
     ex = None
     if n and _nj.enabled():
         try:
-            ex = _nj.split_expand_views(*views, labels) if views is not None else _nj.split_expand(cells, labels)
+            if views is not None and strings and n >= 2 * SPLIT_BATCH_ROWS:
+                ex = _nj.split_expand_views_batched(*views, labels, n_batches=min(8, n // SPLIT_BATCH_ROWS))
+            else:
+                ex = _nj.split_expand_views(*views, labels) if views is not None else _nj.split_expand(cells, labels)
         except UnicodeEncodeError:                             # a lone surrogate somewhere: CPython handles every cell
             ex = None
     out = _Expansion()
@@ -1470,7 +1477,7 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
     n = len(df)
 
     views, cells, cell_of, keep_alive = _picked_cells(df, json_columns)
-    ex = _expand_table(n, cell_of, label_to_category, cells=cells, views=views)
+    ex = _expand_table(n, cell_of, label_to_category, cells=cells, views=views, strings=text_dtype == "object")
     t1 = _time.perf_counter()
 
     # ---- categories in first-appearance order (:773, dict insertion order); category id per record -----------------
@@ -1596,6 +1603,7 @@ def split_frames(df: pd.DataFrame, label_to_category: dict, json_columns: Option
         stats["category_frames_fine"] = {k: round(v, 4) for k, v in fine.items()}
         if ex.native is not None:
             stats["native_s"] = dict(ex.native.seconds)
+            stats["expand_batches"] = len(getattr(ex.native, "_parts", (None,)))
     return result
 
 

@@ -405,6 +405,111 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     return failed ? -1 : 0;
 }
 
+/* The builder in two calls, for callers that know the texts' lengths long before they know where the strings go (the split step:
+ * the records of a batch of rows are final as soon as the batch is parsed, their places only after K8 + K6 have seen ALL records).
+ *   alloc_strs(ptr, len, n, seq, n_threads, all_ascii, ascii_out)   seq[i] = an ASCII str of len[i] characters with its text still
+ *       unwritten, or — for a text that is not ASCII — the finished str; ascii_out[i] says which (may be 0 with all_ascii != 0).
+ *       This is the part that needs the GIL; the caller runs it while other batches are still being parsed by native threads.
+ *   fill_strs(ptr, len, n, seq, slot, out, n_threads, ascii)   writes the ASCII texts and MOVES seq[i] to out[slot[i]] (seq[i]
+ *       becomes NULL; slot == 0 and out == 0: filled in place).  No Python API: runs on worker threads without the GIL. */
+static PyObject *alloc_strs(PyObject *self, PyObject *args) {
+    unsigned long long a_ptr, a_len, a_seq, a_ascii = 0;
+    Py_ssize_t n;
+    int n_threads, all_ascii = 0;
+    if (!PyArg_ParseTuple(args, "KKnKi|iK", &a_ptr, &a_len, &n, &a_seq, &n_threads, &all_ascii, &a_ascii)) return NULL;
+    vshared_t w;
+    memset(&w, 0, sizeof(w));
+    w.ptr = (const char *const *)(uintptr_t)a_ptr;
+    w.len = (const int64_t *)(uintptr_t)a_len;
+    w.objs = (PyObject **)(uintptr_t)a_seq;
+    w.n = (int64_t)n;
+    if (n == 0) Py_RETURN_NONE;
+    if (!all_ascii && !a_ascii) { PyErr_SetString(PyExc_ValueError, "alloc_strs: ascii_out is needed unless all_ascii"); return NULL; }
+    n_threads = clamp_threads(n_threads, (int64_t)n, 4096);
+    w.chunk = VCHUNK_MAX;
+    while (w.chunk > 256 && w.chunk * 4 * n_threads > (int64_t)n) w.chunk >>= 1;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (w.objs[i] == NULL) continue;
+        if (w.objs[i] != Py_None) { PyErr_SetString(PyExc_ValueError, "alloc_strs: the output array must be freshly allocated"); return NULL; }
+        w.objs[i] = NULL;
+        Py_DECREF(Py_None);
+    }
+    if (!all_ascii) {
+        w.ascii = (uint8_t *)(uintptr_t)a_ascii;
+        Py_BEGIN_ALLOW_THREADS
+        vrun_all(&w, n_threads, 0);
+        Py_END_ALLOW_THREADS
+    }
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *o = (!w.ascii || w.ascii[i]) ? PyUnicode_New((Py_ssize_t)w.len[i], 127)
+                                               : PyUnicode_DecodeUTF8(w.ptr[i], (Py_ssize_t)w.len[i], "strict");
+        if (!o) {
+            for (Py_ssize_t j = 0; j < i; ++j) { Py_DECREF(w.objs[j]); w.objs[j] = NULL; }
+            return NULL;
+        }
+        w.objs[i] = o;
+    }
+    Py_RETURN_NONE;
+}
+
+typedef struct {
+    const char *const *ptr;
+    const int64_t *len, *slot;
+    PyObject **seq, **out;
+    const uint8_t *ascii;
+    int64_t lo, hi;
+} fillw_t;
+
+static void *fill_worker(void *arg) {
+    fillw_t *w = (fillw_t *)arg;
+    for (int64_t i = w->lo; i < w->hi; ++i) {
+        PyObject *o = w->seq[i];
+        if (!w->ascii || w->ascii[i]) memcpy(PyUnicode_1BYTE_DATA(o), w->ptr[i], (size_t)w->len[i]);
+        if (w->out) {
+            w->out[w->slot ? w->slot[i] : i] = o;
+            w->seq[i] = NULL;
+        }
+    }
+    return NULL;
+}
+
+static PyObject *fill_strs(PyObject *self, PyObject *args) {
+    unsigned long long a_ptr, a_len, a_seq, a_slot, a_out, a_ascii = 0;
+    Py_ssize_t n;
+    int n_threads;
+    if (!PyArg_ParseTuple(args, "KKnKKKi|K", &a_ptr, &a_len, &n, &a_seq, &a_slot, &a_out, &n_threads, &a_ascii)) return NULL;
+    if (n == 0) Py_RETURN_NONE;
+    n_threads = clamp_threads(n_threads, (int64_t)n, 4096);
+    PyObject **seq = (PyObject **)(uintptr_t)a_seq, **out = (PyObject **)(uintptr_t)a_out;
+    const int64_t *slot = (const int64_t *)(uintptr_t)a_slot;
+    for (Py_ssize_t i = 0; i < n; ++i)
+        if (seq[i] == NULL) { PyErr_SetString(PyExc_ValueError, "fill_strs: the strings were already handed on"); return NULL; }
+    if (out) {                                    /* the target slots must be fresh: release the None references they hold */
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            PyObject **q = &out[slot ? slot[i] : i];
+            if (*q == NULL) continue;
+            if (*q != Py_None) { PyErr_SetString(PyExc_ValueError, "fill_strs: the output array must be freshly allocated"); return NULL; }
+            *q = NULL;
+            Py_DECREF(Py_None);
+        }
+    }
+    fillw_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].ptr = (const char *const *)(uintptr_t)a_ptr;
+        w[t].len = (const int64_t *)(uintptr_t)a_len;
+        w[t].slot = slot;
+        w[t].seq = seq;
+        w[t].out = out;
+        w[t].ascii = (const uint8_t *)(uintptr_t)a_ascii;
+        w[t].lo = (int64_t)n * t / n_threads;
+        w[t].hi = (int64_t)n * (t + 1) / n_threads;
+    }
+    Py_BEGIN_ALLOW_THREADS
+    run_workers(fill_worker, w, sizeof(w[0]), n_threads);
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
 /* map_strs(ptr, len, idx, slot, n, out, n_threads[, all_ascii[, na]]): out[slot[i]] = str(the len[k] bytes at ptr[k]), k = idx[i];
  * all_ascii != 0: the caller vouches that every text is ASCII; na[i] != 0 skips element i */
 static PyObject *map_strs(PyObject *self, PyObject *args) {
@@ -697,6 +802,8 @@ static PyMethodDef methods[] = {
     {"gather_utf8", gather_utf8, METH_VARARGS, "copy (pointer, length) views into one flat buffer at given offsets"},
     {"str_views", str_views, METH_VARARGS, "UTF-8 views of the str elements of an object array"},
     {"strs_from_utf8", strs_from_utf8, METH_VARARGS, "str objects from flat UTF-8 + offsets into an object array"},
+    {"alloc_strs", alloc_strs, METH_VARARGS, "str objects of given lengths, ASCII ones with their text still unwritten"},
+    {"fill_strs", fill_strs, METH_VARARGS, "write the texts of alloc_strs' strings and move them to their places"},
     {"map_strs", map_strs, METH_VARARGS, "out[slot[i]] = str(text idx[i]) from (pointer, length) views"},
     {"map_objects", map_objects, METH_VARARGS, "out[slot[i]] = src[idx[i]] for object arrays, on worker threads"},
     {"map_small", map_small, METH_VARARGS, "out[slot[i]] = table[codes[idx[i]]] for a small table of objects"},

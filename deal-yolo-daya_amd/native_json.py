@@ -522,6 +522,156 @@ def split_expand_views(ptr: np.ndarray, length: np.ndarray, missing: np.ndarray,
     return SplitExpansion(h, len(ptr))
 
 
+class SplitExpansionBatches:
+    """The expansion of a large table made in row batches, with the interface of SplitExpansion.  While native threads parse
+    batch b + 1, the calling thread — the one holding the GIL — allocates the str objects of batch b's records (lengths are final
+    once a batch is parsed; pycells.alloc_strings).  The texts are written, and the strings moved to their places in the category
+    frames, only when ``record_strings`` is told the places (pycells.fill_strings, worker threads, no GIL): the allocation, which
+    is the serial part of building 14 M strings, is hidden behind the parse instead of following it."""
+
+    def __init__(self, parts, bounds, shells):
+        self._parts, self._bounds = parts, bounds
+        self._shells = shells                                  # per batch (seq, ascii) or None
+        self.n_cells = bounds[-1][1] if bounds else 0
+        cat = np.concatenate
+        self.status = cat([p.status for p in parts])
+        self.n_expanded = cat([p.n_expanded for p in parts])
+        self.combo = cat([p.combo for p in parts])
+        self.reasons = cat([p.reasons for p in parts])
+        self.reasons_nonempty = cat([p.reasons_nonempty for p in parts])
+        self.row_cell = cat([p.row_cell + lo for p, (lo, _) in zip(parts, bounds)])
+        self.row_label = cat([p.row_label for p in parts])
+        self.event_cell = cat([p.event_cell + lo for p, (lo, _) in zip(parts, bounds)])
+        self.event_kind = cat([p.event_kind for p in parts])
+        undef, codes = {}, []
+        for p in parts:                                        # the batches' tables of undefined labels become one
+            remap = np.asarray([undef.setdefault(lab, len(undef)) for lab in p.undefined.tolist()] + [-1], np.int32)
+            codes.append(remap[p.event_code])                  # code -1 -> the trailing -1
+        self.event_code = cat(codes)
+        self.undefined = np.empty(len(undef), object)
+        self.undefined[:] = list(undef)
+        self.n_records = int(sum(p.n_records for p in parts))
+        self._rec_base = np.zeros(len(parts) + 1, np.int64)
+        np.cumsum([p.n_records for p in parts], out=self._rec_base[1:])
+        self.rec_ptr = cat([p.rec_ptr for p in parts])         # the handles stay open until close()
+        self.rec_len = cat([p.rec_len for p in parts])
+        self.fast_cells = int(sum(p.fast_cells for p in parts))
+        self.all_ascii = all(p.all_ascii for p in parts)
+        self.seconds = {k: float(sum(p.seconds[k] for p in parts)) for k in ("parse", "gather")}
+        self._open = True
+
+    def label_stats(self, n_labels: int):
+        first = np.full(n_labels, -1, np.int64)
+        count = np.zeros(n_labels, np.int64)
+        for p, base in zip(self._parts, self._rec_base[:-1].tolist()):
+            f, c = p.label_stats(n_labels)
+            take = (f >= 0) & (first < 0)
+            first[take] = f[take] + base
+            count += c
+        return first, count
+
+    def record_strings(self, idx=None, slot=None) -> np.ndarray:
+        from . import pycells
+
+        if not self._open:
+            raise ValueError("the expansion was closed")
+        shells, self._shells = self._shells, None              # usable once: the strings move out
+        if shells is None or idx is not None:
+            shells = None
+            return pycells.strings_from_views(self.rec_ptr, self.rec_len, idx, all_ascii=self.all_ascii, slot=slot,
+                                              checked=slot is not None and idx is None)
+        if slot is None:
+            return np.concatenate([pycells.fill_strings(p.rec_ptr, p.rec_len, seq, asc) for p, (seq, asc) in zip(self._parts, shells)])
+        slot = np.ascontiguousarray(slot, dtype=np.int64)
+        if len(slot) != self.n_records:
+            raise ValueError("record_strings: one slot per record")
+        out = np.empty(self.n_records, object)
+        for p, (seq, asc), lo, hi in zip(self._parts, shells, self._rec_base[:-1].tolist(), self._rec_base[1:].tolist()):
+            pycells.fill_strings(p.rec_ptr, p.rec_len, seq, asc, slot[lo:hi], out)
+        return out
+
+    def record_text(self, idx=None, slot=None):
+        from . import pycells
+
+        if not self._open:
+            raise ValueError("the expansion was closed")
+        return pycells.gather_text(self.rec_ptr, self.rec_len, idx, slot=slot)
+
+    @property
+    def row_json(self) -> np.ndarray:
+        return self.record_strings()
+
+    def close(self):
+        if self._open:
+            self._open = False
+            self._shells = None                                # strings never handed out are released unwritten
+            self.rec_ptr = self.rec_len = None
+            for p in self._parts:
+                p.close()
+
+    def __del__(self):
+        self.close()
+
+
+def split_expand_views_batched(ptr: np.ndarray, length: np.ndarray, missing: np.ndarray, labels: list, n_batches: int = 6,
+                               allocate: bool = True) -> SplitExpansionBatches:
+    """split_expand_views over ``n_batches`` row ranges, one native call each on a helper thread; the calling thread turns every
+    finished batch into its arrays and (``allocate``) the still-empty str objects of its records meanwhile."""
+    import queue
+    import threading
+
+    from . import pycells
+
+    L = _native.load_library()
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    missing = np.ascontiguousarray(missing, dtype=np.uint8)
+    n = len(ptr)
+    n_batches = max(1, min(int(n_batches), n))
+    bounds = [(n * b // n_batches, n * (b + 1) // n_batches) for b in range(n_batches)]
+    lab_buf, lab_off = _label_buffers(labels)
+    threads = max(1, len(os.sched_getaffinity(0)) - 1) if hasattr(os, "sched_getaffinity") else 0
+    ready = queue.Queue()
+    stop = threading.Event()
+
+    def parse_all():
+        for lo, hi in bounds:
+            if stop.is_set():
+                break
+            h = C.c_void_p()
+            rc = L.dyd_json_split_expand_v(ptr[lo:hi].ctypes.data, length[lo:hi].ctypes.data, missing[lo:hi].ctypes.data, hi - lo,
+                                           lab_buf.ctypes.data, lab_off.ctypes.data, len(labels), threads, C.byref(h))
+            ready.put((rc, h))
+            if rc != 0:
+                break
+
+    worker = threading.Thread(target=parse_all, name="dyd-split-parse", daemon=True)
+    worker.start()
+    parts, shells = [], []
+    allocate = allocate and pycells.available()
+    try:
+        for lo, hi in bounds:
+            rc, h = ready.get()
+            _native.check(rc, "dyd_json_split_expand_v")
+            part = SplitExpansion(h, hi - lo)
+            parts.append(part)
+            if allocate:
+                shells.append(pycells.alloc_strings(part.rec_ptr, part.rec_len, part.all_ascii))
+    except BaseException:
+        stop.set()
+        worker.join()
+        while not ready.empty():
+            rc, h = ready.get()
+            if rc == 0 and h:
+                L.dyd_split_free(h)
+        shells = None
+        for part in parts:
+            part.close()
+        raise
+    worker.join()
+    return SplitExpansionBatches(parts, bounds, shells if allocate else None)
+
+
 # ------------------------------------------------------------------------------------------ label_replace step
 RL_REWRITTEN, RL_EMPTY, RL_UNDECODABLE, RL_UNCHANGED, RL_IRREGULAR = 0, 1, 2, 3, 5
 

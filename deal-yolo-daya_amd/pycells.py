@@ -128,6 +128,37 @@ def strings_from_views(ptr: np.ndarray, length: np.ndarray, idx=None, n_threads:
     return out
 
 
+def alloc_strings(ptr: np.ndarray, length: np.ndarray, all_ascii: bool = False, n_threads: int = 0):
+    """First half of strings_from_views for callers that learn the places later: -> (seq, ascii) where seq[i] is an ASCII str of
+    length[i] characters whose text is still UNWRITTEN (or the finished str when text i is not ASCII; ascii[i] says which; ascii
+    is None with ``all_ascii``).  The strings must not be looked at before fill_strings has written them."""
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    n = len(ptr)
+    seq = np.empty(n, object)
+    ascii_ = None if all_ascii else np.zeros(n, np.uint8)
+    if n:
+        _dydpy.alloc_strs(ptr.ctypes.data, length.ctypes.data, n, seq.ctypes.data, _threads(n_threads), 1 if all_ascii else 0, _addr(ascii_))
+    return seq, ascii_
+
+
+def fill_strings(ptr: np.ndarray, length: np.ndarray, seq: np.ndarray, ascii_=None, slot=None, out=None, n_threads: int = 0) -> np.ndarray:
+    """Second half: the texts are written into alloc_strings' strings by worker threads (no GIL) and — with ``out`` — every string
+    MOVES to out[slot[i]] (seq is left holding None).  Without ``out`` the strings are filled in place and seq is returned."""
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    n = len(seq)
+    if len(ptr) != n or len(length) != n or (slot is not None and len(slot) != n):
+        raise ValueError("fill_strings: lengths differ")
+    if slot is not None:
+        slot = np.ascontiguousarray(slot, dtype=np.int64)
+        if out is None or (n and (int(slot.min()) < 0 or int(slot.max()) >= len(out))):
+            raise IndexError("fill_strings: slot out of range")
+    if n:
+        _dydpy.fill_strs(ptr.ctypes.data, length.ctypes.data, n, seq.ctypes.data, _addr(slot), _addr(out), _threads(n_threads), _addr(ascii_))
+    return seq if out is None else out
+
+
 def take(values: np.ndarray, idx=None, n_threads: int = 0, checked: bool = False, slot=None) -> np.ndarray:
     """out[slot[i]] = values[idx[i]] on worker threads: 1-D object arrays (references counted with one atomic add per run of equal
     objects — numpy walks the scattered object headers on one thread) and 1-D arrays of 1 / 2 / 4 / 8-byte items; anything else,

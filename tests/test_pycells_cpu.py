@@ -166,3 +166,36 @@ def test_gathered_text_for_arrow_columns():
     order[slot] = np.arange(len(texts))
     assert bytes(data) == b"".join(raw[k] for k in order.tolist())
     assert np.array_equal(np.diff(off), lens[order])
+
+
+def test_strings_allocated_first_and_written_later():
+    """alloc_strings / fill_strings: the two halves of strings_from_views, with the places known only at the second"""
+    rng = np.random.default_rng(6)
+    texts = _texts(90_000, rng)
+    ptr, lens, keep, _, raw = _views(texts)
+    seq, asc = pycells.alloc_strings(ptr, lens)
+    assert asc.tolist() == [t.isascii() for t in texts]
+    slot = rng.permutation(len(texts))
+    out = np.empty(len(texts), object)
+    got = pycells.fill_strings(ptr, lens, seq, asc, slot, out)
+    want = [None] * len(texts)
+    for i, k in enumerate(slot.tolist()):
+        want[k] = texts[i]
+    assert got is out and out.tolist() == want and all(v is None for v in seq.tolist())
+    for k in (0, 5, 11, 102):
+        s = out[slot[k]]
+        assert type(s) is str and hash(s) == hash(texts[k]) and sys.getsizeof(s) == sys.getsizeof(texts[k]) and sys.getrefcount(s) == 3
+    with pytest.raises(ValueError):                                   # the strings have moved on
+        pycells.fill_strings(ptr, lens, seq, asc, slot, np.empty(len(texts), object))
+    used = np.empty(len(texts), object)
+    used[3] = "occupied"
+    seq2, asc2 = pycells.alloc_strings(ptr, lens)
+    with pytest.raises(ValueError):
+        pycells.fill_strings(ptr, lens, seq2, asc2, slot, used)
+    assert pycells.fill_strings(ptr, lens, seq2, asc2).tolist() == texts     # in place
+    ascii_ix = np.flatnonzero(np.array([t.isascii() for t in texts]))
+    seq3, none = pycells.alloc_strings(ptr[ascii_ix], lens[ascii_ix], all_ascii=True)
+    assert none is None and pycells.fill_strings(ptr[ascii_ix], lens[ascii_ix], seq3).tolist() == [texts[k] for k in ascii_ix.tolist()]
+    seq4, asc4 = pycells.alloc_strings(ptr, lens)                     # released unwritten: nothing reads the text of a dying str
+    del seq4, asc4
+    gc.collect()

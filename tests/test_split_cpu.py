@@ -12,10 +12,14 @@ from deal_yolo_daya_amd.core import processor as P
 from oracle import steps as osteps
 
 
-@pytest.fixture(autouse=True)
-def threaded_builders():
+@pytest.fixture(autouse=True, params=["one call", "row batches"])
+def threaded_builders(request, monkeypatch):
+    """every test twice: the table expanded by one native call, and in row batches with the records' str objects allocated
+    while later batches are parsed (processor.SPLIT_BATCH_ROWS is 150 000 rows in production)"""
     from deal_yolo_daya_amd import pycells
     pycells.set_min_threaded(64)
+    if request.param == "row batches":
+        monkeypatch.setattr(P, "SPLIT_BATCH_ROWS", 90)
     yield
     pycells.set_min_threaded()
 
@@ -41,6 +45,7 @@ def test_split_frames_equal_the_cpu_port_beyond_the_thread_threshold(oracle_back
     rules = synth.rules()
     got = P.split_frames(table, rules, backend=oracle_backend, stats=(st := {}))
     assert st["records"] > 5000 and st["fast_cells"] == len(table)
+    assert st["expand_batches"] == (len(table) // 90 if P.SPLIT_BATCH_ROWS == 90 else 1)
     _same_frames(got, osteps.split_frames(table, rules))
     # ratios that do not sum to one, another seed
     got = P.split_frames(table, rules, None, 6, 3, 1, random_seed=7, backend=oracle_backend)
