@@ -178,8 +178,12 @@ def host_pipeline(df, ref, cpu_rows):
                         "rows_per_s": round(rows_in / (time.perf_counter() - a), 1)})
             return out
 
-        c1 = crun("dedup", len(sub), lambda: osteps.dedup_frame(sub))
+        # the two key steps are pandas one-liners: timed on the WHOLE table (a 20 000-row sample sits in cache and flatters them)
+        c1 = crun("dedup", len(df), lambda: osteps.dedup_frame(df))
         c2 = crun("ref_filter", len(c1), lambda: osteps.ref_filter_frame(c1, ref))
+        del c1, c2
+        c1 = osteps.dedup_frame(sub)
+        c2 = osteps.ref_filter_frame(c1, ref)
         a = time.perf_counter()
         _, projected, _ = osteps.replace_frame(c2)
         _, c_other = osteps.iou_filter_frame(projected, MIN_BOXES, THR)
@@ -193,7 +197,8 @@ def host_pipeline(df, ref, cpu_rows):
                       "on one table, host-inclusive (DataFrame in, DataFrames out), one run",
             "rows": len(df), "seconds": round(total, 3), "rows_per_s": round(len(df) / total, 1), "rows_out": rows_out,
             "steps": steps, "cpu_port": cpu,
-            "cpu_port_sample": f"first {cpu_rows} rows of the same table (split: the first {max(1, cpu_rows // 10)} of its input), 1 core" if cpu else None}
+            "cpu_port_sample": f"dedup, ref_filter: the whole table; replace + iou_filter: first {cpu_rows} rows of it through the first two steps; "
+                               f"split: the first {max(1, cpu_rows // 10)} rows of its input; 1 core" if cpu else None}
 
 
 def path_io(df, rows):

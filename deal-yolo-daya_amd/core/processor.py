@@ -299,10 +299,30 @@ def dedup_keep_mask(col: pd.Series, keep="first", backend=None, verify: bool = T
     return mask
 
 
+def _frame_rows(df: pd.DataFrame, mask: np.ndarray, keep_labels: bool) -> pd.DataFrame:
+    """``df[mask]`` as a new frame (``.reset_index(drop=True)`` unless ``keep_labels``): for a large table one threaded take per
+    column (object cells with batched reference counts, csrc/pyhelpers.c) instead of pandas' per-block take."""
+    if len(df) >= _pycells.MIN_THREADED and _pycells.available() and df.columns.is_unique and df.columns.nlevels == 1:
+        rows = np.flatnonzero(mask)
+
+        def taken(c):
+            col = df[c]
+            if isinstance(col.dtype, np.dtype) and col.dtype.kind in "Oiufb":
+                return _pycells.take(col.to_numpy(), rows, checked=True)
+            return col.array.take(rows)                         # extension arrays and datetimes keep their dtype through their own take
+
+        out = pd.DataFrame({c: taken(c) for c in df.columns}, copy=False)
+        out.columns = df.columns                                # the same Index object kind / name
+        if keep_labels:
+            out.index = df.index[rows]
+        return out
+    return df[mask].copy() if keep_labels else df[mask].reset_index(drop=True)
+
+
 def dedup_frame(df: pd.DataFrame, keep="first", backend=None) -> pd.DataFrame:
     """In-memory twin of the dedup step: rows in original order, index reset (:140-144)."""
     mask = dedup_keep_mask(df["source"], keep, backend)
-    return df[mask].reset_index(drop=True)
+    return _frame_rows(df, mask, keep_labels=False)
 
 
 def deduplicate_csv_by_source(
@@ -394,7 +414,7 @@ def ref_hit_mask(main_col: pd.Series, ref_col: pd.Series, backend=None, verify: 
 def ref_filter_frame(df_main: pd.DataFrame, df_ref: pd.DataFrame, compare_col: str = "source",
                      backend=None) -> pd.DataFrame:
     hit = ref_hit_mask(df_main[compare_col], df_ref[compare_col], backend)
-    return df_main[~hit].copy()
+    return _frame_rows(df_main, ~hit, keep_labels=True)
 
 
 def remove_duplicates_between_csv(

@@ -453,3 +453,33 @@ def test_the_iou_step_takes_the_table_the_replace_step_parked(oracle_backend, tm
     assert P.LAST_IO_PATH["iou"] == "native"
     P.clear_step_cache()
     P._STEP_CACHE["params"] = (2, 0.98)
+
+
+def test_row_subsets_of_large_frames_keep_dtypes_labels_and_values(oracle_backend):
+    """dedup_frame / ref_filter_frame build their result with one threaded take per column once the table is large: the frame
+    must be what ``df[mask].reset_index(drop=True)`` / ``df[~hit].copy()`` are (processor.py:144, :199) for every column kind"""
+    from deal_yolo_daya_amd import pycells
+    rng = np.random.default_rng(0)
+    n = 6000
+    df = pd.DataFrame({"source": [f"u{i % 3500}" for i in range(n)], "w": rng.integers(0, 9, n), "f": rng.random(n),
+                       "cat": pd.Categorical(rng.integers(0, 4, n)), "b": rng.random(n) < 0.5,
+                       "s": pd.array([None if i % 7 == 0 else f"x{i}" for i in range(n)], dtype="string"),
+                       "o": [None if i % 5 == 0 else (i, "t") for i in range(n)],
+                       "d": pd.date_range("2020-01-01", periods=n, freq="h"), "I": pd.array(rng.integers(0, 5, n), dtype="Int64")})
+    df.index = pd.Index(rng.permutation(n) * 3, name="lab")
+    ref = pd.DataFrame({"source": [f"u{i}" for i in range(0, 3500, 3)] + [None]})
+    pycells.set_min_threaded(64)
+    try:
+        for keep in ("first", "last", False):
+            got = P.dedup_frame(df, keep, backend=oracle_backend)
+            exp = df.drop_duplicates(subset=["source"], keep=keep).reset_index(drop=True)
+            pd.testing.assert_frame_equal(got, exp)
+            assert got.equals(exp) and type(got.index) is type(exp.index)
+        got = P.ref_filter_frame(df, ref, backend=oracle_backend)
+        exp = df[~df["source"].astype(str).isin(set(ref["source"].dropna().astype(str)))].copy()
+        pd.testing.assert_frame_equal(got, exp)
+        assert got.index.name == "lab" and 0 < len(got) < len(df)
+        got.iloc[0, 1] = 777                                       # the result owns its data
+        assert df.loc[got.index[0], "w"] != 777 or exp.iloc[0, 1] == 777
+    finally:
+        pycells.set_min_threaded()
