@@ -316,7 +316,7 @@ def _frame_rows(df: pd.DataFrame, mask: np.ndarray, keep_labels: bool) -> pd.Dat
         if keep_labels:
             out.index = df.index[rows]
         return out
-    return df[mask].copy() if keep_labels else df[mask].reset_index(drop=True)
+    return df[mask] if keep_labels else df[mask].reset_index(drop=True)      # (a boolean take is a copy already)
 
 
 def dedup_frame(df: pd.DataFrame, keep="first", backend=None) -> pd.DataFrame:
@@ -1090,7 +1090,7 @@ def replace_and_filter_frame(df: pd.DataFrame, min_boxes: int = 2, iou_threshold
                       else pd.Series(texts, index=kept.index))
     kept["width"] = widths
     kept["height"] = heights
-    out = (kept, excluded, kept[high], kept[~high])
+    out = (kept, excluded, _frame_rows(kept, high, keep_labels=True), _frame_rows(kept, ~high, keep_labels=True))
     totals["s_frame_in"] = t1 - t0
     totals["s_frame_out"] = _t.perf_counter() - t2
     if stats is not None:
