@@ -1281,7 +1281,7 @@ class _Expansion:
             self.native.close()
 
 
-SPLIT_BATCH_ROWS = 150_000      # tables of at least two such batches are expanded batch by batch (native_json.SplitExpansionBatches)
+SPLIT_BATCH_ROWS = 40_000       # tables of at least two such batches are expanded in up to 8 batches (native_json.SplitExpansionBatches)
 
 
 def _expand_table(n: int, cell_of, label_to_category: dict, cells=None, views=None, strings: bool = False) -> _Expansion:

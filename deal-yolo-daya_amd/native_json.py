@@ -316,13 +316,13 @@ def scan_boxes_buffers(data, off, missing, n_threads: int = 0, keep=None) -> Box
     return BoxScan(h, len(off) - 1, (keep, data, off, missing))
 
 
-def strings_from_buffers(text, off, na=None) -> np.ndarray:
+def strings_from_buffers(text, off, na=None, n_threads: int = 0) -> np.ndarray:
     """object array of str (None where na) from flat utf-8 + offsets: the CPython helper when it is built, pyarrow otherwise"""
     from . import pycells
 
     n = len(off) - 1
     if pycells.available():
-        return pycells.strings(text, off, na)
+        return pycells.strings(text, off, na, n_threads)
     import pyarrow as pa
 
     arr = pa.LargeStringArray.from_buffers(n, pa.py_buffer(np.ascontiguousarray(off, dtype=np.int64)),
@@ -383,10 +383,11 @@ class SplitExpansion:
     buffers (``rec_ptr`` / ``rec_len``: one view per record) until ``close()`` — ``record_strings`` turns them into str objects, in
     any order, without a flat copy of the text in between."""
 
-    def __init__(self, handle, n_cells):
+    def __init__(self, handle, n_cells, string_threads: int = 0):
         L = _native.load_library()
         self._h = handle
         self.n_cells = n_cells
+        self._string_threads = string_threads                     # for the per-cell strings (combo, reasons) made right here
         self.status = _view(L.dyd_split_status(handle), np.uint8, n_cells).copy()
         self.n_expanded = _view(L.dyd_split_n_expanded(handle), np.int32, n_cells).copy()
         rows, events = int(L.dyd_split_rows(handle)), int(L.dyd_split_events(handle))
@@ -421,7 +422,7 @@ class SplitExpansion:
         if count == 0:
             return np.empty(0, object)
         text, off = self._buffers(which, count)
-        return strings_from_buffers(text, off)
+        return strings_from_buffers(text, off, n_threads=self._string_threads)
 
     def label_stats(self, n_labels: int):
         """per label of the rules: (index of the first record carrying it or -1, number of records)"""
@@ -653,7 +654,7 @@ def split_expand_views_batched(ptr: np.ndarray, length: np.ndarray, missing: np.
         for lo, hi in bounds:
             rc, h = ready.get()
             _native.check(rc, "dyd_json_split_expand_v")
-            part = SplitExpansion(h, hi - lo)
+            part = SplitExpansion(h, hi - lo, string_threads=1)    # (the cores are parsing the next batch: no helper threads here)
             parts.append(part)
             if allocate:
                 shells.append(pycells.alloc_strings(part.rec_ptr, part.rec_len, part.all_ascii))

@@ -15,7 +15,7 @@ from oracle import steps as osteps
 @pytest.fixture(autouse=True, params=["one call", "row batches"])
 def threaded_builders(request, monkeypatch):
     """every test twice: the table expanded by one native call, and in row batches with the records' str objects allocated
-    while later batches are parsed (processor.SPLIT_BATCH_ROWS is 150 000 rows in production)"""
+    while later batches are parsed (processor.SPLIT_BATCH_ROWS is 40 000 rows in production)"""
     from deal_yolo_daya_amd import pycells
     pycells.set_min_threaded(64)
     if request.param == "row batches":
