@@ -609,10 +609,19 @@ def main():
         # series of the whole configuration.  Skipped where a shard would not fit: 2.9 KB per row resident, and about twice that while
         # the generator's chunks are concatenated (so 100 M rows run from N = 4 on; at N = 2 a shard is 145 GB before the doubling).
         srows = args.strong_rows // world
-        if srows * 2900 * 2.2 < 250e9:
+        fits = srows * 2900 * 2.2 < 250e9
+        if fits:
             del label, fused
             main_res.clear()
             torch.cuda.empty_cache()
+            # every rank must take the same branch (the leg ends in a collective): the shard has to fit on ALL of them, as measured now
+            ok = torch.tensor([1 if torch.cuda.mem_get_info(dev)[0] > srows * 2900 * 2.2 else 0], dtype=torch.int32,
+                              device="cpu" if dist.get_backend() == "gloo" else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            fits = bool(int(ok.item()))
+            if not fits:
+                label = fused = None
+        if fits:
             sres = resident(srows, None, args.strong_steps, 3, 200.0, synth.SEED + 7000 + 1000 * rank)
             st = torch.tensor([sres["elapsed"]], dtype=torch.float64, device=dev)
             if dist.get_backend() == "gloo":
