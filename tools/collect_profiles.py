@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/ (rocprofv3 CSVs from tools/gpu_profile.sh) into the committed summaries:
-profiles/<tag>_bench_kernel_stats.csv, profiles/<tag>_pmc_summary.json, profiles/<tag>_bench.json.
+profiles/<tag>_bench_kernel_stats.csv, profiles/<tag>_pmc_summary.json, profiles/<tag>_bench.json,
+profiles/<tag>_bench_under_rocprof.json (bench.py's line from the run under the kernel trace).
 usage: python tools/collect_profiles.py r01"""
 import glob
 import json
@@ -48,6 +49,13 @@ if os.path.exists(bl):
     lines = [l for l in open(bl) if l.startswith("{")]
     if lines:
         with open(os.path.join(prof, f"{tag}_bench.json"), "w") as fh:
+            fh.write(lines[-1])
+
+rl = os.path.join(out, "rocprof_bench.log")                 # the same command's own line while the kernel trace was on
+if os.path.exists(rl):
+    lines = [l for l in open(rl, errors="replace") if l.startswith("{")]
+    if lines:
+        with open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w") as fh:
             fh.write(lines[-1])
 
 bj = os.path.join(prof, f"{tag}_bench.json")
