@@ -656,17 +656,45 @@ def _replace_csv_core(input_csv_path, backend, fuse=None):
             "columns": columns, "high": high, "totals": totals}
 
 
-def _replace_csv_write(core, output_csv_path, excluded_output_file):
+def _replace_csv_write(core, output_csv_path, excluded_output_file, also=None, reread=False):
     """processed CSV (native writer) + excluded CSV; returns the step's result dict, or _LATE_FALLBACK when the writer's
-    sample check against pandas refused the table (nothing written then)."""
+    sample check against pandas refused the table (nothing written then).
+
+    The processed file is written by a thread of its own, and what the IoU step needs is prepared meanwhile: ``reread`` leaves
+    the light columns as that step's read_csv would type them in core["reread"] (_as_reread: pandas, 0.3 s per 300 k rows);
+    ``also`` = [path, names, None, n_rows, rows] entries of the IoU step's two files (fused twin) are checked against pandas and
+    written side by side with the processed file — entry[2] is then set to the columns; left None when the writer refused one
+    of them (nothing of those files written).  A buffered write holds its file's inode lock, so the writer's threads take turns
+    inside ONE file, while different files proceed in parallel."""
     table, kept_rows, excluded_rows = core["table"], core["kept_rows"], core["excluded_rows"]
-    if not _fc.write_table(str(output_csv_path), core["names"], core["columns"], table.n_rows, rows=kept_rows):
+    main = _fc.prepare_write(str(output_csv_path), core["names"], core["columns"], table.n_rows, kept_rows)
+    if main is None:
         return _LATE_FALLBACK                              # the row count was already printed
-    if excluded_output_file is not None:
-        excluded = table.light.iloc[excluded_rows].copy()
-        excluded.insert(table.names.index(ANNOTATION_COL), ANNOTATION_COL, np.nan)
-        Path(excluded_output_file).parent.mkdir(parents=True, exist_ok=True)
-        excluded[table.names].to_csv(excluded_output_file, index=False, encoding="utf-8-sig")
+    writing = [_fc.WriteInBackground(main)]
+    try:
+        if also or reread:
+            try:
+                cols = _as_reread(core, core["names"])
+            except Exception:  # noqa: BLE001 - work done ahead for the IoU step: its failure belongs to that step
+                cols = None
+            if reread and cols is not None:
+                core["reread"] = cols
+            if also and cols is not None:
+                jobs = [_fc.prepare_write(p_, nm_, cols, n_, r_) for p_, nm_, _, n_, r_ in also]
+                if all(j is not None for j in jobs):
+                    writing += [_fc.WriteInBackground(j) for j in jobs]
+                    also[:] = [(p_, nm_, cols, n_, r_) for p_, nm_, _, n_, r_ in also]
+        if excluded_output_file is not None:
+            excluded = table.light.iloc[excluded_rows].copy()
+            excluded.insert(table.names.index(ANNOTATION_COL), ANNOTATION_COL, np.nan)
+            Path(excluded_output_file).parent.mkdir(parents=True, exist_ok=True)
+            excluded[table.names].to_csv(excluded_output_file, index=False, encoding="utf-8-sig")
+    finally:
+        ok = [w.done() for w in writing]
+    if not ok[0]:
+        return _LATE_FALLBACK
+    if also and len(ok) > 1 and not all(ok[1:]):
+        also[:] = [(p_, nm_, None, n_, r_) for p_, nm_, _, n_, r_ in also]      # an I/O failure there: the caller's other route
     return {
         "filtered_rows": int(len(kept_rows)),
         "excluded_rows": int(len(excluded_rows)),
@@ -697,7 +725,7 @@ def _replace_csv_fast(input_csv_path, output_csv_path, excluded_output_file, bac
         return NotImplemented
     parked = False
     try:
-        res = _replace_csv_write(core, output_csv_path, excluded_output_file)
+        res = _replace_csv_write(core, output_csv_path, excluded_output_file, reread=fuse is not None)
         if res is not _LATE_FALLBACK and fuse is not None:
             heavy = [c for c in core["columns"] if isinstance(c, _fc.Utf8Column)]
             heavy_ok = all((c.na != 0).sum() < len(c) or len(c) == 0 for c in heavy)     # an all-NaN text column is re-read as float
@@ -727,10 +755,10 @@ def _iou_csv_cached(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_thre
         if _file_key(input_csv_path) != entry["key"]:     # the file was touched since: what is parked is not what is on disk
             return False
         kept_rows, high = core["kept_rows"], core["high"]
-        cols = _as_reread(core, core["names"])
+        cols = core.get("reread") or _as_reread(core, core["names"])      # (made while the replace step was writing its file)
         n = core["table"].n_rows
-        return bool(_fc.write_table(str(high_iou_csv), core["names"], cols, n, rows=kept_rows[high[kept_rows]])
-                    and _fc.write_table(str(other_csv), core["names"], cols, n, rows=kept_rows[~high[kept_rows]]))
+        return bool(_fc.write_tables([(str(high_iou_csv), core["names"], cols, n, kept_rows[high[kept_rows]]),
+                                      (str(other_csv), core["names"], cols, n, kept_rows[~high[kept_rows]])]))
     finally:
         core["scan"].close()
 
@@ -857,8 +885,8 @@ def _iou_csv_fast(input_csv_path, high_iou_csv, other_csv, min_boxes, iou_thresh
     scan.close()
     columns = [table.heavy[nm] if nm in table.heavy else table.light[nm] for nm in table.names]
     # sample-check both files before writing either, so a fallback never leaves half the output behind
-    ok = (_fc.write_table(str(high_iou_csv), table.names, columns, table.n_rows, rows=np.flatnonzero(mask))
-          and _fc.write_table(str(other_csv), table.names, columns, table.n_rows, rows=np.flatnonzero(~mask)))
+    ok = _fc.write_tables([(str(high_iou_csv), table.names, columns, table.n_rows, np.flatnonzero(mask)),
+                           (str(other_csv), table.names, columns, table.n_rows, np.flatnonzero(~mask))])
     return None if ok else NotImplemented
 
 
@@ -1144,12 +1172,15 @@ def process_csv_replace_and_filter(
                 heavy_ok = all((c.na != 0).sum() < len(c) or len(c) == 0 for c in core["columns"]
                                if isinstance(c, _fc.Utf8Column))                    # an all-NaN text column is re-read as float
                 kept_rows, high = core["kept_rows"], core["high"]
-                res = _replace_csv_write(core, output_csv_path, excluded_output_file) if heavy_ok else _LATE_FALLBACK
+                n = core["table"].n_rows
+                both = [(str(high_iou_csv), core["names"], None, n, kept_rows[high[kept_rows]]),
+                        (str(other_csv), core["names"], None, n, kept_rows[~high[kept_rows]])]
+                res = _replace_csv_write(core, output_csv_path, excluded_output_file, also=both) if heavy_ok else _LATE_FALLBACK
                 if res is not _LATE_FALLBACK:
-                    cols = _as_reread(core, core["names"])
-                    n = core["table"].n_rows
-                    ok = (_fc.write_table(str(high_iou_csv), core["names"], cols, n, rows=kept_rows[high[kept_rows]])
-                          and _fc.write_table(str(other_csv), core["names"], cols, n, rows=kept_rows[~high[kept_rows]]))
+                    ok = both[0][2] is not None                # the three files went out side by side
+                    if not ok:
+                        cols = _as_reread(core, core["names"])
+                        ok = _fc.write_tables([(p_, nm_, cols, n_, r_) for p_, nm_, _, n_, r_ in both])
                     if ok:
                         LAST_IO_PATH["replace_iou"] = "fused-native"
                         LAST_IO_PATH["replace"] = LAST_IO_PATH["iou"] = "native"

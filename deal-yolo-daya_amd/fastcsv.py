@@ -117,6 +117,19 @@ class CsvIndex:
             self._h = None
 
     def __del__(self):
+        # dropping the index of a large file unmaps gigabytes (0.13 s per 1.6 GB file): nobody waits for that — a thread of its own
+        h = self._h
+        if h is not None and self._buf is not None and self._buf.size >= (64 << 20):
+            import sys
+            import threading
+            try:
+                if not sys.is_finalizing():
+                    free = _native.load_library().dyd_csv_free
+                    self._h = None
+                    threading.Thread(target=free, args=(h,), name="dyd-csv-free", daemon=True).start()
+                    return
+            except Exception:  # noqa: BLE001 - no thread to be had: free it here
+                self._h = h
         self.close()
 
     def has_cr(self) -> bool:
@@ -229,6 +242,18 @@ def _series_column(s: pd.Series):
     if s.dtype == np.bool_:
         return (3, np.ascontiguousarray(s.to_numpy().astype(np.uint8)), None, None)
     if kind == "O":
+        from . import pycells
+        if pycells.available() and len(s) >= 4096:
+            # a column of str cells (missing ones aside) is copied out of the str objects' own UTF-8 by worker threads: no per-cell
+            # Python.  Missing = what to_csv prints as the empty field (None, NaN, NaT, pd.NA).
+            arr = s.to_numpy()
+            na_b = np.zeros(len(arr), bool) if pycells.all_str(arr) else np.asarray(pd.isna(arr), dtype=bool)
+            try:
+                flat = pycells.flat_utf8(arr, na_b)
+            except UnicodeEncodeError:
+                flat = None
+            if flat is not None:                            # (None: some present cell is not a str -> the per-cell walk below)
+                return (0, flat[0] if len(flat[0]) else np.zeros(1, np.uint8), flat[1], na_b.astype(np.uint8))
         vals = s.tolist()
         na = np.fromiter((v is None or (type(v) is float and v != v) for v in vals), dtype=np.uint8, count=len(vals))
         # csv.writer prints str(value) for the scalars an object column can hold after JSON / CSV parsing
@@ -261,8 +286,65 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
     orders source rows (default: all).  Returns False — without touching ``path`` — when a column type is
     not covered or when the sample check against pandas disagrees.  ``append`` / ``header`` = to_csv's
     mode="a" / header= (an appended part carries no BOM, like a text file opened for append at a non-zero offset)."""
-    if not enabled() or not _utf8_like(encoding):
+    job = _prepare_write(path, names, columns, n_rows, rows, encoding, check_rows, append, header)
+    return job is not None and job()
+
+
+def write_tables(tables: list, encoding: str = "utf-8-sig") -> bool:
+    """Several files at once: tables[i] = (path, names, columns, n_rows, rows).  Every table is checked against pandas first —
+    False, with nothing written, if any of them is refused — and then the files are written side by side, one thread each on top
+    of the writer's own: a buffered write holds its file's inode lock (tmpfs, ext4 and xfs alike), so the sixteen pwrite streams of
+    ONE file take turns, while different files proceed in parallel."""
+    import threading
+
+    jobs = [_prepare_write(path, names, columns, n_rows, rows, encoding) for path, names, columns, n_rows, rows in tables]
+    if any(j is None for j in jobs):
         return False
+    if len(jobs) == 1:
+        return jobs[0]()
+    ok = [False] * len(jobs)
+
+    def run(i):
+        ok[i] = jobs[i]()
+
+    threads = [threading.Thread(target=run, args=(i,), name="dyd-csv-write") for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return all(ok)
+
+
+class WriteInBackground:
+    """one prepared table being written by a thread of its own (the writer's sixteen on top): ``done()`` joins -> True on success"""
+
+    def __init__(self, job):
+        import threading
+
+        self._ok = False
+        self._thread = threading.Thread(target=self._run, args=(job,), name="dyd-csv-write")
+        self._thread.start()
+
+    def _run(self, job):
+        self._ok = bool(job())
+
+    def done(self) -> bool:
+        self._thread.join()
+        return self._ok
+
+
+def prepare_write(path: str, names: list, columns: list, n_rows: int, rows=None, encoding: str = "utf-8-sig"):
+    """write_table in two halves: the column buffers and the sample check against pandas now -> a callable that writes the file
+    (True on success), or None when the table is refused (nothing written)"""
+    return _prepare_write(path, names, columns, n_rows, rows, encoding)
+
+
+def _prepare_write(path: str, names: list, columns: list, n_rows: int, rows=None, encoding: str = "utf-8-sig",
+                   check_rows: int = 40, append: bool = False, header: bool = True):
+    """everything of write_table up to the file itself: column buffers, the sample check against pandas.  -> a callable that
+    writes the file (True on success), or None when the table is outside what the native writer reproduces."""
+    if not enabled() or not _utf8_like(encoding):
+        return None
     L = _native.load_library()
     specs, keep = [], []
     for col in columns:
@@ -271,7 +353,7 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
         else:
             sp = _series_column(col)
             if sp is None:
-                return False
+                return None
             specs.append(sp)
     arr = (_Cols * len(specs))()
     for i, (kind, data, off, na) in enumerate(specs):
@@ -284,7 +366,6 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
         if na is not None:
             na = np.ascontiguousarray(na, dtype=np.uint8); keep.append(na); arr[i].na = na.ctypes.data
     header_line = pd.DataFrame(columns=names).to_csv(index=False).encode("utf-8")
-    bom = _BOM if "sig" in encoding.lower() and not (append and os.path.exists(path) and os.path.getsize(path) > 0) else b""
     rows_arr = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
     n_out = n_rows if rows_arr is None else len(rows_arr)
 
@@ -301,14 +382,19 @@ def write_table(path: str, names: list, columns: list, n_rows: int, rows=None, e
         rc = L.dyd_csv_write(None, header_line, len(header_line), arr, len(specs), n_rows, srcc.ctypes.data, len(srcc), int(_QUOTE_CR), 1,
                              1, C.byref(mem), C.byref(ln))
         if rc != 0:
-            return False
+            return None
         got = bytes(_view(mem.value, np.uint8, ln.value))
         L.dyd_host_free(mem)
         if got != want:
-            return False
-    full_header = bom + (header_line if header else b"")
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    rc = L.dyd_csv_write(os.fsencode(path), full_header, len(full_header), arr, len(specs), n_rows,
-                         rows_arr.ctypes.data if rows_arr is not None else None, n_out, int(_QUOTE_CR), 0, 2 if append else 0,
-                         None, None)
-    return rc == 0
+            return None
+
+    def write() -> bool:
+        bom = _BOM if "sig" in encoding.lower() and not (append and os.path.exists(path) and os.path.getsize(path) > 0) else b""
+        full_header = bom + (header_line if header else b"")
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        rc = L.dyd_csv_write(os.fsencode(path), full_header, len(full_header), arr, len(specs), n_rows,
+                             rows_arr.ctypes.data if rows_arr is not None else None, n_out, int(_QUOTE_CR), 0, 2 if append else 0,
+                             None, None)
+        return rc == 0 and len(keep) >= 0          # (keep: the buffers behind `arr` live as long as this job)
+
+    return write

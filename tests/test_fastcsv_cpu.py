@@ -280,3 +280,39 @@ def test_writer_non_finite_floats_like_pandas(tmp_path):
     assert fastcsv.write_table(out, list(df.columns), [df[c] for c in df.columns], n, rows=rows, encoding="utf-8")
     with open(out, "rb") as f:
         assert f.read() == df.iloc[rows].to_csv(index=False).encode("utf-8")
+
+
+def test_large_object_columns_and_files_side_by_side(tmp_path):
+    """object columns of 4096 cells and more are flattened by worker threads straight from the str objects (missing cells of
+    every kind print as the empty field, like to_csv); write_tables checks every table first and writes the files concurrently"""
+    rng = np.random.default_rng(3)
+    n = 6000
+    odd = ['a,b', 'q"uote', "line\nbreak", "中文，标签", "", " lead", "NA", "1.50"]
+    src = [odd[i % len(odd)] if i % 7 == 0 else f"http://h/{i}.jpg" for i in range(n)]
+    holes = list(src)
+    for i in range(0, n, 11):
+        holes[i] = (None, float("nan"), pd.NA, pd.NaT)[(i // 11) % 4]
+    df = pd.DataFrame({"source": pd.Series(src, dtype=object), "holes": pd.Series(holes, dtype=object),
+                       "w": rng.integers(0, 4000, n), "f": rng.random(n), "b": rng.random(n) < 0.5})
+    cols = [df[c] for c in df.columns]
+    rows_a, rows_b = np.flatnonzero(rng.random(n) < 0.3), np.flatnonzero(rng.random(n) < 0.6)[::-1].copy()
+    assert fastcsv.write_table(str(tmp_path / "all.csv"), list(df.columns), cols, n)
+    df.to_csv(tmp_path / "all_pd.csv", index=False, encoding="utf-8-sig")
+    assert (tmp_path / "all.csv").read_bytes() == (tmp_path / "all_pd.csv").read_bytes()
+    assert fastcsv.write_tables([(str(tmp_path / "a.csv"), list(df.columns), cols, n, rows_a),
+                                 (str(tmp_path / "b.csv"), list(df.columns), cols, n, rows_b),
+                                 (str(tmp_path / "c.csv"), list(df.columns), cols, n, None)])
+    for name, rows in (("a", rows_a), ("b", rows_b)):
+        df.iloc[rows].to_csv(tmp_path / f"{name}_pd.csv", index=False, encoding="utf-8-sig")
+        assert (tmp_path / f"{name}.csv").read_bytes() == (tmp_path / f"{name}_pd.csv").read_bytes()
+    assert (tmp_path / "c.csv").read_bytes() == (tmp_path / "all_pd.csv").read_bytes()
+    # one refused table (a dtype the writer does not cover): nothing of ANY file is written
+    bad = cols[:-1] + [pd.Series(pd.date_range("2020-01-01", periods=n))]
+    assert not fastcsv.write_tables([(str(tmp_path / "x.csv"), list(df.columns), cols, n, None),
+                                     (str(tmp_path / "y.csv"), list(df.columns), bad, n, None)])
+    assert not (tmp_path / "x.csv").exists() and not (tmp_path / "y.csv").exists()
+    # a present cell that is not a str sends the column down the per-cell walk, with the same bytes
+    mixed = pd.Series([7 if i == 4500 else v for i, v in enumerate(src)], dtype=object)
+    assert fastcsv.write_table(str(tmp_path / "m.csv"), ["source"], [mixed], n)
+    pd.DataFrame({"source": mixed}).to_csv(tmp_path / "m_pd.csv", index=False, encoding="utf-8-sig")
+    assert (tmp_path / "m.csv").read_bytes() == (tmp_path / "m_pd.csv").read_bytes()
