@@ -383,6 +383,63 @@ struct FastCell {
         ++box;
     }
 
+    // A coordinate in the spelling json.dumps gives it: [-]digits[.digits], at most 19 digits, no exponent, mantissa <= 2^53 — the
+    // value is then one exact int -> double conversion, or one correctly rounded division of exact operands (as in number()).
+    // false: not that shape (the caller walks the point the general way).  The caller guarantees 48 readable bytes at q.
+    static inline bool lean_coord(const char *&q, double &v, bool &is_int) {
+        const char *s = q;
+        const bool neg = *s == '-';
+        s += neg;
+        const char *ib = s;
+        uint64_t m = 0;
+        while (fj_is_digit(*s) && s - ib < 20) { m = m * 10 + (uint64_t)(*s - '0'); ++s; }
+        const int n_int = (int)(s - ib);
+        if (n_int == 0 || (ib[0] == '0' && n_int > 1)) return false;
+        int n_frac = 0;
+        if (*s == '.') {
+            const char *fb = ++s;
+            while (fj_is_digit(*s) && s - fb < 20) { m = m * 10 + (uint64_t)(*s - '0'); ++s; }
+            n_frac = (int)(s - fb);
+            if (n_frac == 0) return false;
+        }
+        if (n_int + n_frac > 19 || m > 9007199254740992ull || *s == 'e' || *s == 'E' || fj_is_digit(*s)) return false;
+        static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18};
+        const double d = n_frac ? (double)m / p10[n_frac] : (double)m;
+        v = neg ? -d : d;
+        is_int = n_frac == 0;
+        q = s;
+        return true;
+    }
+
+    // p at the '{' of a point spelled {"x": <coord>, "y": <coord>} (blanks after ':' and ',' optional): pushes it.  false, with
+    // nothing consumed, for every other spelling.
+    inline bool lean_point() {
+        if (end - p < 112) return false;                       // every read below stays inside the cell
+        const char *q = p;
+        if (memcmp(q, "{\"x\":", 5)) return false;
+        q += 5;
+        q += *q == ' ';
+        double x, y;
+        bool xi, yi;
+        if (!lean_coord(q, x, xi)) return false;
+        if (*q != ',') return false;
+        ++q;
+        q += *q == ' ';
+        if (memcmp(q, "\"y\":", 4)) return false;
+        q += 4;
+        q += *q == ' ';
+        if (!lean_coord(q, y, yi)) return false;
+        if (*q != '}') return false;
+        p = q + 1;
+        A.xy.need(2);
+        A.xy.p[A.xy.n] = x;
+        A.xy.p[A.xy.n + 1] = y;
+        A.xy.n += 2;
+        A.isint.push((uint8_t)((xi ? 1 : 0) | (yi ? 2 : 0)));
+        if ((xi && std::fabs(x) > 33554432.0) || (yi && std::fabs(y) > 33554432.0)) big_int = true;
+        return true;
+    }
+
     // p at the '[' of a ptList (reference :253): pushes the valid points; no output
     bool ptlist(int32_t &count) {
         ++p;
@@ -392,7 +449,9 @@ struct FastCell {
         while (true) {
             ws();
             if (p >= end) return false;
-            if (*p == '{') {
+            if (*p == '{' && lean_point()) {
+                ++count;
+            } else if (*p == '{') {
                 ++p;
                 bool hx = false, hy = false;
                 FastNum nx, ny;

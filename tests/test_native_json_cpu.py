@@ -445,8 +445,12 @@ def _random_number_token(r):
 def test_fast_lane_reprints_numbers_like_cpython(oracle_backend):
     r = random.Random(11)
     cells = []
+    # the point spellings around the lean point parser (host_json_fast.h lean_point): json.dumps' own, the compact one, and near
+    # misses that must take the general walk (blank before '}', two blanks, y first, a third member, a string coordinate)
+    shapes = ['{"x": %s, "y": %s}'] * 6 + ['{"x":%s,"y":%s}', '{"x":%s, "y": %s}', '{"x": %s, "y": %s }', '{"x": %s,  "y": %s}',
+                                          '{"y": %s, "x": %s}', '{"x": %s, "y": %s, "z": 1}', '{ "x": %s, "y": %s}']
     for _ in range(4000):
-        pts = ", ".join('{"x": %s, "y": %s}' % (_random_number_token(r), _random_number_token(r)) for _ in range(r.randint(1, 4)))
+        pts = ", ".join(r.choice(shapes) % (_random_number_token(r), _random_number_token(r)) for _ in range(r.randint(1, 8)))
         cells.append('{"width": %s, "objects": [{"polygon": {"ptList": [%s]}, "score": %s}], "k": [%s, %s]}'
                      % (_random_number_token(r), pts, _random_number_token(r), _random_number_token(r), _random_number_token(r)))
     scan = nj.scan_polygons(cells)
