@@ -482,10 +482,12 @@ def test_fast_lane_and_exact_walker_agree(oracle_backend, monkeypatch):
     fast = run()
     monkeypatch.setenv("DYD_JSON_FAST", "0")
     exact = run()
-    assert fast[-1] > 800 and exact[-1] == 0
-    for a, b in zip(fast[:-2], exact[:-2]):
-        assert np.array_equal(a, b, equal_nan=True)
-    assert fast[-2] == exact[-2]
+    monkeypatch.setenv("DYD_JSON_FAST", "2")           # the lane without its lean point parser: every point by the general walk
+    general = run()
+    assert fast[-1] > 800 and exact[-1] == 0 and general[-1] == fast[-1]
+    for a, b, c in zip(fast[:-2], exact[:-2], general[:-2]):
+        assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True)
+    assert fast[-2] == exact[-2] == general[-2]
 
 
 def _decodes(c):
