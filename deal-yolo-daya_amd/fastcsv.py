@@ -388,13 +388,15 @@ def _prepare_write(path: str, names: list, columns: list, n_rows: int, rows=None
         if got != want:
             return None
 
-    def write() -> bool:
+    buffers = (keep, specs, rows_arr)          # what `arr` points into: bound to the job below, alive as long as it is
+
+    def write(_buffers=buffers) -> bool:
         bom = _BOM if "sig" in encoding.lower() and not (append and os.path.exists(path) and os.path.getsize(path) > 0) else b""
         full_header = bom + (header_line if header else b"")
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         rc = L.dyd_csv_write(os.fsencode(path), full_header, len(full_header), arr, len(specs), n_rows,
                              rows_arr.ctypes.data if rows_arr is not None else None, n_out, int(_QUOTE_CR), 0, 2 if append else 0,
                              None, None)
-        return rc == 0 and len(keep) >= 0          # (keep: the buffers behind `arr` live as long as this job)
+        return rc == 0
 
     return write
