@@ -17,6 +17,9 @@ need no communication.  The two set-valued stages exchange hashes exactly once:
                 category size is made on every rank's device from the seed (K8, dyd_split_ids_seeded_dev): nothing
                 but the counts crosses ranks.
 
+    replace+IoU rows are independent: every rank runs the fused pass on its share of the rows, the shares balanced by the
+                annotation cells' bytes (shard_bounds_by_weight); ONE all-gather of five counts per rank for the totals
+
     label lines rows are independent (K7 per shard); ONE all-gather of the shards' text sizes (8 B each) turns the
                 local byte offsets into offsets inside the concatenated text of all ranks
 
@@ -40,6 +43,66 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple:
     lo = (n * rank) // world
     hi = (n * (rank + 1)) // world
     return lo, hi
+
+
+def shard_bounds_by_weight(weights, world: int, rank: int) -> tuple:
+    """Contiguous row range of `rank` holding about 1/world of sum(weights) ("shards are balanced by box count, not
+    row count, when n_i is skewed").  The cut after row i falls where the running sum first reaches k/world of the total, so the
+    ranges tile [0, n) in row order — "first occurrence" stays the lowest (rank, local index).  All-zero weights: by rows."""
+    w = np.asarray(weights, dtype=np.float64)
+    n = len(w)
+    if n == 0 or world <= 1:
+        return (0, n)
+    c = np.cumsum(w)
+    if not c[-1] > 0:
+        return shard_bounds(n, world, rank)
+    cuts = np.searchsorted(c, c[-1] * np.arange(1, world) / world, side="left") + 1
+    edges = np.concatenate([[0], np.minimum(cuts, n), [n]])
+    edges = np.maximum.accumulate(edges)
+    return int(edges[rank]), int(edges[rank + 1])
+
+
+def annotation_weights(col) -> np.ndarray:
+    """per row the bytes of its annotation cell (0 for a missing one) plus a constant for the row itself: what a row costs the
+    replace -> IoU pass is proportional to its text (points and boxes are spelled out in it), and it is known before any parsing"""
+    from . import pycells
+    values = col.to_numpy() if hasattr(col, "to_numpy") else np.asarray(col, dtype=object)
+    if pycells.available() and values.dtype == object:
+        try:
+            v = pycells.CellViews(values)
+            return np.where(v.missing != 0, 0, v.len).astype(np.int64) + 64
+        except UnicodeEncodeError:
+            pass
+    return np.fromiter((len(c) if isinstance(c, str) else 0 for c in values), dtype=np.int64, count=len(values)) + 64
+
+
+def replace_and_filter_sharded(df, min_boxes: int = 2, iou_threshold: float = 0.98, backend=None, group=None) -> dict:
+    """SURVEY §8e for the replace and IoU steps (a3, a4): rows are independent, so every rank runs the fused replace -> IoU pass
+    (processor.replace_and_filter_frame: scan, ONE fused K1+K2 launch per part, emit) on its contiguous share of the table and
+    nothing of the data path crosses ranks.  The shares are balanced by the annotation cells' bytes (`shard_bounds_by_weight` over
+    `annotation_weights`), not by rows: a table whose dense images cluster would otherwise leave most ranks waiting for one.
+    ONE all-gather of five counts per rank gives the totals.
+
+    `df` is the whole table on every rank (each rank touches only its rows' cells).  -> {"bounds": (lo, hi), "frames": (kept,
+    excluded, high, other) of the local rows with their original row labels, "totals": {rows, kept, excluded, high, other} over
+    all ranks, "per_rank": [[rows, kept, excluded, high, other], ...]}"""
+    from .core import processor as P
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds_by_weight(annotation_weights(df[P.ANNOTATION_COL]), world, rank)
+    frames = P.replace_and_filter_frame(df.iloc[lo:hi], min_boxes, iou_threshold, backend)
+    mine = [hi - lo] + [len(f) for f in frames]
+    per_rank = [mine]
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor(mine, dtype=torch.int64, device=dev)
+        every = torch.empty(world * len(mine), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(every, t, group=group)
+        per_rank = every.reshape(world, len(mine)).cpu().tolist()
+    names = ("rows", "kept", "excluded", "high", "other")
+    return {"bounds": (lo, hi), "frames": frames, "per_rank": per_rank,
+            "totals": {k: int(sum(r[i] for r in per_rank)) for i, k in enumerate(names)}}
 
 
 class HipOps:

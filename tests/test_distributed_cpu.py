@@ -72,6 +72,53 @@ def test_sharded_steps_match_single_process(world, tmp_path):
     assert np.array_equal(starts, off)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_replace_and_iou_shares_are_balanced_by_annotation_bytes(world, tmp_path):
+    """SURVEY §8e partitioning: the fused replace -> IoU pass per rank on contiguous shares cut by annotation bytes — the shares'
+    frames laid end to end are the single-process frames (row labels included), the totals agree on every rank, and no share
+    carries much more than its part of the bytes although the dense images sit in the first 13 % of the rows"""
+    from deal_yolo_daya_amd import synth
+    from deal_yolo_daya_amd.core import processor as P
+    from helpers import OracleBackend
+
+    res = _run(world, tmp_path)
+    dense = synth.to_frame(synth.generate(60, seed=31, boxes_per_row=40))
+    sparse = synth.to_frame(synth.generate(400, seed=32))
+    table = pd.concat([dense, sparse], ignore_index=True)
+    table.loc[[5, 200, 459], P.ANNOTATION_COL] = None
+    table.index = pd.Index(np.arange(len(table)) * 2 + 1)
+    kept, excluded, high, other = P.replace_and_filter_frame(table, 2, 0.98, OracleBackend())
+    bounds = [r["rf_bounds"] for r in res]
+    assert bounds[0][0] == 0 and bounds[-1][1] == len(table) and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+    for k, frame in enumerate((kept, excluded, high, other)):
+        assert sum((r["rf_labels"][k] for r in res), []) == frame.index.tolist()
+    assert sum((r["rf_bbox"] for r in res), []) == kept[P.BBOX_COL].tolist()
+    want = {"rows": len(table), "kept": len(kept), "excluded": len(excluded), "high": len(high), "other": len(other)}
+    assert all(r["rf_totals"] == want for r in res) and all(r["rf_per_rank"] == res[0]["rf_per_rank"] for r in res)
+    total = res[0]["rf_weight_total"]
+    assert sum(r["rf_weight"] for r in res) == total
+    heaviest_row = 40 * 12 * 40 + 2000                            # bytes of one dense row, generously
+    assert max(r["rf_weight"] for r in res) <= total / world + heaviest_row
+    by_rows = [sum(1 for _ in range(*b)) for b in bounds]
+    assert by_rows[0] < 0.85 * len(table) / world                 # the first share is short in rows: it holds the dense images
+
+
+def test_shard_bounds_by_weight_tiles_the_rows():
+    from deal_yolo_daya_amd.distributed import shard_bounds, shard_bounds_by_weight
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 5, 1000):
+        for world in (1, 2, 3, 8):
+            for w in (rng.integers(0, 50, n), np.zeros(n), np.r_[np.full(n // 2, 1000), np.ones(n - n // 2)]):
+                b = [shard_bounds_by_weight(w, world, r) for r in range(world)]
+                assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+                assert all(lo <= hi for lo, hi in b)
+                if n and w.sum() > 0:
+                    share = [w[lo:hi].sum() for lo, hi in b]
+                    assert max(share) <= w.sum() / world + w.max()
+                elif n:
+                    assert b == [shard_bounds(n, world, r) for r in range(world)]
+
+
 def test_shard_bounds_cover_and_balance():
     from deal_yolo_daya_amd.distributed import shard_bounds
     for n in (0, 1, 7, 8, 1000003):
