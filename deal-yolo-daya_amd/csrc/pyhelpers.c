@@ -15,6 +15,7 @@
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <limits.h>
 #include <pthread.h>
 #include <sched.h>
 #include <time.h>
@@ -326,6 +327,119 @@ static void vrun_all(vshared_t *w, int n_threads, int mode) {   /* without the G
 
 /* w: the texts, idx / slot / na, objs and n filled in.  Returns 0, or -1 with an exception set (nothing is left in the array
  * then). */
+/* ---- fresh arenas for a known amount of small str objects --------------------------------------------------------------------
+ * Creating millions of str objects is serial where it allocates (the GIL), and for the split step's records — ~300 bytes, i.e.
+ * pymalloc — most of an allocation's cost is not the allocator: pymalloc maps a new 256 KiB arena for every ~800 records, and
+ * every new 4 KiB page of it is a first-touch fault taken by the one thread everybody waits for.  On the GPU box's host (a VM)
+ * such faults do not even scale with threads: 12 GB/s for all sixteen together, against 260 GB/s for transparent huge pages
+ * (profiles/r03_first_touch.log).  Measured there for 14 M strings of 300 bytes: 0.85-0.91 s from cold arenas, 0.27-0.29 s from
+ * prepared ones.
+ *
+ * So the builders size what they are about to allocate and prepare it first, on all cores, on huge pages: a slab is mapped,
+ * advised MADV_HUGEPAGE and touched, and for the duration of the allocation loop pymalloc's ARENA allocator
+ * (PyObject_SetArenaAllocator, a public hook) hands out the slab's 256 KiB slots.  Afterwards the default allocator is back and
+ * the unused tail of the slab is unmapped.  pymalloc releases an arena with munmap(arena, size) whoever mapped it, so nothing of
+ * ours outlives the call: the slots are ordinary arenas.  Skipped below 4 MB (DYD_PREFAULT_MIN_MB) and with DYD_PREFAULT=0; a
+ * failure on the way just means the strings are allocated the ordinary way.
+ *
+ * (The same was built for strings beyond pymalloc's 512 bytes — the replace step's 2 KB bbox texts, which come from malloc: grow
+ * the main heap's top in 16 MiB blocks, advise and touch it, free the blocks into one chunk below a kept guard block.  Alone in a
+ * process it takes 1 M x 2.5 KB from 0.37 to 0.08 s; inside the real step, whose heap holds gigabytes of live and freed cells,
+ * glibc spends 175 ns per malloc whatever the pages' state and the reservation only added its own 0.06-0.1 s.  Dropped.) */
+#include <sys/mman.h>
+
+#define PF_HUGE ((size_t)2 << 20)
+
+typedef struct {
+    int arena_on;
+    char *map; size_t map_bytes;       /* the slab's mapping; slab = its 2 MiB-aligned part */
+    char *slab; size_t slab_bytes, slab_next;
+    PyObjectArenaAllocator orig;
+} prefault_t;
+
+static prefault_t *g_prefault = NULL;  /* the slab the installed arena allocator serves from (touched under the GIL only) */
+
+typedef struct { char *base; size_t lo, hi; } pf_touch_t;
+static void *pf_touch(void *arg) {
+    pf_touch_t *w = (pf_touch_t *)arg;
+    for (size_t o = w->lo; o < w->hi; o += 4096) ((volatile char *)w->base)[o] = 0;
+    return NULL;
+}
+
+static void *pf_arena_alloc(void *ctx, size_t size) {
+    prefault_t *pf = (prefault_t *)ctx;
+    if (size && (size & 4095) == 0) {
+        const size_t at = (pf->slab_next + size - 1) / size * size;        /* a slot is aligned to its size */
+        if (at + size <= pf->slab_bytes) { pf->slab_next = at + size; return pf->slab + at; }
+    }
+    return pf->orig.alloc(pf->orig.ctx, size);
+}
+static void pf_arena_free(void *ctx, void *ptr, size_t size) {
+    prefault_t *pf = (prefault_t *)ctx;
+    pf->orig.free(pf->orig.ctx, ptr, size);                                /* munmap(ptr, size): fine for a slot of the slab too */
+}
+
+static size_t pf_min_bytes(void) {
+    const char *e = getenv("DYD_PREFAULT_MIN_MB");
+    return (size_t)(e ? atol(e) : 4) << 20;
+}
+static int pf_enabled(void) {
+    const char *e = getenv("DYD_PREFAULT");
+    return !(e && e[0] == '0');
+}
+
+/* what a str object of this length takes from pymalloc (pool overhead included); nothing for one beyond its 512 bytes */
+static inline void pf_count(int64_t len, size_t *small) {
+    const size_t bs = ((size_t)len + 49 + 15) & ~(size_t)15;               /* PyASCIIObject (48) + text + NUL, 16-byte classes */
+    if (bs <= 512) *small += 4096 / ((4096 - 48) / bs);                    /* a 4 KiB pool holds (4096 - 48) / bs blocks */
+}
+
+/* GIL held (released while the pages are touched) */
+static void prefault_begin(prefault_t *pf, size_t small, int n_threads) {
+    memset(pf, 0, sizeof(*pf));
+    if (!pf_enabled() || g_prefault || small == 0 || small < pf_min_bytes()) return;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > MAXT) n_threads = MAXT;
+    const size_t bytes = ((small + small / 16 + ((size_t)1 << 20)) + PF_HUGE - 1) & ~(PF_HUGE - 1);
+    char *map = (char *)mmap(NULL, bytes + PF_HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (map == MAP_FAILED) return;
+    pf->map = map;
+    pf->map_bytes = bytes + PF_HUGE;
+    pf->slab = (char *)(((uintptr_t)map + PF_HUGE - 1) & ~(uintptr_t)(PF_HUGE - 1));
+    pf->slab_bytes = bytes;
+    (void)madvise(pf->slab, bytes, MADV_HUGEPAGE);
+    pf_touch_t w[MAXT];
+    for (int t = 0; t < n_threads; ++t) {
+        w[t].base = pf->slab;
+        w[t].lo = (bytes / 4096 * (size_t)t / (size_t)n_threads) * 4096;
+        w[t].hi = (bytes / 4096 * (size_t)(t + 1) / (size_t)n_threads) * 4096;
+    }
+    Py_BEGIN_ALLOW_THREADS
+    run_workers(pf_touch, w, sizeof(w[0]), n_threads);
+    Py_END_ALLOW_THREADS
+    if (g_prefault) {                                                       /* somebody else got here while the GIL was away */
+        munmap(pf->map, pf->map_bytes);
+        pf->map = NULL;
+        return;
+    }
+    PyObject_GetArenaAllocator(&pf->orig);
+    PyObjectArenaAllocator mine = {pf, pf_arena_alloc, pf_arena_free};
+    PyObject_SetArenaAllocator(&mine);
+    g_prefault = pf;
+    pf->arena_on = 1;
+}
+
+static void prefault_end(prefault_t *pf) {
+    if (!pf->arena_on) return;
+    PyObject_SetArenaAllocator(&pf->orig);
+    g_prefault = NULL;
+    pf->arena_on = 0;
+    char *used_end = pf->slab + ((pf->slab_next + 4095) & ~(size_t)4095), *map_end = pf->map + pf->map_bytes;
+    if (pf->slab > pf->map) munmap(pf->map, (size_t)(pf->slab - pf->map));
+    if (map_end > used_end) munmap(used_end, (size_t)(map_end - used_end));
+    pf->map = NULL;
+}
+
 static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     const int64_t n = w->n;
     if (n == 0) return 0;
@@ -372,6 +486,18 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     }
     const int two_phases = sample_n > 0 && sample_bytes / sample_n >= 464;
     const int want_fillers = two_phases ? 0 : (n_threads - 1 < 6 ? n_threads - 1 : 6);
+    prefault_t pf;
+    {
+        size_t small = 0;
+        if (pf_enabled() && !two_phases && (n >= 65536 || pf_min_bytes() == 0))
+            for (int64_t i = 0; i < n; ++i) {
+                if ((w->na && w->na[i]) || (w->ascii && !w->ascii[i])) continue;
+                int64_t k;
+                (void)vtext(w, i, &k);
+                pf_count(k, &small);
+            }
+        prefault_begin(&pf, small, n_threads);
+    }
     for (int t = 0; t < want_fillers; ++t)
         if (pthread_create(&th[fillers], NULL, vworker, w) == 0) ++fillers;
     for (int64_t i = 0; i < n; ++i) {
@@ -386,6 +512,7 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
         made = i + 1;
         if ((made & (w->chunk - 1)) == 0) __atomic_store_n(&w->ready, made, __ATOMIC_RELEASE);
     }
+    prefault_end(&pf);
     if (failed) __atomic_store_n(&w->abort_fill, 1, __ATOMIC_RELAXED);
     else __atomic_store_n(&w->ready, n, __ATOMIC_RELEASE);
     Py_BEGIN_ALLOW_THREADS
@@ -440,15 +567,25 @@ static PyObject *alloc_strs(PyObject *self, PyObject *args) {
         vrun_all(&w, n_threads, 0);
         Py_END_ALLOW_THREADS
     }
+    prefault_t pf;
+    {
+        size_t small = 0;
+        if (pf_enabled() && (n >= 65536 || pf_min_bytes() == 0))
+            for (Py_ssize_t i = 0; i < n; ++i)
+                if (!w.ascii || w.ascii[i]) pf_count(w.len[i], &small);
+        prefault_begin(&pf, small, n_threads);
+    }
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject *o = (!w.ascii || w.ascii[i]) ? PyUnicode_New((Py_ssize_t)w.len[i], 127)
                                                : PyUnicode_DecodeUTF8(w.ptr[i], (Py_ssize_t)w.len[i], "strict");
         if (!o) {
+            prefault_end(&pf);
             for (Py_ssize_t j = 0; j < i; ++j) { Py_DECREF(w.objs[j]); w.objs[j] = NULL; }
             return NULL;
         }
         w.objs[i] = o;
     }
+    prefault_end(&pf);
     Py_RETURN_NONE;
 }
 

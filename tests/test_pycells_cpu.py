@@ -199,3 +199,41 @@ def test_strings_allocated_first_and_written_later():
     seq4, asc4 = pycells.alloc_strings(ptr, lens)                     # released unwritten: nothing reads the text of a dying str
     del seq4, asc4
     gc.collect()
+
+
+def test_small_strings_from_prepared_arenas(monkeypatch):
+    """the builders take pymalloc's new arenas from a slab they mapped, advised as huge pages and touched on all cores
+    (csrc/pyhelpers.c prefault_begin; from 4 MB of strings on, here from the first byte): the strings are the same strings, the
+    default arena allocator is back afterwards (ordinary objects come and go), freeing the strings unmaps the slab's arenas like
+    any others, and the address space does not grow over repeated rounds"""
+    import resource
+
+    monkeypatch.setenv("DYD_PREFAULT_MIN_MB", "0")
+    rng = np.random.default_rng(9)
+    texts = _texts(150_000, rng, big_every=13)
+    ptr, lens, keep, _, raw = _views(texts)
+    slot = rng.permutation(len(texts))
+
+    def vm_size():
+        for line in open("/proc/self/status"):
+            if line.startswith("VmSize:"):
+                return int(line.split()[1])
+        return 0
+
+    sizes = []
+    for rnd in range(6):
+        monkeypatch.setenv("DYD_PREFAULT", "0" if rnd == 3 else "1")
+        a = pycells.strings_from_views(ptr, lens, None, slot=slot)
+        seq, asc = pycells.alloc_strings(ptr, lens)
+        b = pycells.fill_strings(ptr, lens, seq, asc)
+        want = [None] * len(texts)
+        for i, k in enumerate(slot.tolist()):
+            want[k] = texts[i]
+        assert a.tolist() == want and b.tolist() == texts
+        junk = [str(i) * 3 for i in range(200_000)]                     # ordinary allocations after the builders: pymalloc's own arenas
+        assert junk[777] == "777777777"
+        del a, b, seq, junk, want
+        gc.collect()
+        sizes.append(vm_size())
+    assert max(sizes[2:]) - min(sizes[2:]) < 400_000                    # kB: no slab is left mapped round after round
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss > 0
