@@ -383,11 +383,12 @@ class SplitExpansion:
     buffers (``rec_ptr`` / ``rec_len``: one view per record) until ``close()`` — ``record_strings`` turns them into str objects, in
     any order, without a flat copy of the text in between."""
 
-    def __init__(self, handle, n_cells, string_threads: int = 0):
+    def __init__(self, handle, n_cells, string_threads: int = 0, late_text: bool = False):
         L = _native.load_library()
         self._h = handle
         self.n_cells = n_cells
         self._string_threads = string_threads                     # for the per-cell strings (combo, reasons) made right here
+        self._late = [] if late_text else None                    # (ptr, len, seq, ascii) of strings allocated now and written by finish_text()
         self.status = _view(L.dyd_split_status(handle), np.uint8, n_cells).copy()
         self.n_expanded = _view(L.dyd_split_n_expanded(handle), np.int32, n_cells).copy()
         rows, events = int(L.dyd_split_rows(handle)), int(L.dyd_split_events(handle))
@@ -422,7 +423,23 @@ class SplitExpansion:
         if count == 0:
             return np.empty(0, object)
         text, off = self._buffers(which, count)
+        if self._late is not None:
+            from . import pycells
+            if pycells.available() and count >= pycells.MIN_THREADED // 16:    # allocate now (the GIL's part), write later on all cores
+                ptr = (off[:-1] + (text.ctypes.data if len(text) else 0)).astype(np.uint64)
+                length = np.diff(off)
+                seq, asc = pycells.alloc_strings(ptr, length)
+                self._late.append((ptr, length, seq, asc))
+                return seq
         return strings_from_buffers(text, off, n_threads=self._string_threads)
+
+    def finish_text(self):
+        """writes the text of the per-cell strings that were only allocated so far (``late_text``); the handle must still be open"""
+        from . import pycells
+
+        late, self._late = self._late, None
+        for ptr, length, seq, asc in late or ():
+            pycells.fill_strings(ptr, length, seq, asc)
 
     def label_stats(self, n_labels: int):
         """per label of the rules: (index of the first record carrying it or -1, number of records)"""
@@ -654,7 +671,7 @@ def split_expand_views_batched(ptr: np.ndarray, length: np.ndarray, missing: np.
         for lo, hi in bounds:
             rc, h = ready.get()
             _native.check(rc, "dyd_json_split_expand_v")
-            part = SplitExpansion(h, hi - lo, string_threads=1)    # (the cores are parsing the next batch: no helper threads here)
+            part = SplitExpansion(h, hi - lo, string_threads=1, late_text=allocate)   # (the cores are parsing the next batch)
             parts.append(part)
             if allocate:
                 shells.append(pycells.alloc_strings(part.rec_ptr, part.rec_len, part.all_ascii))
@@ -670,6 +687,8 @@ def split_expand_views_batched(ptr: np.ndarray, length: np.ndarray, missing: np.
             part.close()
         raise
     worker.join()
+    for part in parts:
+        part.finish_text()
     return SplitExpansionBatches(parts, bounds, shells if allocate else None)
 
 
