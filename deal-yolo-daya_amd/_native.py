@@ -145,6 +145,9 @@ SIGNATURES = {
     "dyd_split_label_count": (C.c_void_p, [C.c_void_p]),
     "dyd_split_fast_cells": (C.c_int64, [C.c_void_p]),
     "dyd_split_all_ascii": (C.c_int, [C.c_void_p]),
+    "dyd_split_reason_code": (C.c_void_p, [C.c_void_p]),
+    "dyd_split_reason_distinct": (C.c_int64, [C.c_void_p]),
+    "dyd_split_reason_first": (C.c_void_p, [C.c_void_p]),
     "dyd_split_seconds": (None, [C.c_void_p, C.c_void_p]),
     "dyd_json_relabel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_int, C.POINTER(C.c_void_p)]),

@@ -1982,6 +1982,8 @@ struct dyd_split {
     Raw<uint8_t> ev_kind;
     Raw<char> combo, reasons;
     std::vector<int64_t> combo_off, reasons_off;
+    std::vector<int32_t> reason_code;      // per cell: index of its reasons text among the distinct ones (-1: none); empty: not made
+    std::vector<int64_t> reason_first;     // per distinct reasons text the first cell carrying it
     std::vector<std::string> undef_names;               // distinct undefined labels, first-appearance order over the parts
     std::string undef_text;
     std::vector<int64_t> undef_off;
@@ -2131,6 +2133,26 @@ int split_expand_src(const CellSrc &src, const uint8_t *missing, int64_t n_cells
                 pt.ev_code.clear_free(); pt.combo.clear_free(); pt.reasons.clear_free();
             }))
             throw std::bad_alloc();
+        {   // The reasons repeat (they name the undefined labels of a row): a code per cell and the first cell of every distinct
+            // text let the caller build each distinct str ONCE (they are Chinese: a decode per cell otherwise).  Given up beyond
+            // 4096 distinct texts (reason_code stays empty: the caller makes the strings cell by cell).
+            h->reason_code.assign((size_t)n_cells, -1);
+            std::unordered_map<std::string_view, int32_t> seen;
+            bool ok = true;
+            for (int64_t i = 0; i < n_cells && ok; ++i) {
+                const int64_t a = h->reasons_off[(size_t)i], b = h->reasons_off[(size_t)i + 1];
+                if (b == a) continue;
+                const std::string_view sv(h->reasons.p + a, (size_t)(b - a));
+                auto it = seen.find(sv);
+                if (it == seen.end()) {
+                    if (h->reason_first.size() >= 4096) { ok = false; break; }
+                    it = seen.emplace(sv, (int32_t)h->reason_first.size()).first;
+                    h->reason_first.push_back(i);
+                }
+                h->reason_code[(size_t)i] = it->second;
+            }
+            if (!ok) { h->reason_code.clear(); h->reason_first.clear(); }
+        }
         const auto T2 = std::chrono::steady_clock::now();
         h->t_parse = std::chrono::duration<double>(T1 - T0).count();
         h->t_gather = std::chrono::duration<double>(T2 - T1).count();
@@ -2184,6 +2206,9 @@ const int64_t *dyd_split_label_first(const dyd_split *h) { return h->label_first
 const int64_t *dyd_split_label_count(const dyd_split *h) { return h->label_count.data(); }
 int64_t dyd_split_fast_cells(const dyd_split *h) { return h->fast_cells; }
 int dyd_split_all_ascii(const dyd_split *h) { return h->all_ascii ? 1 : 0; }
+const int32_t *dyd_split_reason_code(const dyd_split *h) { return h->reason_code.empty() ? nullptr : h->reason_code.data(); }
+int64_t dyd_split_reason_distinct(const dyd_split *h) { return (int64_t)h->reason_first.size(); }
+const int64_t *dyd_split_reason_first(const dyd_split *h) { return h->reason_first.data(); }
 void dyd_split_seconds(const dyd_split *h, double *parse_gather2) {
     if (h && parse_gather2) { parse_gather2[0] = h->t_parse; parse_gather2[1] = h->t_gather; }
 }

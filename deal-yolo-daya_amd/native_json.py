@@ -408,7 +408,7 @@ class SplitExpansion:
         L.dyd_split_seconds(handle, secs.ctypes.data)
         self.seconds = {"parse": float(secs[0]), "gather": float(secs[1])}
         self.combo = self._strings(1, n_cells)
-        self.reasons = self._strings(2, n_cells)
+        self.reasons = self._reason_strings(n_cells)
         self.reasons_nonempty = np.diff(self._buffers(2, n_cells)[1]) > 0 if n_cells else np.zeros(0, bool)
         self.undefined = self._strings(4, int(L.dyd_split_undefined(handle)))      # distinct labels event_code indexes
         self._n_labels = None
@@ -432,6 +432,28 @@ class SplitExpansion:
                 self._late.append((ptr, length, seq, asc))
                 return seq
         return strings_from_buffers(text, off, n_threads=self._string_threads)
+
+    def _reason_strings(self, count) -> np.ndarray:
+        """per cell its joined reasons ("" for none): one str per DISTINCT text, shared by the cells that carry it — the texts name a
+        row's undefined labels, so a table holds a handful of them (they are Chinese: a decode each otherwise)"""
+        L = _native.load_library()
+        codes_ptr = L.dyd_split_reason_code(self._h) if count else None
+        if not codes_ptr:
+            return self._strings(2, count)
+        from . import pycells
+
+        n_distinct = int(L.dyd_split_reason_distinct(self._h))
+        codes = _view(codes_ptr, np.int32, count)
+        first = _view(L.dyd_split_reason_first(self._h), np.int64, n_distinct)
+        text, off = self._buffers(2, count)
+        table = np.empty(n_distinct + 1, object)
+        for k, cell in enumerate(first.tolist()):
+            table[k] = bytes(text[off[cell]:off[cell + 1]]).decode("utf-8")
+        table[n_distinct] = ""
+        codes = np.where(codes < 0, n_distinct, codes).astype(np.int32)
+        if pycells.available():
+            return pycells.take_small(table, codes, n_threads=self._string_threads)
+        return table[codes]
 
     def finish_text(self):
         """writes the text of the per-cell strings that were only allocated so far (``late_text``); the handle must still be open"""

@@ -363,6 +363,12 @@ const int64_t *dyd_split_label_first(const dyd_split *h);     /* [n_labels] */
 const int64_t *dyd_split_label_count(const dyd_split *h);     /* [n_labels] */
 int64_t dyd_split_fast_cells(const dyd_split *h);             /* cells the single-parse lane took */
 int dyd_split_all_ascii(const dyd_split *h);                  /* 1: every record text is pure ASCII */
+/* The reasons of a table are few distinct texts (they name a row's undefined labels): per cell the index of its text among the
+ * distinct ones (-1: no reasons), or NULL when there were more than 4096 of them; their number; per distinct text the first cell
+ * carrying it (its bytes are dyd_split_strings(h, 2) at that cell). */
+const int32_t *dyd_split_reason_code(const dyd_split *h);
+int64_t dyd_split_reason_distinct(const dyd_split *h);
+const int64_t *dyd_split_reason_first(const dyd_split *h);
 void dyd_split_seconds(const dyd_split *h, double *parse_gather2);
 void dyd_split_free(dyd_split *h);
 
