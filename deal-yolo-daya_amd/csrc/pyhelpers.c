@@ -248,6 +248,52 @@ static inline int text_is_ascii(const unsigned char *s, int64_t n) {
     return !(acc & 0x8080808080808080ull);
 }
 
+/* Class of a UTF-8 text for the builders: 1 = ASCII; 2 = its widest character lies in U+0100..U+FFFF (Chinese labels and
+ * separators: a 2-byte str whose characters the workers can write), *nch = its number of characters; 0 = anything else (Latin-1
+ * only, or beyond the BMP, or too long): decoded by CPython on the calling thread.  The class must be exact — CPython keeps every
+ * str in the narrowest form that holds it and compares forms before contents. */
+static inline uint8_t text_class(const unsigned char *s, int64_t n, int32_t *nch) {
+    if (text_is_ascii(s, n)) return 1;
+    int64_t chars = 0;
+    unsigned wide = 0, four = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const unsigned c = s[j];
+        chars += (c & 0xC0u) != 0x80u;
+        wide |= (unsigned)(c >= 0xC4u) & (unsigned)(c <= 0xEFu);
+        four |= (unsigned)(c >= 0xF0u);
+    }
+    if (four || !wide || chars > 0x7fffffff) return 0;
+    *nch = (int32_t)chars;
+    return 2;
+}
+
+/* strict UTF-8 -> UCS-2 for a text of class 2 into exactly nch units: 0, or -1 for anything CPython's strict decoder would refuse
+ * (or that does not come to nch characters) — the caller then lets CPython decode that text and raise what it raises */
+static inline int utf8_to_ucs2(const unsigned char *s, int64_t n, Py_UCS2 *d, int64_t nch) {
+    int64_t j = 0, k = 0;
+    while (j < n) {
+        const unsigned c = s[j];
+        if (k >= nch) return -1;
+        if (c < 0x80u) { d[k++] = (Py_UCS2)c; ++j; continue; }
+        if (c >= 0xC2u && c <= 0xDFu) {
+            if (j + 1 >= n || (s[j + 1] & 0xC0u) != 0x80u) return -1;
+            d[k++] = (Py_UCS2)(((c & 0x1Fu) << 6) | (s[j + 1] & 0x3Fu));
+            j += 2;
+            continue;
+        }
+        if (c >= 0xE0u && c <= 0xEFu) {
+            if (j + 2 >= n || (s[j + 1] & 0xC0u) != 0x80u || (s[j + 2] & 0xC0u) != 0x80u) return -1;
+            const unsigned cp = ((c & 0x0Fu) << 12) | ((s[j + 1] & 0x3Fu) << 6) | (s[j + 2] & 0x3Fu);
+            if (cp < 0x800u || (cp >= 0xD800u && cp <= 0xDFFFu)) return -1;
+            d[k++] = (Py_UCS2)cp;
+            j += 3;
+            continue;
+        }
+        return -1;
+    }
+    return k == nch ? 0 : -1;
+}
+
 /* The str builder.  Text k is given either as a view (ptr[k], len[k]) or as base[off[k] .. off[k+1]); element i of the walk
  * takes text k = idx[i] (idx absent: k = i) and its str goes to objs[slot[i]] (slot absent: i); na[i] != 0 skips the element
  * (its slot keeps what it holds).  The output slots must be fresh (NULL / None).
@@ -268,7 +314,9 @@ typedef struct {
     const uint8_t *na;
     PyObject **objs;             /* the output array */
     PyObject **seq;              /* element i's object, in walk order (== objs when there is no slot) */
-    uint8_t *ascii;              /* per i: 1 = ASCII text (NULL: all are) */
+    uint8_t *ascii;              /* per i: the text's class (text_class: 1 ASCII, 2 BMP, 0 other; 3 = found malformed while filling); NULL: all ASCII */
+    int32_t *nch;                /* per i: characters of a class-2 text (between classification and allocation) */
+    int bad_text;                /* a worker met malformed UTF-8 (that element's class is 3 now) */
     int64_t n;
     int64_t chunk;               /* elements per chunk: a power of two, small enough for every thread to get several */
     int64_t next_chunk;          /* atomic: next chunk a worker takes */
@@ -303,11 +351,18 @@ static void *vworker(void *arg) {
             int64_t n;
             const unsigned char *s = vtext(w, i, &n);
             if (w->mode == 0) {
-                w->ascii[i] = (uint8_t)text_is_ascii(s, n);
+                int32_t chars = 0;
+                w->ascii[i] = text_class(s, n, &chars);
+                if (w->nch) w->nch[i] = chars;
+                else if (w->ascii[i] == 2) w->ascii[i] = 0;
                 continue;
             }
             PyObject *o = w->seq[i];
-            if (!w->ascii || w->ascii[i]) memcpy(PyUnicode_1BYTE_DATA(o), s, (size_t)n);
+            if (!w->ascii || w->ascii[i] == 1) memcpy(PyUnicode_1BYTE_DATA(o), s, (size_t)n);
+            else if (w->ascii[i] == 2 && utf8_to_ucs2(s, n, PyUnicode_2BYTE_DATA(o), (int64_t)PyUnicode_GET_LENGTH(o)) != 0) {
+                w->ascii[i] = 3;
+                __atomic_store_n(&w->bad_text, 1, __ATOMIC_RELAXED);
+            }
             if (w->slot) w->objs[w->slot[i]] = o;
         }
     }
@@ -461,7 +516,14 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     }
     if (!all_ascii) {
         w->ascii = (uint8_t *)PyMem_RawMalloc((size_t)n);
-        if (!w->ascii) { if (w->slot) PyMem_RawFree(w->seq); PyErr_NoMemory(); return -1; }
+        w->nch = (int32_t *)PyMem_RawMalloc((size_t)n * sizeof(int32_t));
+        if (!w->ascii || !w->nch) {
+            if (w->slot) PyMem_RawFree(w->seq);
+            PyMem_RawFree(w->ascii); PyMem_RawFree(w->nch);
+            w->ascii = NULL; w->nch = NULL;
+            PyErr_NoMemory();
+            return -1;
+        }
         Py_BEGIN_ALLOW_THREADS
         vrun_all(w, n_threads, 0);
         Py_END_ALLOW_THREADS
@@ -494,7 +556,8 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
                 if ((w->na && w->na[i]) || (w->ascii && !w->ascii[i])) continue;
                 int64_t k;
                 (void)vtext(w, i, &k);
-                pf_count(k, &small);
+                if (w->ascii && w->ascii[i] == 2) pf_count(24 + 2 * (int64_t)w->nch[i] + 1, &small);   /* 72-byte header, 2 bytes a character */
+                else pf_count(k, &small);
             }
         prefault_begin(&pf, small, n_threads);
     }
@@ -504,8 +567,10 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
         if (!(w->na && w->na[i])) {
             int64_t k;
             const unsigned char *s = vtext(w, i, &k);
-            PyObject *o = (!w->ascii || w->ascii[i]) ? PyUnicode_New((Py_ssize_t)k, 127)
-                                                     : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
+            const int cls = w->ascii ? w->ascii[i] : 1;
+            PyObject *o = cls == 1 ? PyUnicode_New((Py_ssize_t)k, 127)
+                        : cls == 2 ? PyUnicode_New((Py_ssize_t)w->nch[i], 0xFFFF)
+                                   : PyUnicode_DecodeUTF8((const char *)s, (Py_ssize_t)k, "strict");
             if (!o) { failed = 1; break; }
             w->seq[i] = o;
         }
@@ -520,15 +585,29 @@ static int build_strs(vshared_t *w, int n_threads, int all_ascii) {
     else if (!failed) vworker(w);                  /* help with what is left */
     for (int t = 0; t < fillers; ++t) pthread_join(th[t], NULL);
     Py_END_ALLOW_THREADS
+    if (!failed && w->bad_text) {                  /* malformed UTF-8 behind a class-2 text: CPython decodes it and raises what it raises */
+        for (int64_t i = 0; i < n && !failed; ++i) {
+            if ((w->na && w->na[i]) || !w->ascii || w->ascii[i] != 3) continue;
+            int64_t k;
+            const unsigned char *t = vtext(w, i, &k);
+            PyObject *o = PyUnicode_DecodeUTF8((const char *)t, (Py_ssize_t)k, "strict");
+            if (!o) { failed = 1; break; }
+            Py_DECREF(w->seq[i]);                   /* (it decoded after all: that is the string then) */
+            w->seq[i] = o;
+            w->objs[w->slot ? w->slot[i] : i] = o;
+        }
+    }
     if (failed) {                                  /* hand everything back: the array is as fresh as it came */
         for (int64_t i = 0; i < made; ++i) {
             if (w->na && w->na[i]) continue;
+            PyObject *o = w->seq[i];                /* (seq IS objs when there is no slot: read before the slot is cleared) */
             w->objs[w->slot ? w->slot[i] : i] = NULL;
-            Py_DECREF(w->seq[i]);
+            Py_XDECREF(o);
         }
     }
     if (w->slot) PyMem_RawFree(w->seq);
     if (w->ascii) { PyMem_RawFree(w->ascii); w->ascii = NULL; }
+    if (w->nch) { PyMem_RawFree(w->nch); w->nch = NULL; }
     return failed ? -1 : 0;
 }
 
@@ -563,6 +642,8 @@ static PyObject *alloc_strs(PyObject *self, PyObject *args) {
     }
     if (!all_ascii) {
         w.ascii = (uint8_t *)(uintptr_t)a_ascii;
+        w.nch = (int32_t *)PyMem_RawMalloc((size_t)n * sizeof(int32_t));
+        if (!w.nch) return PyErr_NoMemory();
         Py_BEGIN_ALLOW_THREADS
         vrun_all(&w, n_threads, 0);
         Py_END_ALLOW_THREADS
@@ -571,21 +652,27 @@ static PyObject *alloc_strs(PyObject *self, PyObject *args) {
     {
         size_t small = 0;
         if (pf_enabled() && (n >= 65536 || pf_min_bytes() == 0))
-            for (Py_ssize_t i = 0; i < n; ++i)
-                if (!w.ascii || w.ascii[i]) pf_count(w.len[i], &small);
+            for (Py_ssize_t i = 0; i < n; ++i) {
+                if (!w.ascii || w.ascii[i] == 1) pf_count(w.len[i], &small);
+                else if (w.ascii[i] == 2) pf_count(24 + 2 * (int64_t)w.nch[i] + 1, &small);
+            }
         prefault_begin(&pf, small, n_threads);
     }
     for (Py_ssize_t i = 0; i < n; ++i) {
-        PyObject *o = (!w.ascii || w.ascii[i]) ? PyUnicode_New((Py_ssize_t)w.len[i], 127)
-                                               : PyUnicode_DecodeUTF8(w.ptr[i], (Py_ssize_t)w.len[i], "strict");
+        const int cls = w.ascii ? w.ascii[i] : 1;
+        PyObject *o = cls == 1 ? PyUnicode_New((Py_ssize_t)w.len[i], 127)
+                    : cls == 2 ? PyUnicode_New((Py_ssize_t)w.nch[i], 0xFFFF)
+                               : PyUnicode_DecodeUTF8(w.ptr[i], (Py_ssize_t)w.len[i], "strict");
         if (!o) {
             prefault_end(&pf);
             for (Py_ssize_t j = 0; j < i; ++j) { Py_DECREF(w.objs[j]); w.objs[j] = NULL; }
+            PyMem_RawFree(w.nch);
             return NULL;
         }
         w.objs[i] = o;
     }
     prefault_end(&pf);
+    PyMem_RawFree(w.nch);
     Py_RETURN_NONE;
 }
 
@@ -595,13 +682,17 @@ typedef struct {
     PyObject **seq, **out;
     const uint8_t *ascii;
     int64_t lo, hi;
+    int64_t bad;                 /* -1, or the first element whose class-2 text turned out malformed */
 } fillw_t;
 
 static void *fill_worker(void *arg) {
     fillw_t *w = (fillw_t *)arg;
+    w->bad = -1;
     for (int64_t i = w->lo; i < w->hi; ++i) {
         PyObject *o = w->seq[i];
-        if (!w->ascii || w->ascii[i]) memcpy(PyUnicode_1BYTE_DATA(o), w->ptr[i], (size_t)w->len[i]);
+        if (!w->ascii || w->ascii[i] == 1) memcpy(PyUnicode_1BYTE_DATA(o), w->ptr[i], (size_t)w->len[i]);
+        else if (w->ascii[i] == 2 && utf8_to_ucs2((const unsigned char *)w->ptr[i], w->len[i], PyUnicode_2BYTE_DATA(o), (int64_t)PyUnicode_GET_LENGTH(o)) != 0 && w->bad < 0)
+            w->bad = i;
         if (w->out) {
             w->out[w->slot ? w->slot[i] : i] = o;
             w->seq[i] = NULL;
@@ -644,6 +735,12 @@ static PyObject *fill_strs(PyObject *self, PyObject *args) {
     Py_BEGIN_ALLOW_THREADS
     run_workers(fill_worker, w, sizeof(w[0]), n_threads);
     Py_END_ALLOW_THREADS
+    for (int t = 0; t < n_threads; ++t)
+        if (w[t].bad >= 0) {                           /* malformed UTF-8: CPython's decoder says what is wrong with it */
+            PyObject *o = PyUnicode_DecodeUTF8(w[t].ptr[w[t].bad], (Py_ssize_t)w[t].len[w[t].bad], "strict");
+            if (o) { Py_DECREF(o); PyErr_SetString(PyExc_ValueError, "fill_strs: a text changed between alloc_strs and fill_strs"); }
+            return NULL;
+        }
     Py_RETURN_NONE;
 }
 

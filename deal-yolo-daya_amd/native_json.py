@@ -428,7 +428,7 @@ class SplitExpansion:
             if pycells.available() and count >= pycells.MIN_THREADED // 16:    # allocate now (the GIL's part), write later on all cores
                 ptr = (off[:-1] + (text.ctypes.data if len(text) else 0)).astype(np.uint64)
                 length = np.diff(off)
-                seq, asc = pycells.alloc_strings(ptr, length)
+                seq, asc = pycells.alloc_strings(ptr, length, n_threads=max(1, self._string_threads))   # (short texts: no helper threads)
                 self._late.append((ptr, length, seq, asc))
                 return seq
         return strings_from_buffers(text, off, n_threads=self._string_threads)

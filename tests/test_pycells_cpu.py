@@ -21,11 +21,26 @@ def _views(texts):
     return (buf.ctypes.data + off[:-1]).astype(np.uint64), lens, buf, off, raw
 
 
+def _text_class(t):
+    """csrc/pyhelpers.c text_class: 1 ASCII, 2 widest character in U+0100..U+FFFF (written by the workers as a 2-byte str), 0 else"""
+    if t.isascii():
+        return 1
+    return 2 if 0xFF < max(map(ord, t)) <= 0xFFFF else 0
+
+
 def _texts(n, rng, big_every=11):
     out = []
     for i in range(n):
         if i % 97 == 5:
             out.append("中文，标签；" * (i % 5 + 1))
+        elif i % 97 == 6:
+            out.append(("c%d，c%d，猫%d" % (i, i + 1, i)) * (i % 3 + 1))          # ASCII with BMP separators: the label combos
+        elif i % 211 == 9:
+            out.append("café crème %d" % i)                                       # Latin-1 only: a 1-byte non-ASCII str (CPython decodes)
+        elif i % 211 == 10:
+            out.append("emoji \U0001F600 %d ，" % i)                              # beyond the BMP (CPython decodes)
+        elif i % 211 == 11:
+            out.append("é，\u07ff\u0800\uffff%d" % i)                            # 2- and 3-byte sequences at their boundaries
         elif i % 53 == 7:
             out.append("")
         elif i % big_every == 0:
@@ -174,7 +189,7 @@ def test_strings_allocated_first_and_written_later():
     texts = _texts(90_000, rng)
     ptr, lens, keep, _, raw = _views(texts)
     seq, asc = pycells.alloc_strings(ptr, lens)
-    assert asc.tolist() == [t.isascii() for t in texts]
+    assert asc.tolist() == [_text_class(t) for t in texts]
     slot = rng.permutation(len(texts))
     out = np.empty(len(texts), object)
     got = pycells.fill_strings(ptr, lens, seq, asc, slot, out)
@@ -237,3 +252,31 @@ def test_small_strings_from_prepared_arenas(monkeypatch):
         sizes.append(vm_size())
     assert max(sizes[2:]) - min(sizes[2:]) < 400_000                    # kB: no slab is left mapped round after round
     assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss > 0
+
+
+def test_malformed_utf8_raises_what_cpython_raises():
+    """texts whose class says "2-byte str" but whose bytes are not UTF-8 (truncated sequence, surrogate, overlong form, stray
+    continuation byte): the builders let CPython decode that text, i.e. raise its UnicodeDecodeError, and leave nothing behind"""
+    good = ["标签，c%d" % i for i in range(70_000)]
+    for bad in (b"\xe4\xb8", b"ok\xed\xa0\x80\xe4\xb8\xad", b"\xe0\x80\xaf\xe4\xb8\xad", b"\xe4\xb8\xad\x80x", b"\xe4\xb8\xad\xc4"):
+        raw = [t.encode("utf-8") for t in good]
+        raw[31_337] = bad
+        buf = np.frombuffer(b"".join(raw), np.uint8)
+        lens = np.array([len(r) for r in raw], np.int64)
+        off = np.zeros(len(raw) + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        ptr = (buf.ctypes.data + off[:-1]).astype(np.uint64)
+        with pytest.raises(UnicodeDecodeError):
+            bad.decode("utf-8")
+        with pytest.raises(UnicodeDecodeError):
+            pycells.strings_from_views(ptr, lens)
+        with pytest.raises(UnicodeDecodeError):
+            pycells.strings(buf, off)
+        try:
+            seq, asc = pycells.alloc_strings(ptr, lens)
+        except UnicodeDecodeError:
+            continue                                                      # (classified 0: CPython decoded it at once)
+        with pytest.raises(UnicodeDecodeError):
+            pycells.fill_strings(ptr, lens, seq, asc)
+        del seq
+        gc.collect()
