@@ -280,3 +280,43 @@ def test_malformed_utf8_raises_what_cpython_raises():
             pycells.fill_strings(ptr, lens, seq, asc)
         del seq
         gc.collect()
+
+
+def test_builders_from_several_python_threads(monkeypatch):
+    """two Python threads building strings at once (the GIL changes hands while pages are touched and while workers copy): one of
+    them gets the prepared arenas, the other allocates the ordinary way; both get their strings, and ordinary allocations by a third
+    thread go on meanwhile"""
+    import threading
+
+    monkeypatch.setenv("DYD_PREFAULT_MIN_MB", "0")
+    rng = np.random.default_rng(10)
+    texts = _texts(200_000, rng, big_every=17)
+    ptr, lens, keep, _, raw = _views(texts)
+    results, errors, stop = {}, [], threading.Event()
+
+    def build(tag):
+        try:
+            for _ in range(3):
+                a = pycells.strings_from_views(ptr, lens)
+                seq, asc = pycells.alloc_strings(ptr, lens)
+                b = pycells.fill_strings(ptr, lens, seq, asc)
+                results[tag] = a.tolist() == texts and b.tolist() == texts
+                del a, b, seq
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    def churn():
+        while not stop.is_set():
+            junk = [("k%d" % i) * 4 for i in range(20_000)]
+            del junk
+
+    third = threading.Thread(target=churn)
+    third.start()
+    workers = [threading.Thread(target=build, args=(k,)) for k in range(2)]
+    for t in workers:
+        t.start()
+    for t in workers:
+        t.join()
+    stop.set()
+    third.join()
+    assert not errors and results == {0: True, 1: True}
