@@ -413,6 +413,7 @@ typedef struct {
 } prefault_t;
 
 static prefault_t *g_prefault = NULL;  /* the slab the installed arena allocator serves from (touched under the GIL only) */
+static int g_prefault_off = 0;         /* set when preparing turned out slower than what it saves (see prefault_begin) */
 
 typedef struct { char *base; size_t lo, hi; } pf_touch_t;
 static void *pf_touch(void *arg) {
@@ -452,7 +453,7 @@ static inline void pf_count(int64_t len, size_t *small) {
 /* GIL held (released while the pages are touched) */
 static void prefault_begin(prefault_t *pf, size_t small, int n_threads) {
     memset(pf, 0, sizeof(*pf));
-    if (!pf_enabled() || g_prefault || small == 0 || small < pf_min_bytes()) return;
+    if (!pf_enabled() || g_prefault_off || g_prefault || small == 0 || small < pf_min_bytes()) return;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > MAXT) n_threads = MAXT;
     const size_t bytes = ((small + small / 16 + ((size_t)1 << 20)) + PF_HUGE - 1) & ~(PF_HUGE - 1);
@@ -469,9 +470,17 @@ static void prefault_begin(prefault_t *pf, size_t small, int n_threads) {
         w[t].lo = (bytes / 4096 * (size_t)t / (size_t)n_threads) * 4096;
         w[t].hi = (bytes / 4096 * (size_t)(t + 1) / (size_t)n_threads) * 4096;
     }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     Py_BEGIN_ALLOW_THREADS
     run_workers(pf_touch, w, sizeof(w[0]), n_threads);
     Py_END_ALLOW_THREADS
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    /* where huge pages have to be made by compacting a fragmented machine first, touching can take longer than the faults it was
+     * meant to save (seen once: 1.7 s for 640 MB on a long-running 64 GB container, against 0.03 s afterwards): below 1 GB/s on a
+     * slab of 64 MB or more the preparation is switched off for the rest of the process */
+    const double touch_s = (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    if (bytes >= ((size_t)64 << 20) && touch_s > (double)bytes / 1e9) g_prefault_off = 1;
     if (g_prefault) {                                                       /* somebody else got here while the GIL was away */
         munmap(pf->map, pf->map_bytes);
         pf->map = NULL;
